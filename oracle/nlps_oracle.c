@@ -1,0 +1,1333 @@
+/*
+ * nlps_oracle.c — CPU ORACLE (test infrastructure only; see nlps_oracle.h header note).
+ * PARITY UNPINNED: plain-C restatement of the reference algorithm, pinned by no reference-run
+ * output (the reference needs <lapacke.h>/LAPACK, absent here) — see DESIGN.md.
+ *
+ * Every function cites the reference file:line (relative to /root/reference/nl-partsol/src) it
+ * follows.  Loop orders, operand orders and comparison operators follow the reference so that
+ * integer results (I0, neighbour lists, masks) are what the reference would produce.
+ */
+#include "nlps_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TOL_NR 10E-6 /* Macros.h:40 */
+#define PI_MATRIXLIB 3.14159265358979323846 /* Macros.h:42 */
+
+/* DSQR, Macros.h:49-50: (a == 0 ? 0 : a*a) */
+static inline double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ======================================================================================
+ * Mesh: structured Q4/H8 grid whose neighbour tables are produced with the list semantics of
+ * InOutFun/Read_GramsBox.c:293-507, Nodes/Read-GID-Mesh.c:406-416 and Matlib/ChainOp.c:163-293.
+ * Canonical numbering (the build's synthetic meshes): nodes x-fastest, elements x-fastest,
+ * GiD connectivity order (Q4 counter-clockwise; H8 bottom face ccw then top face ccw).
+ * ====================================================================================== */
+
+typedef struct {
+  int ndim, n[3], nc[3];
+} grid_t;
+
+static inline int node_id(const grid_t *g, int i, int j, int k) {
+  return i + g->n[0] * (j + g->n[1] * k);
+}
+
+/* Connectivity chain of element (ci,cj,ck): file order pushed one by one => chain is the reverse
+ * (Read-GID-Mesh.c:411-413, ChainOp.c:163-182). */
+static int element_chain(const grid_t *g, int ci, int cj, int ck, int *out) {
+  int file[8], nn;
+  if (g->ndim == 2) {
+    file[0] = node_id(g, ci, cj, 0);
+    file[1] = node_id(g, ci + 1, cj, 0);
+    file[2] = node_id(g, ci + 1, cj + 1, 0);
+    file[3] = node_id(g, ci, cj + 1, 0);
+    nn = 4;
+  } else {
+    for (int t = 0; t < 2; t++) {
+      file[4 * t + 0] = node_id(g, ci, cj, ck + t);
+      file[4 * t + 1] = node_id(g, ci + 1, cj, ck + t);
+      file[4 * t + 2] = node_id(g, ci + 1, cj + 1, ck + t);
+      file[4 * t + 3] = node_id(g, ci, cj + 1, ck + t);
+    }
+    nn = 8;
+  }
+  for (int a = 0; a < nn; a++) out[a] = file[nn - 1 - a];
+  return nn;
+}
+
+static int in_list(const int *v, int n, int x) {
+  for (int i = 0; i < n; i++)
+    if (v[i] == x) return 1;
+  return 0;
+}
+
+/* node_I_locality, Read_GramsBox.c:371-400: union (ChainOp.c:275-293) of the connectivity chains
+ * of the elements around node I, the elements taken in NodeNeighbour chain order.  NodeNeighbour[I]
+ * is filled by pushing element indices in ascending order (Read_GramsBox.c:293-330), so its chain
+ * order is DESCENDING element index.  Returns the result in chain order (front first). */
+static int node_locality(const grid_t *g, int I, int *out) {
+  int i = I % g->n[0], j = (I / g->n[0]) % g->n[1], k = I / (g->n[0] * g->n[1]);
+  int push[32], np = 0;
+  int klo = g->ndim == 3 ? k : 0, khi = g->ndim == 3 ? k - 1 : 0;
+  /* descending element index: ck from high to low, cj high to low, ci high to low */
+  for (int ck = klo; ck >= khi; ck--) {
+    if (g->ndim == 3 && (ck < 0 || ck >= g->nc[2])) continue;
+    for (int cj = j; cj >= j - 1; cj--) {
+      if (cj < 0 || cj >= g->nc[1]) continue;
+      for (int ci = i; ci >= i - 1; ci--) {
+        if (ci < 0 || ci >= g->nc[0]) continue;
+        int ch[8];
+        int nn = element_chain(g, ci, cj, ck, ch);
+        for (int a = 0; a < nn; a++)
+          if (!in_list(push, np, ch[a])) push[np++] = ch[a];
+      }
+    }
+  }
+  for (int a = 0; a < np; a++) out[a] = push[np - 1 - a];
+  return np;
+}
+
+/* fill_nodal_locality with 2 rings + ring_search_nodal_locality, Read_GramsBox.c:334-456. */
+static int node_two_ring(const grid_t *g, int I, int *out) {
+  int S[ORC_MAXNB], ns = 0;
+  int search[ORC_MAXNB], nsearch = 1;
+  search[0] = I;
+  for (int ring = 0; ring < 2; ring++) {
+    int newp[ORC_MAXNB], nnew = 0;
+    for (int s = 0; s < nsearch; s++) {
+      int aux[32];
+      int na = node_locality(g, search[s], aux);
+      for (int a = 0; a < na; a++) {
+        if (!in_list(S, ns, aux[a])) {
+          S[ns++] = aux[a];
+          newp[nnew++] = aux[a];
+        }
+      }
+    }
+    for (int a = 0; a < nnew; a++) search[a] = newp[nnew - 1 - a]; /* chain order of new set */
+    nsearch = nnew;
+  }
+  for (int a = 0; a < ns; a++) out[a] = S[ns - 1 - a];
+  return ns;
+}
+
+static inline int axis_class(int i, int n) {
+  if (i < 2) return i;
+  if (i > n - 3) return 4 - (n - 1 - i);
+  return 2;
+}
+
+orc_mesh *orc_mesh_build(int ndim, const int n[3], const double origin[3], double h) {
+  orc_mesh *m = (orc_mesh *)calloc(1, sizeof(orc_mesh));
+  grid_t g;
+  g.ndim = ndim;
+  for (int a = 0; a < 3; a++) {
+    g.n[a] = (a < ndim) ? n[a] : 1;
+    g.nc[a] = (a < ndim) ? n[a] - 1 : 1;
+    m->n[a] = g.n[a];
+    m->origin[a] = (a < ndim) ? origin[a] : 0.0;
+  }
+  m->ndim = ndim;
+  m->h = h;
+  m->nnodes = g.n[0] * g.n[1] * g.n[2];
+  int nn = m->nnodes;
+  m->coords = (double *)malloc(sizeof(double) * nn * ndim);
+  for (int I = 0; I < nn; I++) {
+    int ijk[3] = {I % g.n[0], (I / g.n[0]) % g.n[1], I / (g.n[0] * g.n[1])};
+    for (int a = 0; a < ndim; a++) m->coords[I * ndim + a] = origin[a] + h * (double)ijk[a];
+  }
+  m->r1_ptr = (int *)malloc(sizeof(int) * (nn + 1));
+  m->r2_ptr = (int *)malloc(sizeof(int) * (nn + 1));
+  int cap1 = ndim == 2 ? 9 : 27, cap2 = ndim == 2 ? 25 : 125;
+  m->r1 = (int *)malloc(sizeof(int) * (size_t)nn * cap1);
+  m->r2 = (int *)malloc(sizeof(int) * (size_t)nn * cap2);
+  m->h_avg = (double *)malloc(sizeof(double) * nn);
+  m->active = (unsigned char *)calloc(nn, 1);
+
+  /* Stencils are translation invariant inside one boundary class; cache them as ijk offsets. */
+  int cacheable = 1;
+  for (int a = 0; a < ndim; a++)
+    if (g.n[a] < 5) cacheable = 0;
+  typedef struct {
+    int have, n1, n2;
+    signed char o1[27][3], o2[125][3];
+  } cls_t;
+  cls_t *cache = (cls_t *)calloc(125, sizeof(cls_t));
+
+  int p1 = 0, p2 = 0;
+  for (int I = 0; I < nn; I++) {
+    int ijk[3] = {I % g.n[0], (I / g.n[0]) % g.n[1], I / (g.n[0] * g.n[1])};
+    m->r1_ptr[I] = p1;
+    m->r2_ptr[I] = p2;
+    int key = 0;
+    if (cacheable) {
+      int c[3] = {2, 2, 2};
+      for (int a = 0; a < ndim; a++) c[a] = axis_class(ijk[a], g.n[a]);
+      key = c[0] + 5 * (c[1] + 5 * c[2]);
+    }
+    if (cacheable && cache[key].have) {
+      cls_t *c = &cache[key];
+      for (int a = 0; a < c->n1; a++)
+        m->r1[p1++] = node_id(&g, ijk[0] + c->o1[a][0], ijk[1] + c->o1[a][1], ijk[2] + c->o1[a][2]);
+      for (int a = 0; a < c->n2; a++)
+        m->r2[p2++] = node_id(&g, ijk[0] + c->o2[a][0], ijk[1] + c->o2[a][1], ijk[2] + c->o2[a][2]);
+    } else {
+      int l1[32], l2[ORC_MAXNB];
+      int n1 = node_locality(&g, I, l1);
+      int n2 = node_two_ring(&g, I, l2);
+      for (int a = 0; a < n1; a++) m->r1[p1++] = l1[a];
+      for (int a = 0; a < n2; a++) m->r2[p2++] = l2[a];
+      if (cacheable) {
+        cls_t *c = &cache[key];
+        c->have = 1;
+        c->n1 = n1;
+        c->n2 = n2;
+        for (int a = 0; a < n1; a++) {
+          int J = l1[a];
+          c->o1[a][0] = (signed char)(J % g.n[0] - ijk[0]);
+          c->o1[a][1] = (signed char)((J / g.n[0]) % g.n[1] - ijk[1]);
+          c->o1[a][2] = (signed char)(J / (g.n[0] * g.n[1]) - ijk[2]);
+        }
+        for (int a = 0; a < n2; a++) {
+          int J = l2[a];
+          c->o2[a][0] = (signed char)(J % g.n[0] - ijk[0]);
+          c->o2[a][1] = (signed char)((J / g.n[0]) % g.n[1] - ijk[1]);
+          c->o2[a][2] = (signed char)(J / (g.n[0] * g.n[1]) - ijk[2]);
+        }
+      }
+    }
+  }
+  m->r1_ptr[nn] = p1;
+  m->r2_ptr[nn] = p2;
+  free(cache);
+
+  /* compute_nodal_distance_local, Read_GramsBox.c:460-507: mean distance to the 1-ring
+   * neighbours (self excluded), norm = pow(sum DSQR, 0.5) (MatrixOp.c:843-870). */
+  for (int A = 0; A < nn; A++) {
+    double avg = 0.0;
+    int cnt = 0;
+    for (int q = m->r1_ptr[A]; q < m->r1_ptr[A + 1]; q++) {
+      int B = m->r1[q];
+      if (A != B) {
+        double aux = 0.0;
+        for (int a = 0; a < ndim; a++)
+          aux += dsqr(m->coords[B * ndim + a] - m->coords[A * ndim + a]);
+        avg += pow(aux, 0.5);
+        cnt++;
+      }
+    }
+    m->h_avg[A] = avg / (double)cnt;
+  }
+  return m;
+}
+
+void orc_mesh_free(orc_mesh *m) {
+  if (!m) return;
+  free(m->coords);
+  free(m->r1_ptr);
+  free(m->r1);
+  free(m->r2_ptr);
+  free(m->r2);
+  free(m->h_avg);
+  free(m->active);
+  free(m);
+}
+
+/* ======================================================================================
+ * Small dense algebra replacing LAPACK on <=3x3 (Matlib/MatrixOp.c:320-382 dgetrf/dgetri,
+ * Matlib/TensorLib.c:172-228 dsyev, :829-905 adjunt, :966-990 rcond).
+ * ====================================================================================== */
+
+/* inverse__MatrixLib__ (MatrixOp.c:320): reference = LAPACK LU + dgetri; here closed-form
+ * adjugate/determinant (identical up to rounding).  Row-major n x n, n = 1..3. */
+int orc_inverse(double *Am1, const double *A, int n) {
+  if (n == 1) {
+    if (A[0] == 0.0) return 1;
+    Am1[0] = 1.0 / A[0];
+    return 0;
+  }
+  if (n == 2) {
+    double det = A[0] * A[3] - A[1] * A[2];
+    if (det == 0.0) return 1;
+    double id = 1.0 / det;
+    Am1[0] = A[3] * id;
+    Am1[1] = -A[1] * id;
+    Am1[2] = -A[2] * id;
+    Am1[3] = A[0] * id;
+    return 0;
+  }
+  double c00 = A[4] * A[8] - A[5] * A[7];
+  double c01 = A[5] * A[6] - A[3] * A[8];
+  double c02 = A[3] * A[7] - A[4] * A[6];
+  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  if (det == 0.0) return 1;
+  double id = 1.0 / det;
+  Am1[0] = c00 * id;
+  Am1[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+  Am1[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Am1[3] = c01 * id;
+  Am1[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+  Am1[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Am1[6] = c02 * id;
+  Am1[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+  Am1[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  return 0;
+}
+
+/* rcond__TensorLib__ (TensorLib.c:966-990) hands the UNFACTORED matrix to dgecon, which reads it
+ * as LU factors (unit-lower L = strict lower triangle, U = upper triangle) and returns
+ * 1 / (ANORM * ||(L U)^-1||_1) with ANORM = ||A||_1 from dlange (:981).  Restated literally with
+ * the exact 1-norm of the small inverse (dgecon's dlacn2 estimate is exact at these sizes in
+ * practice).  E.g. [[2,1],[1,3]] -> 0.25 (SURVEY.md §7 hard part 6).  Only the <1e-8 gate uses it. */
+double orc_rcond_ref(const double *A, int n) {
+  double LU[9], inv[9];
+  double anorm = 0.0;
+  for (int j = 0; j < n; j++) {
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += fabs(A[i * n + j]);
+    if (s > anorm) anorm = s;
+  }
+  /* LU = L * U */
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      double s = 0.0;
+      for (int k = 0; k < n; k++) {
+        double l = (k < i) ? A[i * n + k] : (k == i ? 1.0 : 0.0);
+        double u = (k <= j) ? A[k * n + j] : 0.0;
+        s += l * u;
+      }
+      LU[i * n + j] = s;
+    }
+  if (anorm == 0.0) return 0.0;
+  if (orc_inverse(inv, LU, n)) return 0.0;
+  double inorm = 0.0;
+  for (int j = 0; j < n; j++) {
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += fabs(inv[i * n + j]);
+    if (s > inorm) inorm = s;
+  }
+  if (!(inorm > 0.0) || isinf(inorm) || isnan(inorm)) return 0.0;
+  return (1.0 / inorm) / anorm;
+}
+
+/* sym_eigen_analysis__TensorLib__ (TensorLib.c:172-228) = LAPACKE_dsyev(ROW_MAJOR,'V','U'):
+ * eigenvalues ascending, eigenvector A in COLUMN A of the row-major matrix (eigvec[i*n+A]).
+ * Restated as cyclic Jacobi (orthonormal to rounding also for repeated eigenvalues).  Vector
+ * sign is LAPACK-implementation defined; every use on the path is sign-independent
+ * (sum_A f_A n_A (x) n_A).  'U': only the upper triangle of A is referenced. */
+int orc_sym_eigen(double *eigval, double *eigvec, const double *A, int n) {
+  double a[9], v[9];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      a[i * n + j] = (j >= i) ? A[i * n + j] : A[j * n + i];
+      v[i * n + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 50; sweep++) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) {
+        if (i != j) off += a[i * n + j] * a[i * n + j];
+        else diag += a[i * n + j] * a[i * n + j];
+      }
+    if (off <= 1e-32 * diag || off == 0.0) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        double apq = a[p * n + q];
+        if (apq == 0.0) continue;
+        double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * apq);
+        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; k++) {
+          double akp = a[k * n + p], akq = a[k * n + q];
+          a[k * n + p] = c * akp - s * akq;
+          a[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          double apk = a[p * n + k], aqk = a[q * n + k];
+          a[p * n + k] = c * apk - s * aqk;
+          a[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          double vkp = v[k * n + p], vkq = v[k * n + q];
+          v[k * n + p] = c * vkp - s * vkq;
+          v[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < n; i++) eigval[i] = a[i * n + i];
+  for (int i = 0; i < n - 1; i++)
+    for (int j = i + 1; j < n; j++)
+      if (eigval[idx[j]] < eigval[idx[i]]) {
+        int t = idx[i];
+        idx[i] = idx[j];
+        idx[j] = t;
+      }
+  double w[3];
+  for (int i = 0; i < n; i++) w[i] = eigval[idx[i]];
+  for (int A2 = 0; A2 < n; A2++) {
+    eigval[A2] = w[A2];
+    for (int i = 0; i < n; i++) eigvec[i * n + A2] = v[i * n + idx[A2]];
+  }
+  for (int i = 0; i < n; i++)
+    if (isnan(eigval[i])) return 1;
+  return 0;
+}
+
+/* I3__TensorLib__, TensorLib.c:154-168 (same term order). */
+static double I3(const double *A, int ndim) {
+  if (ndim == 2) return A[0] * A[3] - A[1] * A[2];
+  return A[0] * A[4] * A[8] - A[0] * A[5] * A[7] + A[1] * A[5] * A[6] - A[1] * A[3] * A[8] +
+         A[2] * A[3] * A[7] - A[2] * A[4] * A[6];
+}
+
+/* compute_adjunt__TensorLib__, TensorLib.c:829-905: A^{-T} (transpose then LAPACK inverse). */
+static int adjunt(double *A_mT, const double *A, int ndim) {
+  double At[9];
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) At[i * ndim + j] = A[j * ndim + i];
+  return orc_inverse(A_mT, At, ndim);
+}
+
+/* ======================================================================================
+ * LME shape functions, Nodes/LME.c
+ * ====================================================================================== */
+
+/* fa__LME__, LME.c:676-696 */
+static inline double fa_lme(const double *la, const double *lambda, double beta, int ndim) {
+  double la_x_la = 0.0, la_x_lambda = 0.0;
+  for (int i = 0; i < ndim; i++) {
+    la_x_la += la[i] * la[i];
+    la_x_lambda += la[i] * lambda[i];
+  }
+  return -beta * la_x_la + la_x_lambda;
+}
+
+/* p__LME__, LME.c:700-737 */
+void orc_p_lme(double *p, const double *l, int na, int ndim, const double *lambda, double beta) {
+  double Z = 0.0;
+  for (int a = 0; a < na; a++) {
+    p[a] = exp(fa_lme(&l[a * ndim], lambda, beta, ndim));
+    Z += p[a];
+  }
+  double Z_m1 = (double)1 / Z;
+  for (int a = 0; a < na; a++) p[a] *= Z_m1;
+}
+
+/* r__LME__, LME.c:766-791 */
+static void r_lme(double *r, const double *l, const double *p, int na, int ndim) {
+  for (int i = 0; i < ndim; i++) {
+    r[i] = 0.0;
+    for (int a = 0; a < na; a++) r[i] += p[a] * l[a * ndim + i];
+  }
+}
+
+/* J__LME__, LME.c:795-832 */
+static void J_lme(double *J, const double *l, const double *p, const double *r, int na, int ndim) {
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) {
+      double s = 0.0;
+      for (int a = 0; a < na; a++) s += p[a] * l[a * ndim + i] * l[a * ndim + j];
+      s -= r[i] * r[j];
+      J[i * ndim + j] = s;
+    }
+}
+
+/* dp__LME__, LME.c:836-891: dp_a = -p_a J^-1 l_a */
+int orc_dp_lme(double *dp, const double *l, const double *p, int na, int ndim) {
+  double r[3], J[9], Jm1[9];
+  r_lme(r, l, p, na, ndim);
+  J_lme(J, l, p, r, na, ndim);
+  if (orc_inverse(Jm1, J, ndim)) return 1;
+  for (int a = 0; a < na; a++) {
+    for (int i = 0; i < ndim; i++) {
+      double s = 0.0; /* get_A_x_b_Mat, MatrixOp.c:464-481 */
+      for (int j = 0; j < ndim; j++) s += Jm1[i * ndim + j] * l[a * ndim + j];
+      dp[a * ndim + i] = -p[a] * s;
+    }
+  }
+  return 0;
+}
+
+/* __lambda_Newton_Rapson, LME.c:272-353 */
+int orc_lambda_newton(const double *l, int na, int ndim, double *lambda, double beta,
+                      const orc_params *prm, int *iters) {
+  int MaxIter = prm->max_iter_lme;
+  int NumIter = 0;
+  double p[ORC_MAXNB], r[3], J[9], Jm1[9];
+  double norm_r = 10;
+  while (NumIter <= MaxIter) {
+    orc_p_lme(p, l, na, ndim, lambda, beta);
+    r_lme(r, l, p, na, ndim);
+    double aux = 0.0; /* norm__MatrixLib__(r,2), MatrixOp.c:843-870 */
+    for (int i = 0; i < ndim; i++) aux += dsqr(r[i]);
+    norm_r = pow(aux, 0.5);
+    if (norm_r > prm->tol_wrapper_lme) {
+      J_lme(J, l, p, r, na, ndim);
+      if (orc_rcond_ref(J, ndim) < 1E-8) {
+        if (iters) *iters = NumIter;
+        return 1;
+      }
+      /* solve__MatrixLib__, MatrixOp.c:1014-1032: inverse then product */
+      if (orc_inverse(Jm1, J, ndim)) return 1;
+      for (int i = 0; i < ndim; i++) {
+        double d = 0.0;
+        for (int j = 0; j < ndim; j++) d += Jm1[i * ndim + j] * r[j];
+        lambda[i] -= d;
+      }
+      NumIter++;
+    } else {
+      break;
+    }
+  }
+  if (iters) *iters = NumIter;
+  if (NumIter >= MaxIter) return 1;
+  (void)norm_r;
+  return 0;
+}
+
+/* point_distance__MeshTools__, Nodes-Tools.c:397-420: sqrt(sum pow(d,2)) */
+static inline double point_distance(const double *a, const double *b, int ndim) {
+  double D = 0;
+  for (int i = 0; i < ndim; i++) D += pow(a[i] - b[i], 2);
+  return sqrt(D);
+}
+
+/* get_closest_node__MeshTools__, Nodes-Tools.c:476-538: strict '<' => first minimum in chain order */
+static int closest_node(const double *x, const int *chain, int n, const double *coords, int ndim) {
+  int I = chain[0];
+  double DistMin = point_distance(x, &coords[I * ndim], ndim);
+  int I_DistMin = I;
+  for (int q = 1; q < n; q++) {
+    I = chain[q];
+    double d = point_distance(x, &coords[I * ndim], ndim);
+    if (d < DistMin) {
+      DistMin = d;
+      I_DistMin = I;
+    }
+  }
+  return I_DistMin;
+}
+
+
+/* tributary__LME__, LME.c:1019-1099.  Walks NodalLocality[I0] in array (= chain) order, keeps
+ * active nodes with generalised_Euclidean_distance (MatrixOp.c:895-920, identity metric) <= Ra,
+ * and PUSHES each one (prepend, ChainOp.c:163-182) => the output chain is in REVERSE walk order.
+ * Returns the count, or -1 when < ndim+1 nodes (the reference exit()s, LME.c:1087-1092). */
+static int tributary(int *list, const double *x, double beta_p, int I0, const orc_mesh *M,
+                     const orc_params *prm) {
+  int ndim = M->ndim;
+  int tmp[ORC_MAXNB], nt = 0;
+  double Ra = sqrt(-log(prm->tol_zero_lme) / beta_p);
+  for (int q = M->r2_ptr[I0]; q < M->r2_ptr[I0 + 1]; q++) {
+    int Node0 = M->r2[q];
+    if (M->active[Node0]) {
+      double sqr_distance = 0;
+      for (int i = 0; i < ndim; i++) {
+        double la = x[i] - M->coords[Node0 * ndim + i]; /* substraction__MatrixLib__(X_p, X_I) */
+        sqr_distance += la * la;                        /* identity metric: la_i * (1*la_i) */
+      }
+      if (sqrt(sqr_distance) <= Ra) tmp[nt++] = Node0;
+    }
+  }
+  if (nt < ndim + 1) return -1;
+  for (int a = 0; a < nt; a++) list[a] = tmp[nt - 1 - a];
+  return nt;
+}
+
+/* compute_distance__MeshTools__, Nodes-Tools.c:424-446: l_a = x_p - x_a in list order */
+static void compute_distance(double *l, const int *list, int nn, const double *x, const orc_mesh *M) {
+  int ndim = M->ndim;
+  for (int a = 0; a < nn; a++)
+    for (int i = 0; i < ndim; i++) l[a * ndim + i] = x[i] - M->coords[list[a] * ndim + i];
+}
+
+/* beta__LME__, LME.c:177-185 */
+static inline double beta_lme(double gamma, double h_avg) { return gamma / (h_avg * h_avg); }
+
+/* activation loop shared by initialize__LME__ (LME.c:122-141) and local_search__LME__ (:949-965) */
+static void activate_one_rings(const orc_particles *P, orc_mesh *M) {
+  for (int p = 0; p < P->np; p++) {
+    int I0 = P->I0[p];
+    for (int q = M->r1_ptr[I0]; q < M->r1_ptr[I0 + 1]; q++) M->active[M->r1[q]] = 1;
+  }
+}
+
+/* third loop of initialize__LME__ (LME.c:143-173) and local_search__LME__ (:969-1006) */
+static int lists_and_lambda(orc_particles *P, orc_mesh *M, const orc_params *prm) {
+  int STATUS = 0;
+  int ndim = M->ndim;
+#pragma omp parallel for schedule(static) reduction(| : STATUS)
+  for (int p = 0; p < P->np; p++) {
+    double l[ORC_MAXNB * 3];
+    const double *x = &P->x[p * ndim];
+    double Beta_p = P->beta[p]; /* previous beta (0 at initialisation => Ra = +inf) */
+    int nn = tributary(&P->list[(size_t)p * ORC_MAXNB], x, Beta_p, P->I0[p], M, prm);
+    if (nn < 0) {
+      P->nn[p] = 0;
+      if (P->status) P->status[p] |= 2;
+      STATUS |= 1;
+      continue;
+    }
+    P->nn[p] = nn;
+    compute_distance(l, &P->list[(size_t)p * ORC_MAXNB], nn, x, M);
+    Beta_p = beta_lme(prm->gamma_lme, M->h_avg[P->I0[p]]);
+    P->beta[p] = Beta_p;
+    int st = orc_lambda_newton(l, nn, ndim, &P->lambda[p * ndim], Beta_p, prm, NULL);
+    if (st) {
+      if (P->status) P->status[p] |= 1;
+      STATUS |= 1;
+    }
+  }
+  return STATUS;
+}
+
+/* initialize__LME__, LME.c:45-173 (wrapper_LME = Newton-Raphson).  The element search (:73-108)
+ * takes the FIRST element in index order whose closed box contains the particle (Q4.c:305-338);
+ * on the structured grid that is the lowest cell index per axis.  I0 = closest node of that
+ * element in connectivity-chain order (:90-91). */
+int orc_initialize_lme(orc_particles *P, orc_mesh *M, const orc_params *prm) {
+  int ndim = M->ndim;
+  grid_t g;
+  g.ndim = ndim;
+  for (int a = 0; a < 3; a++) {
+    g.n[a] = M->n[a];
+    g.nc[a] = (a < ndim) ? M->n[a] - 1 : 1;
+  }
+  for (int p = 0; p < P->np; p++) {
+    const double *x = &P->x[p * ndim];
+    int c[3] = {0, 0, 0};
+    for (int a = 0; a < ndim; a++) {
+      int ci = (int)floor((x[a] - M->origin[a]) / M->h);
+      if (ci < 0) ci = 0;
+      if (ci > g.nc[a] - 1) ci = g.nc[a] - 1;
+      /* lowest-index cell whose closed interval holds x */
+      while (ci > 0 && x[a] <= M->origin[a] + M->h * (double)ci) ci--;
+      while (ci < g.nc[a] - 1 && x[a] > M->origin[a] + M->h * (double)(ci + 1)) ci++;
+      if (x[a] < M->origin[a] + M->h * (double)ci || x[a] > M->origin[a] + M->h * (double)(ci + 1))
+        return 1; /* LME.c:110-114: particle not found */
+      c[a] = ci;
+    }
+    int ch[8];
+    int nn = element_chain(&g, c[0], c[1], c[2], ch);
+    P->I0[p] = closest_node(x, ch, nn, M->coords, ndim);
+  }
+  activate_one_rings(P, M);
+  return lists_and_lambda(P, M, prm);
+}
+
+/* local_search__MeshTools__ (Shape-Functions.c:31-90) + local_search__LME__ (LME.c:895-1015) */
+int orc_local_search(orc_particles *P, orc_mesh *M, const orc_params *prm) {
+  int ndim = M->ndim;
+  memset(M->active, 0, (size_t)M->nnodes); /* Shape-Functions.c:38-46 */
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P->np; p++) {
+    double aux = 0.0; /* norm__MatrixLib__(dis_p,2) > 0, LME.c:924 */
+    for (int i = 0; i < ndim; i++) aux += dsqr(P->dis[p * ndim + i]);
+    if (pow(aux, 0.5) > 0.0) {
+      int I0 = P->I0[p];
+      P->I0[p] = closest_node(&P->x[p * ndim], &M->r1[M->r1_ptr[I0]], M->r1_ptr[I0 + 1] - M->r1_ptr[I0],
+                              M->coords, ndim);
+    }
+  }
+  activate_one_rings(P, M);
+  return lists_and_lambda(P, M, prm);
+}
+
+/* compute_N__MeshTools__, Shape-Functions.c:163-195 (LME branch) */
+int orc_compute_N(double *N, const orc_particles *P, const orc_mesh *M, int p) {
+  double l[ORC_MAXNB * 3];
+  int nn = P->nn[p];
+  compute_distance(l, &P->list[(size_t)p * ORC_MAXNB], nn, &P->x[p * M->ndim], M);
+  orc_p_lme(N, l, nn, M->ndim, &P->lambda[p * M->ndim], P->beta[p]);
+  return nn;
+}
+
+/* compute_dN__MeshTools__, Shape-Functions.c:319-354 (LME branch) */
+int orc_compute_dN(double *dN, const orc_particles *P, const orc_mesh *M, int p) {
+  double l[ORC_MAXNB * 3], N[ORC_MAXNB];
+  int nn = P->nn[p];
+  compute_distance(l, &P->list[(size_t)p * ORC_MAXNB], nn, &P->x[p * M->ndim], M);
+  orc_p_lme(N, l, nn, M->ndim, &P->lambda[p * M->ndim], P->beta[p]);
+  if (orc_dp_lme(dN, l, N, nn, M->ndim)) return -1;
+  return nn;
+}
+
+/* ======================================================================================
+ * Masks, Nodes/Nodes-Tools.c:46-156
+ * ====================================================================================== */
+
+/* get_active_nodes__MeshTools__, Nodes-Tools.c:46-66 */
+int orc_active_nodes(int *nodes2mask, const orc_mesh *M) {
+  int Nactivenodes = 0;
+  for (int A = 0; A < M->nnodes; A++) {
+    if (M->active[A]) {
+      nodes2mask[A] = Nactivenodes;
+      Nactivenodes++;
+    } else {
+      nodes2mask[A] = -1;
+    }
+  }
+  return Nactivenodes;
+}
+
+/* get_active_dofs__MeshTools__, Nodes-Tools.c:70-156 */
+int orc_active_dofs(int *dofs2mask, const int *nodes2mask, int nactive, int ndof, const orc_bcc *bcc,
+                    int nbcc, int step, int nsteps) {
+  int Order = nactive * ndof;
+  memset(dofs2mask, 0, sizeof(int) * (size_t)Order);
+  for (int i = 0; i < nbcc; i++)
+    for (int j = 0; j < bcc[i].nnodes; j++) {
+      int Id_BCC_mask = nodes2mask[bcc[i].nodes[j]];
+      if (Id_BCC_mask != -1)
+        for (int k = 0; k < bcc[i].dim; k++)
+          if (bcc[i].dir[k * nsteps + step] == 1) dofs2mask[Id_BCC_mask * ndof + k] = -1;
+    }
+  int Nactive = 0;
+  for (int A_i = 0; A_i < Order; A_i++)
+    if (dofs2mask[A_i] != -1) {
+      dofs2mask[A_i] = Nactive;
+      Nactive++;
+    }
+  return Nactive;
+}
+
+/* ======================================================================================
+ * Stage functions of U_Newmark_Beta (Formulations/Displacements/U-Newmark-beta.c).  The OpenMP
+ * structure (parallel for over particles, omp critical around every nodal +=) is the reference's.
+ * ====================================================================================== */
+
+/* __compute_nodal_lumped_mass, U-Newmark-beta.c:528-597 */
+int orc_lumped_mass(double *Mv, const orc_particles *P, const orc_mesh *M, const int *nodes2mask) {
+  int ndim = M->ndim;
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P->np; p++) {
+    double N[ORC_MAXNB];
+    int nn = orc_compute_N(N, P, M, p);
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    double m_p = P->mass[p];
+    for (int A = 0; A < nn; A++) {
+      int Mask_node_A = nodes2mask[conn[A]];
+      double M_AB_p = N[A] * m_p;
+#pragma omp critical
+      {
+        for (int i = 0; i < ndim; i++) Mv[Mask_node_A * ndim + i] += M_AB_p;
+      }
+    }
+  }
+  return 0;
+}
+
+/* __get_nodal_field_n, U-Newmark-beta.c:615-696 (the Dirichlet post-loop :698-770 is a no-op:
+ * its VecSetValues are commented out) */
+int orc_nodal_field_n(double *V, double *Av, const double *Mv, const orc_particles *P,
+                      const orc_mesh *M, const int *nodes2mask, const int *dofs2mask, int nactive) {
+  int ndim = M->ndim;
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P->np; p++) {
+    double N[ORC_MAXNB];
+    int nn = orc_compute_N(N, P, M, p);
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    double m_p = P->mass[p];
+    const double *vel_p = &P->vel[p * ndim];
+    const double *acc_p = &P->acc[p * ndim];
+    for (int A = 0; A < nn; A++) {
+      int Mask_node_A = nodes2mask[conn[A]];
+      double m__x__N = m_p * N[A];
+#pragma omp critical
+      {
+        for (int i = 0; i < ndim; i++) {
+          int idx = Mask_node_A * ndim + i;
+          if (dofs2mask[idx] != -1) { /* VEC_IGNORE_NEGATIVE_INDICES */
+            V[idx] += m__x__N * vel_p[i];
+            Av[idx] += m__x__N * acc_p[i];
+          }
+        }
+      }
+    }
+  }
+  for (int i = 0; i < nactive * ndim; i++) { /* VecPointwiseDivide :695-696 */
+    V[i] = V[i] / Mv[i];
+    Av[i] = Av[i] / Mv[i];
+  }
+  return 0;
+}
+
+/* update_*_Deformation_Gradient*, Particles/compute-Strains.c:20-105,176-207 */
+static void update_increment_DF(double *DF_p, const double *DeltaU, const double *gradient_p, int nn,
+                                int ndim, double diag) {
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) DF_p[i * ndim + j] = diag * (i == j);
+  for (int A = 0; A < nn; A++)
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) DF_p[i * ndim + j] += DeltaU[A * ndim + i] * gradient_p[A * ndim + j];
+}
+
+static void update_F_n1(double *F_n1, const double *F_n, const double *f_n1, int ndim) {
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) {
+      double aux = 0;
+      for (int k = 0; k < ndim; k++) aux += f_n1[i * ndim + k] * F_n[k * ndim + j];
+      F_n1[i * ndim + j] = aux;
+    }
+}
+
+static void update_rate_F_n1(double *dt_F_n1, const double *dt_f_n1, const double *F_n,
+                             const double *f_n1, const double *dt_F_n, int ndim) {
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) {
+      double aux = 0.0;
+      for (int k = 0; k < ndim; k++)
+        aux += dt_f_n1[i * ndim + k] * F_n[k * ndim + j] + f_n1[i * ndim + k] * dt_F_n[k * ndim + j];
+      dt_F_n1[i * ndim + j] = aux;
+    }
+}
+
+/* __local_compatibility_conditions, U-Newmark-beta.c:1064-1160 (F-bar off).  dU_dt may be NULL
+ * (the rate tensors are consumed only by the Newtonian-fluid law, Constitutive.c:84-108). */
+int orc_compatibility(const double *dU, const double *dU_dt, orc_particles *P, const orc_mesh *M,
+                      const int *nodes2mask) {
+  int ndim = M->ndim, T = P->T;
+  int STATUS = 0;
+#pragma omp parallel for schedule(static) reduction(| : STATUS)
+  for (int p = 0; p < P->np; p++) {
+    double dN[ORC_MAXNB * 3], dUa[ORC_MAXNB * 3], dVa[ORC_MAXNB * 3];
+    int nn = orc_compute_dN(dN, P, M, p);
+    if (nn < 0) {
+      STATUS |= 1;
+      continue;
+    }
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    for (int A = 0; A < nn; A++) { /* get_set_field__MeshTools__, Nodes-Tools.c:249-275 */
+      int A_mask = nodes2mask[conn[A]];
+      for (int i = 0; i < ndim; i++) {
+        dUa[A * ndim + i] = dU[A_mask * ndim + i];
+        if (dU_dt) dVa[A * ndim + i] = dU_dt[A_mask * ndim + i];
+      }
+    }
+    double *F_n_p = &P->F_n[p * T], *F_n1_p = &P->F_n1[p * T], *DF_p = &P->DF[p * T];
+    update_increment_DF(DF_p, dUa, dN, nn, ndim, 1.0);
+    update_F_n1(F_n1_p, F_n_p, DF_p, ndim);
+    if (dU_dt && P->dt_DF) {
+      update_increment_DF(&P->dt_DF[p * T], dVa, dN, nn, ndim, 0.0);
+      update_rate_F_n1(&P->dt_F_n1[p * T], &P->dt_DF[p * T], F_n_p, DF_p, &P->dt_F_n[p * T], ndim);
+    }
+    P->J_n1[p] = I3(F_n1_p, ndim);
+    if (P->J_n1[p] <= 0.0) { /* :1137-1142: message + clamp */
+      P->J_n1[p] = 0.0;
+      if (P->status) P->status[p] |= 4;
+    }
+  }
+  return STATUS;
+}
+
+/* left_Cauchy_Green__Particles__, compute-Strains.c:365-384 */
+static void left_cauchy_green(double *b, const double *F, int ndim) {
+  if (ndim == 2) {
+    b[0] = F[0] * F[0] + F[1] * F[1];
+    b[1] = F[0] * F[2] + F[1] * F[3];
+    b[2] = b[1];
+    b[3] = F[2] * F[2] + F[3] * F[3];
+  } else {
+    b[0] = F[0] * F[0] + F[1] * F[1] + F[2] * F[2];
+    b[1] = F[0] * F[3] + F[1] * F[4] + F[2] * F[5];
+    b[2] = F[0] * F[6] + F[1] * F[7] + F[2] * F[8];
+    b[3] = b[1];
+    b[4] = F[3] * F[3] + F[4] * F[4] + F[5] * F[5];
+    b[5] = F[3] * F[6] + F[4] * F[7] + F[5] * F[8];
+    b[6] = b[2];
+    b[7] = b[5];
+    b[8] = F[6] * F[6] + F[7] * F[7] + F[8] * F[8];
+  }
+}
+
+/* compute_Kirchhoff_Stress_Neo_Hookean__Constitutive__, Hyperelastic/Neo-Hookean.c:38-85
+ * (+ energy :18-34; I1 = trace of the d x d block, TensorLib.c:113-125 with the 3-D typo read as
+ * the obvious trace). */
+static int stress_neo_hookean(int ndim, const orc_material *mat, const double *F_n1, double J,
+                              double *T, double *W) {
+  double G = mat->E / (2 * (1 + mat->nu));
+  double lambda = mat->nu * mat->E / ((1 - mat->nu * 2) * (1 + mat->nu));
+  double J2 = J * J;
+  double c0 = lambda * 0.5 * (J2 - 1.0);
+  double b[9];
+  left_cauchy_green(b, F_n1, ndim);
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) {
+      double Id = (i == j) ? 1.0 : 0.0;
+      T[i * ndim + j] = c0 * Id + G * (b[i * ndim + j] - Id);
+    }
+  if (ndim == 2) T[4] = c0;
+  double I1_b = (ndim == 2) ? b[0] + b[3] : b[0] + b[4] + b[8];
+  double f_J = 0.25 * lambda * (J * J - 1) - 0.5 * lambda * log(J) - G * log(J);
+  *W = f_J + 0.5 * G * (I1_b - ndim);
+  return 0;
+}
+
+/* rotate principal values to xyz with eigenvector A = COLUMN A (Hencky.c:248-265,
+ * Drucker-Prager.c:755-776, :663-710) */
+static void ppal_to_xyz(double *T_xyz, const double *T_ppal, const double *eigvec, int ndim) {
+  double T_aux[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int A = 0; A < ndim; A++)
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++)
+        T_aux[i * ndim + j] += T_ppal[A] * eigvec[A + i * ndim] * eigvec[A + j * ndim];
+  for (int i = 0; i < ndim * ndim; i++) T_xyz[i] = T_aux[i];
+  if (ndim == 2) T_xyz[4] = T_ppal[2];
+}
+
+/* compute_Kirchhoff_Stress_Hencky__Constitutive__, Hyperelastic/Hencky.c:40-94,233-285 */
+static int stress_hencky(int ndim, const orc_material *mat, const double *F_n1, double *T, double *W) {
+  double b[9], eigvec[9] = {0}, eigval[3] = {0.0, 0.0, 1.0}; /* 2-D: third eigenvalue fixed 1.0, :48 */
+  double E = mat->E, nu = mat->nu;
+  double Lame = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+  double G = E / (2.0 * (1.0 + nu));
+  double AA[9] = {Lame + 2 * G, Lame, Lame, Lame, Lame + 2 * G, Lame, Lame, Lame, Lame + 2 * G};
+  left_cauchy_green(b, F_n1, ndim);
+  if (orc_sym_eigen(eigval, eigvec, b, ndim)) return 1;
+  double Eh[3], Tp[3];
+  Eh[0] = 0.5 * log(eigval[0]);
+  Eh[1] = 0.5 * log(eigval[1]);
+  Eh[2] = 0.5 * log(eigval[2]);
+  Tp[0] = AA[0] * Eh[0] + AA[1] * Eh[1] + AA[2] * Eh[2];
+  Tp[1] = AA[3] * Eh[0] + AA[4] * Eh[1] + AA[5] * Eh[2];
+  Tp[2] = AA[6] * Eh[0] + AA[7] * Eh[1] + AA[8] * Eh[2];
+  ppal_to_xyz(T, Tp, eigvec, ndim);
+  *W = 0.5 * (Tp[0] * Eh[0] + Tp[1] * Eh[1] + Tp[2] * Eh[2]);
+  return 0;
+}
+
+/* compute_Kirchhoff_Stress_Drucker_Prager__Constitutive__, Plasticity/Drucker-Prager.c:319-613 and
+ * its helpers :617-1084.  The plastic branches index eigenvectors row-wise (:957,1059) while the
+ * elastic branch and the b_e corrector index column-wise (:770,699); the two agree in the only
+ * buildable (2-D) reference because LAPACK's 2x2 eigenvector matrix is symmetric.  Restated with
+ * the consistent COLUMN convention (SURVEY.md §7 hard part 3).  C_ep (:1088-1198, implicit tangent
+ * only) is not produced. */
+static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_params *prm,
+                                 const double *d_phi, const double *b_e_n, double kappa_n,
+                                 double eps_n_in, double *T, double *W, double *b_e, double *kappa_out,
+                                 double *eps_out) {
+  double eigval[3] = {0, 0, 0}, eigvec[9] = {0}, btr[9] = {0};
+  /* __compute_trial_b_e :617-660 */
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++)
+      for (int k = 0; k < ndim; k++)
+        for (int l = 0; l < ndim; l++)
+          btr[i * ndim + j] += d_phi[i * ndim + k] * b_e_n[k * ndim + l] * d_phi[j * ndim + l];
+  if (orc_sym_eigen(eigval, eigvec, btr, ndim)) return 1;
+  if (ndim == 2) eigval[2] = b_e_n[4];
+
+  double Etr[3] = {0.5 * log(eigval[0]), 0.5 * log(eigval[1]), 0.5 * log(eigval[2])};
+
+  double K = mat->E / (3.0 * (1.0 - 2.0 * mat->nu));
+  double G = mat->E / (2.0 * (1.0 + mat->nu));
+  double p_ref = mat->p_ref;
+  double rad_friction_angle = (PI_MATRIXLIB / 180.0) * mat->phi_deg;
+  double rad_dilatancy_angle = (PI_MATRIXLIB / 180.0) * mat->psi_deg;
+  double exp_param = mat->exponent_ortiz;
+  double kappa_0 = mat->kappa_0;
+  double eps_0 = mat->eps_0;
+  double alpha_F, alpha_Q, beta;
+  if (ndim == 2) { /* :362-368 plane-strain match */
+    alpha_F = sqrt(2. / 3.) * tan(rad_friction_angle) / sqrt(3. + 4. * dsqr(tan(rad_friction_angle)));
+    alpha_Q = sqrt(2. / 3.) * tan(rad_dilatancy_angle) / sqrt(3. + 4. * dsqr(tan(rad_dilatancy_angle)));
+    beta = sqrt(2. / 3.) * 3. / sqrt(3. + 4. * dsqr(tan(rad_friction_angle)));
+  } else { /* :370-375 */
+    alpha_F = sqrt(2 / 3.) * 2 * sin(rad_friction_angle) / (3 - sin(rad_friction_angle));
+    alpha_Q = sqrt(2 / 3.) * 2 * sin(rad_dilatancy_angle) / (3 - sin(rad_dilatancy_angle));
+    beta = sqrt(2 / 3.) * 6 * cos(rad_friction_angle) / (3 - sin(rad_friction_angle));
+  }
+
+  double n[3] = {0, 0, 0}, dEp[3] = {0, 0, 0};
+  double PHI, PHI_0, d_PHI;
+  double d_gamma_k = 0;
+  double eps_n = eps_n_in, eps_k = eps_n, kappa_k = kappa_n, d_kappa_k = 0.0;
+  double TOL = prm->tol_radial_returning;
+  int MaxIter = prm->max_iter_radial_returning, Iter = 0;
+  double Tp[3];
+
+  /* plastic laws start from the n-state, Constitutive.c:160-168 */
+  *kappa_out = kappa_n;
+  *eps_out = eps_n_in;
+
+  /* __trial_elastic :713-738 */
+  double tr = Etr[0] + Etr[1] + Etr[2];
+  double Evol = (1.0 / 3.0) * tr;
+  double Tvol[3], Tdev[3];
+  for (int a = 0; a < 3; a++) {
+    Tvol[a] = -p_ref - K * Evol;
+    Tdev[a] = 2 * G * (Etr[a] - Evol);
+  }
+  double pressure = (Tvol[0] + Tvol[1] + Tvol[2]) / 3.0;
+  double J2 = sqrt(Tdev[0] * Tdev[0] + Tdev[1] * Tdev[1] + Tdev[2] * Tdev[2]);
+
+#define YIELD_CLASSICAL(dg, kap) \
+  (J2 - 2.0 * G * (dg) - 3.0 * alpha_F * (pressure - 3.0 * K * alpha_Q * (dg)) - beta * (kap))
+
+  PHI = PHI_0 = YIELD_CLASSICAL(d_gamma_k, kappa_k); /* :886-896 */
+
+  if (PHI_0 <= TOL_NR) { /* elastic :410-432 */
+    for (int a = 0; a < 3; a++) Tp[a] = -Tvol[a] + Tdev[a];
+    ppal_to_xyz(T, Tp, eigvec, ndim);
+  } else {
+    if (J2 > TOL_NR) { /* __compute_plastic_flow_direction :798-812 */
+      n[0] = Tdev[0] / J2;
+      n[1] = Tdev[1] / J2;
+      n[2] = Tdev[2] / J2;
+    }
+    /* __d_kappa :849-863 */
+    {
+      double base = 1.0 + eps_n / eps_0;
+      if (base < 0.0) return 1;
+      d_kappa_k = (kappa_0 / (exp_param * eps_0)) * pow(base, 1.0 / exp_param - 1.0);
+    }
+    /* __compute_pressure_limit :867-882 */
+    double ads = sqrt(1.0 + 3.0 * alpha_Q * alpha_Q);
+    if (alpha_F == 0.0) return 1;
+    double pressure_limit = 3.0 * alpha_Q * K / (2.0 * G) * J2 +
+                            beta / (3.0 * alpha_F) * ((J2 / (2.0 * G)) * d_kappa_k * ads + kappa_k);
+
+    if (-pressure < pressure_limit) { /* classical return :457-530 */
+      while (fabs(PHI / PHI_0) >= TOL) {
+        Iter++;
+        if (Iter == MaxIter) break;
+        d_PHI = 9.0 * K * alpha_F * alpha_Q - 2.0 * G - beta * d_kappa_k * ads; /* :900-909 */
+        if (fabs(d_PHI) < TOL) return 1;
+        d_gamma_k += -PHI / d_PHI;
+        if (d_gamma_k < 0.0) return 1;
+        eps_k = eps_n + d_gamma_k * sqrt(3.0 * alpha_Q * alpha_Q + 1.0); /* __eps :816-829 */
+        if (eps_k < 0.0) return 1;
+        {
+          double base = 1.0 + eps_k / eps_0; /* __kappa :833-847 */
+          if (base < 0.0) return 1;
+          kappa_k = kappa_0 * pow(base, 1.0 / exp_param);
+          if (kappa_k < 0.0) return 1;
+          d_kappa_k = (kappa_0 / (exp_param * eps_0)) * pow(base, 1.0 / exp_param - 1.0);
+        }
+        PHI = YIELD_CLASSICAL(d_gamma_k, kappa_k);
+      }
+      for (int a = 0; a < 3; a++) /* :913-927 */
+        Tp[a] = -Tvol[a] + Tdev[a] + d_gamma_k * (3 * K * alpha_Q - 2 * G * n[a]);
+      *eps_out = eps_k; /* :931-947 */
+      *kappa_out = kappa_k;
+      for (int a = 0; a < 3; a++) dEp[a] = d_gamma_k * (alpha_Q + n[a]);
+      ppal_to_xyz(T, Tp, eigvec, ndim);
+    } else { /* apex return :532-590 */
+      double d_gamma_1 = J2 / (2.0 * G);
+      double d_gamma_2_k = 0.0;
+      d_gamma_k = d_gamma_1 + d_gamma_2_k;
+      while (fabs(PHI / PHI_0) >= TOL) {
+        Iter++;
+        if (Iter == MaxIter) break;
+        d_PHI = 3.0 * alpha_Q * K + /* __d_yield_function_apex :1004-1018 */
+                3.0 * d_kappa_k * beta * (alpha_Q * alpha_Q) * d_gamma_k /
+                    (3.0 * alpha_F *
+                     sqrt((d_gamma_1 * d_gamma_1) + 3.0 * (alpha_Q * alpha_Q) * (d_gamma_k * d_gamma_k)));
+        if (fabs(d_PHI) < TOL) break;
+        d_gamma_2_k += -PHI / d_PHI;
+        if (d_gamma_2_k < 0.0) {
+          d_gamma_k = 0.0;
+          d_gamma_2_k = 0.0;
+          break;
+        } else {
+          d_gamma_k = d_gamma_1 + d_gamma_2_k;
+        }
+        PHI = (beta / (3.0 * alpha_F) * /* __yield_function_apex :987-1000 */
+                   (kappa_k + d_kappa_k * sqrt((d_gamma_1 * d_gamma_1) +
+                                               3.0 * (alpha_Q * alpha_Q) * (d_gamma_k * d_gamma_k))) -
+               pressure + 3.0 * K * alpha_Q * d_gamma_k);
+      }
+      eps_k = eps_n + d_gamma_k * sqrt(3.0 * alpha_Q * alpha_Q + 1.0);
+      if (eps_k < 0.0) return 1;
+      for (int a = 0; a < 3; a++) Tp[a] = -Tvol[a] + d_gamma_k * 3 * K * alpha_Q; /* :1022-1032 */
+      *eps_out = eps_k; /* :1036-1051 */
+      *kappa_out = kappa_k;
+      for (int a = 0; a < 3; a++) dEp[a] = d_gamma_k * alpha_Q + d_gamma_1 * n[a];
+      ppal_to_xyz(T, Tp, eigvec, ndim);
+    }
+  }
+#undef YIELD_CLASSICAL
+
+  Etr[0] -= dEp[0]; /* :593-597 */
+  Etr[1] -= dEp[1];
+  Etr[2] -= dEp[2];
+  *W = 0.5 * (Tp[0] * Etr[0] + Tp[1] * Etr[1] + Tp[2] * Etr[2]);
+
+  /* __corrector_b_e :663-710 */
+  double ev[3] = {exp(2 * Etr[0]), exp(2 * Etr[1]), exp(2 * Etr[2])};
+  ppal_to_xyz(b_e, ev, eigvec, ndim); /* same column-wise rotation; 2-D: b_e[4] = ev[2] */
+  return 0;
+}
+
+/* Stress_integration__Constitutive__, Constitutive/Constitutive.c:18-258 (the three laws on the path) */
+int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, const double *F_n1,
+                   const double *DF, double J, const double *b_e_n, double kappa_n, double eps_n,
+                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1) {
+  switch (mat->type) {
+  case ORC_MAT_NEO_HOOKEAN:
+    return stress_neo_hookean(ndim, mat, F_n1, J, stress, W);
+  case ORC_MAT_HENCKY:
+    return stress_hencky(ndim, mat, F_n1, stress, W);
+  case ORC_MAT_DRUCKER_PRAGER:
+    return stress_drucker_prager(ndim, mat, prm, DF, b_e_n, kappa_n, eps_n, stress, W, b_e_n1,
+                                 kappa_n1, eps_n1);
+  default:
+    return 1; /* Constitutive.c:251-256 exit()s */
+  }
+}
+
+/* __constitutive_update, U-Newmark-beta.c:1208-1242 */
+int orc_constitutive(orc_particles *P, const orc_material *mats, const orc_params *prm) {
+  int STATUS = 0;
+  int T = P->T;
+#pragma omp parallel for schedule(static) reduction(| : STATUS)
+  for (int p = 0; p < P->np; p++) {
+    const orc_material *mat = &mats[P->matidx[p]];
+    double dummyb[9], dk, de;
+    int st = orc_stress_one(P->ndim, mat, prm, &P->F_n1[p * T], &P->DF[p * T], P->J_n1[p],
+                            P->b_e_n ? &P->b_e_n[p * T] : dummyb, P->kappa_n ? P->kappa_n[p] : 0.0,
+                            P->eps_n ? P->eps_n[p] : 0.0, &P->stress[p * T], &P->W[p],
+                            P->b_e_n1 ? &P->b_e_n1[p * T] : dummyb, P->kappa_n1 ? &P->kappa_n1[p] : &dk,
+                            P->eps_n1 ? &P->eps_n1[p] : &de);
+    if (st) {
+      if (P->status) P->status[p] |= 8;
+      STATUS |= 1;
+    }
+  }
+  return STATUS;
+}
+
+/* __nodal_internal_forces, U-Newmark-beta.c:1257-1374 + push_forward_dN__MeshTools__,
+ * Shape-Functions.c:405-448 */
+int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
+                        const int *dofs2mask) {
+  int ndim = M->ndim, T = P->T;
+  int STATUS = 0;
+#pragma omp parallel for schedule(static) reduction(| : STATUS)
+  for (int p = 0; p < P->np; p++) {
+    double dN[ORC_MAXNB * 3], dN1[ORC_MAXNB * 3], d_phi_mT[9];
+    int nn = orc_compute_dN(dN, P, M, p);
+    if (nn < 0 || adjunt(d_phi_mT, &P->DF[p * T], ndim)) {
+      STATUS |= 1;
+      continue;
+    }
+    for (int A = 0; A < nn; A++)
+      for (int i = 0; i < ndim; i++) {
+        double s = 0.0;
+        for (int j = 0; j < ndim; j++) s += d_phi_mT[i * ndim + j] * dN[A * ndim + j];
+        dN1[A * ndim + i] = s;
+      }
+    double V0_p = P->vol0[p];
+    const double *kirchhoff_p = &P->stress[p * T];
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    for (int A = 0; A < nn; A++) {
+      int Mask_node_A = nodes2mask[conn[A]];
+      double f[3];
+      for (int i = 0; i < ndim; i++) {
+        f[i] = 0.0;
+        for (int j = 0; j < ndim; j++) f[i] += kirchhoff_p[i * ndim + j] * dN1[A * ndim + j];
+      }
+#pragma omp critical
+      {
+        for (int i = 0; i < ndim; i++) {
+          int idx = Mask_node_A * ndim + i;
+          if (dofs2mask[idx] != -1) R[idx] += f[i] * V0_p;
+        }
+      }
+    }
+  }
+  return STATUS;
+}
+
+/* __update_particles_internal_variables, U-Newmark-beta.c:1917-1978 */
+void orc_roll_state(orc_particles *P) {
+  int T = P->T;
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P->np; p++) {
+    P->J_n[p] = P->J_n1[p];
+    P->rho[p] = P->mass[p] / (P->vol0[p] * P->J_n[p]);
+    if (P->kappa_n) P->kappa_n[p] = P->kappa_n1[p];
+    if (P->eps_n) P->eps_n[p] = P->eps_n1[p];
+    for (int i = 0; i < T; i++) {
+      if (P->b_e_n) P->b_e_n[p * T + i] = P->b_e_n1[p * T + i];
+      P->F_n[p * T + i] = P->F_n1[p * T + i];
+      if (P->dt_F_n) P->dt_F_n[p * T + i] = P->dt_F_n1[p * T + i];
+    }
+  }
+}
+
+/* __update_particles_kinetics_FLIP_PIC, U-Newmark-beta.c:1993-2072 */
+int orc_update_kinetics(double alpha_blend, const double *dU, const double *Un_dt, const double *dU_dt,
+                        const double *dU_dt2, orc_particles *P, const orc_mesh *M,
+                        const int *nodes2mask) {
+  int ndim = M->ndim;
+  double beta_blend = 1 - alpha_blend;
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P->np; p++) {
+    double N[ORC_MAXNB];
+    int nn = orc_compute_N(N, P, M, p);
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    for (int i = 0; i < ndim; i++) P->vel[p * ndim + i] = alpha_blend * P->vel[p * ndim + i];
+    for (int A = 0; A < nn; A++) {
+      int A_mask = nodes2mask[conn[A]];
+      for (int i = 0; i < ndim; i++) {
+        double DU_pI = N[A] * dU[A_mask * ndim + i];
+        double D_V_pI = N[A] * dU_dt[A_mask * ndim + i];
+        double V_n_pI = N[A] * Un_dt[A_mask * ndim + i];
+        double D_A_pI = N[A] * dU_dt2[A_mask * ndim + i];
+        P->acc[p * ndim + i] += D_A_pI;
+        P->vel[p * ndim + i] += D_V_pI + beta_blend * V_n_pI;
+        P->dis[p * ndim + i] += DU_pI;
+        P->x[p * ndim + i] += DU_pI;
+      }
+    }
+  }
+  return 0;
+}
+
+/* ======================================================================================
+ * Explicit predictor-corrector step.  The explicit drivers are stubs in the reference (SURVEY.md
+ * fact 2); this composes the maintained stage functions in the order and with the formulas of
+ * U-Verlet.c: predictor :229-253, nodal dU projection :301-367, Dirichlet :455-527, local state
+ * :530-676 (density :630-632), nodal equilibrium :919-957 (a = g + F/M, reactions on fixed dofs),
+ * G2P of acceleration and dU :962-1010, corrector :1024-1084; internal force in the Kirchhoff form of
+ * U-Newmark-beta.c:1257-1374 with the sign of U-Verlet.c:783 (Forces -= f_int).
+ * ====================================================================================== */
+int orc_explicit_step(orc_particles *P, orc_mesh *M, const orc_material *mats, const orc_params *prm,
+                      const orc_bcc *bcc, int nbcc, int step, int nsteps, double dt, double gamma,
+                      const double *gravity, orc_step_out *out) {
+  int ndim = M->ndim, T = P->T, np = P->np;
+  int STATUS = 0;
+
+  STATUS |= orc_local_search(P, M, prm);
+  if (STATUS) return STATUS;
+  int nactive = orc_active_nodes(out->nodes2mask, M);
+  out->nactive = nactive;
+  int nd = nactive * ndim;
+  orc_active_dofs(out->dofs2mask, out->nodes2mask, nactive, ndim, bcc, nbcc, step, nsteps);
+  memset(out->mass, 0, sizeof(double) * nd);
+  memset(out->dU, 0, sizeof(double) * nd);
+  memset(out->force, 0, sizeof(double) * nd);
+  memset(out->accel, 0, sizeof(double) * nd);
+  memset(out->reaction, 0, sizeof(double) * nd);
+
+  /* __mass_NODES :160-223 == __compute_nodal_lumped_mass */
+  orc_lumped_mass(out->mass, P, M, out->nodes2mask);
+
+  /* __predictor_PARTICLES :229-253 */
+  for (int p = 0; p < np; p++)
+    for (int i = 0; i < ndim; i++) {
+      int idx = p * ndim + i;
+      P->d_dis[idx] = dt * P->vel[idx] + 0.5 * dsqr(dt) * P->acc[idx];
+      P->vel[idx] += (1 - gamma) * dt * P->acc[idx];
+    }
+
+  /* __d_displacement_NODES :301-367 */
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < np; p++) {
+    double N[ORC_MAXNB];
+    int nn = orc_compute_N(N, P, M, p);
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    double m_p = P->mass[p];
+    for (int A = 0; A < nn; A++) {
+      int A_mask = out->nodes2mask[conn[A]];
+#pragma omp critical
+      {
+        for (int i = 0; i < ndim; i++) out->dU[A_mask * ndim + i] += m_p * N[A] * P->d_dis[p * ndim + i];
+      }
+    }
+  }
+  for (int i = 0; i < nd; i++) out->dU[i] = out->dU[i] / out->mass[i];
+
+  /* impose_Dirichlet_Boundary_Conditions :455-527 */
+  for (int b = 0; b < nbcc; b++)
+    for (int j = 0; j < bcc[b].nnodes; j++) {
+      int m = out->nodes2mask[bcc[b].nodes[j]];
+      if (m == -1) continue;
+      for (int k = 0; k < bcc[b].dim; k++)
+        if (bcc[b].dir[k * nsteps + step] == 1) out->dU[m * ndim + k] = bcc[b].value[k * nsteps + step];
+    }
+
+  /* __update_Local_State :530-676: kinematics (J <= 0 is fatal here, :608-613) ... */
+  STATUS |= orc_compatibility(out->dU, NULL, P, M, out->nodes2mask);
+  for (int p = 0; p < np; p++) {
+    if (P->J_n1[p] <= 0.0) STATUS |= 1;
+    double Delta_J_p = I3(&P->DF[p * T], ndim); /* :630-632 */
+    P->rho[p] = P->rho[p] / Delta_J_p;
+  }
+  if (STATUS) return STATUS;
+  /* ... and stress */
+  STATUS |= orc_constitutive(P, mats, prm);
+  if (STATUS) return STATUS;
+
+  /* nodal forces: Forces -= f_int (U-Verlet.c:783) on every dof (fixed dofs keep it as reaction) */
+  {
+    int *alldofs = (int *)calloc((size_t)nd, sizeof(int)); /* all free for the accumulation */
+    double *fint = (double *)calloc((size_t)nd, sizeof(double));
+    STATUS |= orc_internal_forces(fint, P, M, out->nodes2mask, alldofs);
+    for (int i = 0; i < nd; i++) out->force[i] = -fint[i];
+    free(alldofs);
+    free(fint);
+  }
+
+  /* solve_Nodal_Equilibrium :919-957 */
+  for (int A = 0; A < nactive; A++)
+    for (int i = 0; i < ndim; i++) {
+      int idx = A * ndim + i;
+      if (out->dofs2mask[idx] != -1) {
+        out->accel[idx] = (gravity ? gravity[i] : 0.0) + out->force[idx] / out->mass[idx];
+      } else {
+        out->accel[idx] = 0.0;
+        out->reaction[idx] = out->force[idx];
+      }
+    }
+
+  /* G2P :962-1010 */
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < np; p++) {
+    double N[ORC_MAXNB];
+    int nn = orc_compute_N(N, P, M, p);
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    for (int i = 0; i < ndim; i++) {
+      P->acc[p * ndim + i] = 0.0;
+      P->d_dis[p * ndim + i] = 0.0;
+    }
+    for (int A = 0; A < nn; A++) {
+      int A_mask = out->nodes2mask[conn[A]];
+      for (int i = 0; i < ndim; i++) {
+        P->acc[p * ndim + i] += N[A] * out->accel[A_mask * ndim + i];
+        P->d_dis[p * ndim + i] += N[A] * out->dU[A_mask * ndim + i];
+      }
+    }
+  }
+
+  /* compute_Explicit_Newmark_Corrector :1024-1084 */
+  for (int p = 0; p < np; p++) {
+    P->J_n[p] = P->J_n1[p];
+    if (P->kappa_n) P->kappa_n[p] = P->kappa_n1[p];
+    if (P->eps_n) P->eps_n[p] = P->eps_n1[p];
+    if (P->b_e_n)
+      for (int i = 0; i < T; i++) P->b_e_n[p * T + i] = P->b_e_n1[p * T + i];
+    for (int i = 0; i < ndim; i++) {
+      P->vel[p * ndim + i] += gamma * dt * P->acc[p * ndim + i];
+      P->x[p * ndim + i] += P->d_dis[p * ndim + i];
+      P->dis[p * ndim + i] += P->d_dis[p * ndim + i];
+    }
+    for (int i = 0; i < T; i++) P->F_n[p * T + i] = P->F_n1[p * T + i];
+  }
+  return STATUS;
+}
