@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/s of the explicit P2G + stress + G2P step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one fused explicit predictor-corrector particle step (search + LME Newton, P2G of mass
+and momentum, G2P gradient + F-update + Kirchhoff stress, P2G of the internal force, G2P kinematic
+update) over the synthetic cloud.  N = 1 runs BASELINE configs[1]: 3-D elastic cube impact,
+1 M particles (50^3 cells x 8), LME, Neo-Hookean, inside a 60^3-cell grid with a rigid floor.
+N > 1 is WEAK scaling: every rank owns one such 1 M-particle block, stacked along z (the slab axis),
+ghost-node layers exchanged with the two z-neighbours over RCCL (torch.distributed, backend nccl).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic bytes per particle per stage, FP64, 3-D (SURVEY.md §8d / BASELINE.md §3.4)
+BYTES_3D = {"S1": 100, "S2": 123, "S3": 371, "S4": 215, "S5": 408, "step": 1217}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VEC_PEAK_TFLOPS = 78.6  # half the 157.3 TF FP32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cells", type=int, default=50, help="cells per axis of one rank's block (50 -> 1 M particles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=24, help="cells per axis of the CPU-baseline sample")
+    ap.add_argument("--halo", choices=["p2p", "allreduce"], default="p2p")
+    return ap.parse_args()
+
+
+def build_case(rank, world, cells, margin=5):
+    synth = importlib.import_module("nl-partsol_amd.synth")
+    gc = [cells + 2 * margin, cells + 2 * margin, cells * world + 2 * margin]
+    lo = [margin, margin, margin + cells * rank]
+    cloud = synth.make_cloud(3, gc, lo, [cells] * 3, h=1.0, jitter=0.05, seed=12345 + rank,
+                             velocity=[0.0, 0.0, -10.0])
+    return {"ndim": 3, "cells": gc, "grid_n": synth.grid_nodes(gc), "origin": [0.0, 0.0, 0.0], "h": 1.0,
+            "cloud": cloud, "materials": [{"type": 0, "E": 1.0e7, "nu": 0.3}], "block_lo": lo}
+
+
+class SlabHalo:
+    """Ghost-node exchange for a z-slab partition.  Rank r contributes to node layers
+    [zlo_r, zhi_r]; the layers it shares with rank r+-1 are summed (doubles) or OR-ed (bytes) with that
+    neighbour only (xGMI is point-to-point: two concurrent neighbour transfers, no ring).  Nodes are
+    x-fastest / z-slowest, so a range of z layers is one contiguous slice of the nodal array."""
+
+    def __init__(self, torch, dist, rank, world, grid_n, cells, margin, reach=4, mode="p2p"):
+        self.torch, self.dist, self.rank, self.world, self.mode = torch, dist, rank, world, mode
+        self.plane = grid_n[0] * grid_n[1]
+        self.nz = grid_n[2]
+        # rank r's particles live in cells [margin + r*cells, margin + (r+1)*cells); closest node I0 may be
+        # any node plane of those cells, its 5^3 stencil reaches 2 planes further; `reach` adds drift room
+        self.lo = [max(0, margin + r * cells - reach) for r in range(world)]
+        self.hi = [min(self.nz - 1, margin + (r + 1) * cells + reach) for r in range(world)]
+        self.bufs = {}
+
+    def overlap(self, a, b):
+        lo, hi = max(self.lo[a], self.lo[b]), min(self.hi[a], self.hi[b])
+        return (lo, hi) if lo <= hi else None
+
+    def __call__(self, dptr, nfield, elem, kind):
+        torch, dist = self.torch, self.dist
+        dtype = torch.float64 if elem == 8 else torch.uint8
+        n = self.plane * self.nz * nfield
+        arr = _as_tensor(torch, dptr, n, dtype)
+        if self.mode == "allreduce":
+            dist.all_reduce(arr, op=dist.ReduceOp.SUM if kind == 0 else dist.ReduceOp.MAX)
+            return 0
+        ops, recv = [], []
+        for nb in (self.rank - 1, self.rank + 1):
+            if nb < 0 or nb >= self.world:
+                continue
+            ov = self.overlap(self.rank, nb)
+            if ov is None:
+                continue
+            sl = arr[ov[0] * self.plane * nfield:(ov[1] + 1) * self.plane * nfield]
+            key = (nb, nfield, elem)
+            if key not in self.bufs:
+                self.bufs[key] = (torch.empty_like(sl), torch.empty_like(sl))
+            sbuf, rbuf = self.bufs[key]
+            sbuf.copy_(sl)
+            ops.append(dist.P2POp(dist.isend, sbuf, nb))
+            ops.append(dist.P2POp(dist.irecv, rbuf, nb))
+            recv.append((sl, rbuf))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for sl, rbuf in recv:
+            if kind == 0:
+                sl.add_(rbuf)
+            else:
+                torch.maximum(sl, rbuf, out=sl)
+        return 0
+
+
+def _as_tensor(torch, dptr, n, dtype):
+    """Wraps a raw device pointer owned by the library as a torch tensor (no copy)."""
+    itemsize = 8 if dtype == torch.float64 else 1
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8" if itemsize == 8 else "|u1",
+                                  "data": (int(dptr), False), "version": 2}
+    return torch.as_tensor(h, device="cuda")
+
+
+def cpu_baseline(cells):
+    """Times the oracle's explicit step (a from-scratch CPU port, OpenMP, the reference's critical-section
+    structure) on a bounded 3-D sample of the same workload, on all host cores of this box."""
+    os.environ.pop("OMP_NUM_THREADS", None)
+    from oracle import orc
+    synth = importlib.import_module("nl-partsol_amd.synth")
+    margin = 5
+    gc = [cells + 2 * margin] * 3
+    cloud = synth.make_cloud(3, gc, [margin] * 3, [cells] * 3, velocity=[0.0, 0.0, -10.0])
+    M = orc.OracleMesh(3, synth.grid_nodes(gc), [0.0] * 3, 1.0)
+    P = orc.OracleParticles(cloud)
+    prm = orc.default_params()
+    mats = orc.make_materials([{"type": 0, "E": 1.0e7, "nu": 0.3}])
+    assert orc.initialize_lme(P, M, prm) == 0
+    nsteps = 3
+    nodes = synth.plane_nodes(synth.grid_nodes(gc), 2, 0)
+    bcs = orc.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nsteps), dtype=np.int32),
+                       "value": np.zeros((3, nsteps))}])
+    st = orc.ExplicitStepper(P, M, mats, prm, bcs, nsteps)
+    assert st.step(0, 1e-3) == 0  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2:
+        assert st.step(n + 1, 1e-3) == 0
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": P.np * n / dt, "unit": "particle-steps/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "%d^3 cells x 8 = %d particles, 3-D LME Neo-Hookean explicit step, %d steps, oracle/nlps_oracle.c "
+                      "with OpenMP (omp critical nodal accumulation as in U-Newmark-beta.c)" % (cells, P.np, n)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    nlps = importlib.import_module("nl-partsol_amd.nlps")
+    synth = importlib.import_module("nl-partsol_amd.synth")
+
+    margin = 5
+    case = build_case(rank, world, a.cells, margin)
+    total_steps = a.steps + a.warmup + 1
+    stream = torch.cuda.current_stream().cuda_stream
+    S = nlps.Solver(3, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"],
+                    nsteps=total_steps, stream=stream)
+    nodes = synth.plane_nodes(case["grid_n"], 2, 0)
+    bcs = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, total_steps), dtype=np.int32),
+                        "value": np.zeros((3, total_steps))}])
+    if world > 1:
+        halo = SlabHalo(torch, dist, rank, world, case["grid_n"], a.cells, margin, mode=a.halo)
+        S.set_halo_exchange(halo)
+    S.initialise_shapefun()
+    dt = 0.1 * case["h"] / 100.0  # CFL 0.1, celerity sqrt(E/rho) = 100
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    t = 0
+    for _ in range(a.warmup):
+        S.explicit_step(bcs, t, dt)
+        t += 1
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        S.explicit_step(bcs, t, dt)
+        t += 1
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    flags = S.status_flags()
+    if flags:
+        raise SystemExit("bench: particle failure flags 0x%x" % flags)
+
+    # per-kernel times of one more step (HIP events on the launch stream), untimed
+    S.set_timing(True)
+    kms = np.zeros(8)
+    reps = 3
+    for _ in range(reps):
+        S.explicit_step(bcs, min(t, total_steps - 1), dt)
+        kms += np.array(S.get_timing())
+    kms /= reps
+    S.set_timing(False)
+
+    if rank == 0:
+        npart = S.np
+        # dominant kernel = the P2G scatter kernel group with the largest share
+        names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update", "nodal"]
+        alg = [0, BYTES_3D["S1"] + BYTES_3D["S2"], BYTES_3D["S3"] + BYTES_3D["S4"], BYTES_3D["S5"], 0]
+        dom = int(np.argmax(kms[:4]))
+        achieved = npart * alg[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(names[dom])
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "particle-steps/sec (P2G+stress+G2P)", "value": npart * world * a.steps / elapsed,
+            "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D elastic cube impact, %d particles/GPU (%d^3 cells x 8), LME gamma=3, "
+                                   "Neo-Hookean E=1e7 nu=0.3, explicit predictor-corrector step, 1xMI355X per rank; "
+                                   "blocks stacked along z for N>1" % (npart, a.cells),
+                       "particles_total": npart * world, "grid_nodes": int(np.prod(case["grid_n"])),
+                       "halo": a.halo if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_particle": alg[dom], "kernel_ms": float(kms[dom]),
+                         "note": "3-D LME is FP64-ALU/atomic-bound, not HBM-bound (DESIGN.md); see kernel_ms_all"},
+            "kernel_ms_all": {names[i]: float(kms[i]) for i in range(5)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_cells)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

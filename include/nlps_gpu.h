@@ -1,0 +1,206 @@
+/*
+ * nlps_gpu.h — C-ABI of the MI355X (gfx950) implementation of NL-PartSol's particle<->grid transfer
+ * and per-particle stress-update hot path.
+ *
+ * Plain C, plain pointers and sizes.  Every entry point names the reference interface it replaces
+ * (file:line relative to nl-partsol/src of migmolper/NL-PartSol @ v1).  The reference passes its fat
+ * `Particle` / `Mesh` structs by value (Types.h:548-760); here the same data crosses the boundary as
+ * the contiguous row-major arrays those structs already own (`Matrix.nV`, MatrixOp.c:128-181), so the
+ * glue a maintainer adds in U-Newmark-beta.c / U-Static.c is pointer plumbing only.
+ *
+ * Conventions
+ *  - return value: 0 = EXIT_SUCCESS, 1 = EXIT_FAILURE (reference convention, U-Newmark-beta.c:199-204);
+ *    the library never exit()s; nlps_gpu_last_error() returns the message the reference would have
+ *    printed in red on stderr.  A missing GPU / failed HIP call is a failure, never a CPU fallback.
+ *  - arithmetic is FP64; index maps are 32-bit int and bit-identical to the reference's.
+ *  - particle state is device resident between calls (SoA, sorted by background-grid cell); host
+ *    arrays are stale until nlps_gpu_download_state().
+ *  - nodal vectors ("Vec" arrays of the PETSc driver) use the reference's masked numbering
+ *    [Nactivenodes*Ndim], index = Nodes2Mask[node]*Ndim + i.  Each such pointer may be a HOST pointer
+ *    (VecGetArray) or a DEVICE pointer (hipMalloc / torch tensor); the library detects which.
+ *  - threading: one host thread per handle (the PETSc thread); all work is issued on one HIP stream.
+ */
+#ifndef NLPS_GPU_H
+#define NLPS_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nlps_gpu nlps_gpu; /* opaque: device buffers, stream, tables */
+
+#define NLPS_MAXNB 128 /* row stride of downloaded neighbour lists (>= 5^3) */
+
+/* Material.Type strings of Constitutive/Constitutive.c:28-258 that are on the path */
+enum {
+  NLPS_MAT_NEO_HOOKEAN = 0,   /* "Neo-Hookean-Wriggers", Hyperelastic/Neo-Hookean.c:38-85 */
+  NLPS_MAT_HENCKY = 1,        /* "Hencky",               Hyperelastic/Hencky.c:40-94       */
+  NLPS_MAT_DRUCKER_PRAGER = 2 /* "Drucker-Prager",       Plasticity/Drucker-Prager.c:319-613 */
+};
+
+/* Structured background grid (GramsBox mesh, InOutFun/Read_GramsBox.c:54): Q4 / H8 lattice, nodes
+ * numbered x-fastest, elements x-fastest with GiD connectivity order.  h_avg = FEM_Mesh.h_avg
+ * (Read_GramsBox.c:460-507) or NULL to have the library compute it with the same rule. */
+typedef struct {
+  int ndim;          /* NumberDimensions, Macros.h:33-37 */
+  int n[3];          /* nodes per axis */
+  double origin[3];
+  double h;          /* lattice spacing (FEM_Mesh.DeltaX) */
+  const double *h_avg;
+} nlps_grid;
+
+/* Snapshot of the globals the path reads implicitly (Globals.h:21,33-58);
+ * defaults InOutFun/Read_GramsShapeFun.c:100-104. */
+typedef struct {
+  double gamma_lme;        /* gamma_LME        (3.0)   */
+  double tol_zero_lme;     /* TOL_zero_LME     (1e-6)  */
+  double tol_wrapper_lme;  /* TOL_wrapper_LME  (1e-10) */
+  int max_iter_lme;        /* max_iter_LME     (10)    */
+  double tol_radial_returning;   /* TOL_Radial_Returning            */
+  int max_iter_radial_returning; /* Max_Iterations_Radial_Returning */
+} nlps_params;
+
+/* Material, Types.h:359-458 (members read by the three laws) */
+typedef struct {
+  int type;
+  double E, nu;
+  double phi_deg, psi_deg; /* phi_Frictional, psi_Frictional */
+  double kappa_0, exponent_ortiz, eps_0 /* Plastic_Strain_0 */, p_ref /* ReferencePressure */;
+} nlps_material;
+
+/* Particle fields, Types.h:184-283 / 548-623: HOST pointers to the reference's row-major arrays
+ * (MPM_Mesh.Phi.<field>.nV).  T = 5 in 2-D (xx,xy,yx,yy,zz), 9 in 3-D.  Optional members may be NULL. */
+typedef struct {
+  int np;               /* NumGP */
+  double *x_GC;         /* [np][ndim] */
+  double *dis;          /* [np][ndim] */
+  double *vel;          /* [np][ndim] */
+  double *acc;          /* [np][ndim] */
+  double *F_n;          /* [np][T] */
+  double *F_n1;         /* [np][T]  optional on upload (defaults to F_n) */
+  double *DF;           /* [np][T]  optional on upload (identity) */
+  double *Stress;       /* [np][T]  optional on upload (0): Kirchhoff stress */
+  double *b_e_n;        /* [np][T]  optional (identity) */
+  double *b_e_n1;       /* [np][T]  optional */
+  double *J_n;          /* [np] */
+  double *J_n1;         /* [np]     optional (J_n) */
+  double *rho;          /* [np] */
+  double *mass;         /* [np] */
+  double *Vol_0;        /* [np] */
+  double *W;            /* [np]     optional */
+  double *Kappa_n, *Kappa_n1, *EPS_n, *EPS_n1; /* [np] optional (0) */
+  int *MatIdx;          /* [np] */
+  int *I0;              /* [np]      NULL on upload => nlps_gpu_initialize_lme() must be called */
+  double *lambda;       /* [np][ndim] (MPM_Mesh.lambda.nV) optional */
+  double *Beta;         /* [np]       (MPM_Mesh.Beta.nV)   optional */
+} nlps_particles;
+
+/* Dirichlet boundary = Load of FEM_Mesh.Bounds (Types.h:296-351), flattened:
+ * dir[k*nsteps + t] = Dir[k*NumTimeStep+t], value[k*nsteps + t] = Value[k].Fx[t]. */
+typedef struct {
+  int nnodes;
+  const int *nodes;
+  int dim;
+  const int *dir;
+  const double *value;
+} nlps_bcc;
+
+/* ------------------------------------------------------------------ lifetime */
+
+/* Uploads the particle set (AoS -> cell-sorted SoA) and builds the grid tables.
+ * hip_stream: a hipStream_t to issue all work on (NULL = the library creates its own). */
+int nlps_gpu_create(nlps_gpu **h, const nlps_grid *grid, const nlps_params *prm,
+                    const nlps_material *mats, int nmats, const nlps_particles *host, int nsteps,
+                    void *hip_stream);
+int nlps_gpu_destroy(nlps_gpu *h);
+const char *nlps_gpu_last_error(const nlps_gpu *h);
+int nlps_gpu_synchronize(nlps_gpu *h);
+
+/* Copies the device state back into the caller's arrays in the caller's particle order (before VTK/CSV
+ * output, Outputs/WriteVtk.c:95-266, or host tangent assembly).  NULL members are skipped. */
+int nlps_gpu_download_state(nlps_gpu *h, nlps_particles *host);
+/* MPM_Mesh.NumberNodes[p] and ListNodes[p] as arrays (chain order = nodal_set__Particles__ order,
+ * Particles/Particles-Tools.c:71-82): nn[np], list[np][NLPS_MAXNB]. */
+int nlps_gpu_download_lists(nlps_gpu *h, int *nn, int *list);
+/* FEM_Mesh.ActiveNode[nnodes] as bytes */
+int nlps_gpu_download_active(nlps_gpu *h, unsigned char *active);
+/* OR of the per-particle failure flags (1 Newton, 2 connectivity, 4 J<=0, 8 constitutive, 16 halo) */
+int nlps_gpu_status_flags(nlps_gpu *h, int *flags);
+
+/* ------------------------------------------------------------------ level-B stage calls */
+
+/* initialise_shapefun__MeshTools__ -> initialize__LME__, Nodes/LME.c:45-173 */
+int nlps_gpu_initialize_lme(nlps_gpu *h);
+
+/* local_search__MeshTools__ (Nodes/Shape-Functions.c:31-90) -> local_search__LME__ (Nodes/LME.c:895-1015):
+ * I0 update, 1-ring activation, neighbour lists, beta, lambda Newton. */
+int nlps_gpu_local_search(nlps_gpu *h);
+
+/* get_active_nodes__MeshTools__ + get_active_dofs__MeshTools__ (Nodes/Nodes-Tools.c:46-156).
+ * nodes2mask[nnodes] / dofs2mask[nactive*ndim] may be NULL (kept on the device only). */
+int nlps_gpu_active_masks(nlps_gpu *h, const nlps_bcc *bcc, int nbcc, int step, int *nactive,
+                          int *nfree_dofs, int *nodes2mask, int *dofs2mask);
+
+/* __compute_nodal_lumped_mass, U-Newmark-beta.c:528-597.  M[nactive*ndim] is overwritten. */
+int nlps_gpu_lumped_mass(nlps_gpu *h, double *M);
+
+/* __get_nodal_field_n, U-Newmark-beta.c:615-696.  V, A overwritten; needs M from the call above. */
+int nlps_gpu_nodal_field_n(nlps_gpu *h, double *V, double *A, const double *M);
+
+/* __local_compatibility_conditions, U-Newmark-beta.c:1064-1160: DF, F_n1, J_n1 (dU_dt may be NULL:
+ * the rate tensors feed only the Newtonian-fluid law, Constitutive.c:84-108). */
+int nlps_gpu_compatibility(nlps_gpu *h, const double *dU, const double *dU_dt);
+
+/* __constitutive_update -> Stress_integration__Constitutive__, U-Newmark-beta.c:1208-1242,
+ * Constitutive/Constitutive.c:18-258 */
+int nlps_gpu_constitutive(nlps_gpu *h);
+
+/* __nodal_internal_forces, U-Newmark-beta.c:1257-1374 (+ push_forward_dN__MeshTools__,
+ * Shape-Functions.c:405-448).  R[nactive*ndim] is ACCUMULATED into; Dirichlet dofs are skipped. */
+int nlps_gpu_internal_forces(nlps_gpu *h, double *R);
+
+/* __update_particles_internal_variables, U-Newmark-beta.c:1917-1978 */
+int nlps_gpu_roll_state(nlps_gpu *h);
+
+/* __update_particles_kinetics_FLIP_PIC, U-Newmark-beta.c:1993-2072 */
+int nlps_gpu_update_kinetics(nlps_gpu *h, double alpha_blend, const double *dU, const double *Un_dt,
+                             const double *dU_dt, const double *dU_dt2);
+
+/* Fused explicit predictor-corrector step (stage order and formulas of U-Verlet.c:229-253, 301-367,
+ * 455-527, 530-676, 919-1010, 1024-1084; internal force in the Kirchhoff form of
+ * U-Newmark-beta.c:1257-1374).  gravity[ndim] may be NULL.  One P2G+stress+G2P particle step. */
+int nlps_gpu_explicit_step(nlps_gpu *h, const nlps_bcc *bcc, int nbcc, int step, double dt,
+                           double gamma, const double *gravity);
+/* Number of active nodes after the last search (computes Nodes2Mask on the device). */
+int nlps_gpu_num_active(nlps_gpu *h, int *nactive);
+/* Nodal results of the last explicit step in masked numbering (any pointer may be NULL). */
+int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force, double *accel,
+                            double *reaction);
+
+/* ------------------------------------------------------------------ multi-GPU hooks */
+
+/* Halo exchange callback, invoked by explicit_step / the P2G stages after a nodal scatter, on the
+ * handle's stream order.  dptr = device array [nnodes_grid][nfield] of `elem_bytes`-sized elements in
+ * GRID numbering (x fastest, slab axis slowest => a slab halo is one contiguous byte range);
+ * kind: 0 = sum doubles, 1 = OR bytes.  The callee sums/ORs the halo layers with the neighbouring
+ * ranks (RCCL send/recv or all-reduce).  NULL = single GPU. */
+typedef int (*nlps_halo_fn)(void *ctx, void *dptr, int nfield, int elem_bytes, int kind);
+int nlps_gpu_set_halo_exchange(nlps_gpu *h, nlps_halo_fn fn, void *ctx);
+/* Range of node layers along the slab axis this rank's particles may touch (5^d stencil reach). */
+int nlps_gpu_touched_layers(nlps_gpu *h, int *lo, int *hi);
+
+/* ------------------------------------------------------------------ measurement */
+
+/* Time (ms, HIP events on the handle's stream) of the kernels of the last explicit step:
+ * [0] search+activate, [1] lists+Newton+P2G mass/momentum, [2] G2P grad+F+stress+P2G force,
+ * [3] G2P kinematics+roll, [4] nodal/mask kernels.  Enabled with nlps_gpu_set_timing(h,1). */
+int nlps_gpu_set_timing(nlps_gpu *h, int on);
+int nlps_gpu_get_timing(nlps_gpu *h, float ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

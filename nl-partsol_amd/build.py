@@ -1,0 +1,27 @@
+"""Builds the gfx950 shared library (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "nlps_gpu.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "nlps_device.hpp"), os.path.join(HERE, "csrc", "nlps_tables.hpp"),
+        os.path.join(HERE, "..", "include", "nlps_gpu.h")]
+LIB = os.path.join(HERE, "csrc", "libnlps_gpu.so")
+# -ffp-contract=off: index-deciding arithmetic (closest node, cut-off radius) must round exactly like
+# the CPU path; hot loops that may fuse use explicit fma().  -munsafe-fp-atomics: hardware
+# global_atomic_add_f64 instead of a CAS loop.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+         "-munsafe-fp-atomics", "-Wall"]
+
+
+def build(force=False):
+    if not force and os.path.exists(LIB) and all(
+            os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS if os.path.exists(d)):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc] + FLAGS + ["-o", LIB, SRC])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

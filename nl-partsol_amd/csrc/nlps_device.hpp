@@ -1,0 +1,509 @@
+// nlps_device.hpp — device-side building blocks (gfx950): separable LME evaluation on the
+// structured background grid, <=3x3 tensor algebra in registers, the three Kirchhoff-stress laws.
+//
+// Reference semantics (file:line relative to nl-partsol/src of migmolper/NL-PartSol):
+//   p_a, r, J, grad p_a ........ Nodes/LME.c:676-891
+//   Newton for lambda .......... Nodes/LME.c:272-353
+//   Neo-Hookean ................ Constitutive/Hyperelastic/Neo-Hookean.c:18-85
+//   Hencky ..................... Constitutive/Hyperelastic/Hencky.c:40-94,233-285
+//   Drucker-Prager ............. Constitutive/Plasticity/Drucker-Prager.c:319-1084
+//
+// MI355X-first formulation: on a lattice, x_a = x_I0 + h*(i,j,k), so
+//   exp(-beta |l_a|^2 + lambda.l_a) = Ex(i) * Ey(j) * Ez(k)
+// with 5 one-dimensional factors per axis: 15 exp() per evaluation instead of 5^3 = 125, every
+// factor and every partial sum held in registers by one lane (one particle per lane, no cross-lane
+// traffic).  Neighbourhood membership (active node AND |l_a| <= Ra, LME.c:1062-1082) is a 125-bit
+// mask per particle in lexicographic stencil order (bit = i + 5*j + 25*k).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nlps {
+
+typedef unsigned long long u64;
+
+struct GridD {
+  int nd;
+  int n[3];
+  int nnodes;
+  double o[3];
+  double h;
+};
+
+// per-material constants, precomputed on the host with libm so they carry the bits the CPU path has
+struct MatD {
+  int type;
+  double E, nu;
+  double G, lame, K;                 // shear, Lame, bulk (E/(3(1-2nu)))
+  double alpha_F, alpha_Q, beta_dp;  // Drucker-Prager.c:362-375
+  double kappa_0, exp_param, eps_0, p_ref;
+};
+
+struct ParamsD {
+  double gamma_lme, neg_log_tol_zero, tol_wrapper;
+  int max_iter_lme;
+  double tol_radial;
+  int max_iter_radial;
+};
+
+#define NLPS_TOL_NR 10E-6  // Macros.h:40
+
+__device__ __forceinline__ double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }  // Macros.h:49-50
+
+// ------------------------------------------------------------------------------------------------
+// small tensors (row-major, N = 2|3)
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ double det(const double* A) {  // I3__TensorLib__, TensorLib.c:154-168
+  if (N == 2) return A[0] * A[3] - A[1] * A[2];
+  return A[0] * A[4] * A[8] - A[0] * A[5] * A[7] + A[1] * A[5] * A[6] - A[1] * A[3] * A[8] +
+         A[2] * A[3] * A[7] - A[2] * A[4] * A[6];
+}
+
+// inverse__MatrixLib__ (MatrixOp.c:320, LAPACK dgetrf/dgetri in the reference): adjugate / det
+template <int N>
+__device__ __forceinline__ bool inverse(double* Am1, const double* A) {
+  if (N == 2) {
+    double d = A[0] * A[3] - A[1] * A[2];
+    if (d == 0.0) return false;
+    double id = 1.0 / d;
+    Am1[0] = A[3] * id;
+    Am1[1] = -A[1] * id;
+    Am1[2] = -A[2] * id;
+    Am1[3] = A[0] * id;
+    return true;
+  }
+  double c00 = A[4] * A[8] - A[5] * A[7];
+  double c01 = A[5] * A[6] - A[3] * A[8];
+  double c02 = A[3] * A[7] - A[4] * A[6];
+  double d = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  if (d == 0.0) return false;
+  double id = 1.0 / d;
+  Am1[0] = c00 * id;
+  Am1[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+  Am1[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Am1[3] = c01 * id;
+  Am1[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+  Am1[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Am1[6] = c02 * id;
+  Am1[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+  Am1[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  return true;
+}
+
+// rcond__TensorLib__ as the reference really evaluates it (TensorLib.c:966-990: dgecon on the
+// unfactored matrix): 1 / (||A||_1 * ||(L_A U_A)^-1||_1).  Gate only (LME.c:308).
+template <int N>
+__device__ __forceinline__ double rcond_ref(const double* A) {
+  double anorm = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) s += fabs(A[i * N + j]);
+    anorm = s > anorm ? s : anorm;
+  }
+  double LU[N * N], inv[N * N];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        double l = (k < i) ? A[i * N + k] : (k == i ? 1.0 : 0.0);
+        double u = (k <= j) ? A[k * N + j] : 0.0;
+        s += l * u;
+      }
+      LU[i * N + j] = s;
+    }
+  if (anorm == 0.0) return 0.0;
+  if (!inverse<N>(inv, LU)) return 0.0;
+  double inorm = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) s += fabs(inv[i * N + j]);
+    inorm = s > inorm ? s : inorm;
+  }
+  if (!(inorm > 0.0) || isinf(inorm) || isnan(inorm)) return 0.0;
+  return (1.0 / inorm) / anorm;
+}
+
+// Symmetric eigen-decomposition by cyclic Jacobi, all in registers (replaces LAPACKE_dsyev,
+// TensorLib.c:208 / Drucker-Prager.c:635).  Eigenvector A = COLUMN A of v.  Unsorted: every use on
+// the path is a permutation- and sign-invariant sum over A.
+template <int N>
+__device__ __forceinline__ void sym_eigen(double* w, double* v, const double* Ain) {
+  double a[N * N];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      a[i * N + j] = (j >= i) ? Ain[i * N + j] : Ain[j * N + i];
+      v[i * N + j] = (i == j) ? 1.0 : 0.0;
+    }
+#pragma unroll 1
+  for (int sweep = 0; sweep < 12; sweep++) {
+    double off = 0.0, dg = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        if (i != j) off += a[i * N + j] * a[i * N + j];
+        else dg += a[i * N + j] * a[i * N + j];
+      }
+    if (off <= 1e-32 * dg || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < N - 1; p++)
+#pragma unroll
+      for (int q = p + 1; q < N; q++) {
+        double apq = a[p * N + q];
+        if (apq != 0.0) {
+          double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
+          double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+          for (int k = 0; k < N; k++) {
+            double akp = a[k * N + p], akq = a[k * N + q];
+            a[k * N + p] = c * akp - s * akq;
+            a[k * N + q] = s * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < N; k++) {
+            double apk = a[p * N + k], aqk = a[q * N + k];
+            a[p * N + k] = c * apk - s * aqk;
+            a[q * N + k] = s * apk + c * aqk;
+          }
+#pragma unroll
+          for (int k = 0; k < N; k++) {
+            double vkp = v[k * N + p], vkq = v[k * N + q];
+            v[k * N + p] = c * vkp - s * vkq;
+            v[k * N + q] = s * vkp + c * vkq;
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) w[i] = a[i * N + i];
+}
+
+template <int N>
+__device__ __forceinline__ void left_cauchy_green(double* b, const double* F) {  // compute-Strains.c:365-384
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; k++) s += F[i * N + k] * F[j * N + k];
+      b[i * N + j] = s;
+    }
+}
+
+// sum_A T_A n_A (x) n_A with n_A = column A (Hencky.c:248-265; Drucker-Prager.c:755-776, 663-710)
+template <int N>
+__device__ __forceinline__ void ppal_to_xyz(double* T, const double* Tp, const double* v) {
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int A = 0; A < N; A++) s += Tp[A] * v[A + i * N] * v[A + j * N];
+      T[i * N + j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kirchhoff-stress laws.  Tensors are passed as the d x d block t[N*N] plus the 2-D zz slot.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct StressIO {
+  double tau[N * N];
+  double tau_zz;  // 2-D slot 4
+  double W;
+  double be[N * N];
+  double be_zz;
+  double kappa, eps;
+  int fail;
+};
+
+template <int N>
+__device__ __forceinline__ void law_neo_hookean(const MatD& m, const double* F, double J, StressIO<N>& o) {
+  double c0 = m.lame * 0.5 * (J * J - 1.0);
+  double b[N * N];
+  left_cauchy_green<N>(b, F);
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double Id = (i == j) ? 1.0 : 0.0;
+      o.tau[i * N + j] = c0 * Id + m.G * (b[i * N + j] - Id);
+    }
+  o.tau_zz = c0;
+  double I1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; i++) I1 += b[i * N + i];
+  double lj = log(J);
+  double f_J = 0.25 * m.lame * (J * J - 1) - 0.5 * m.lame * lj - m.G * lj;
+  o.W = f_J + 0.5 * m.G * (I1 - (double)N);
+}
+
+template <int N>
+__device__ __forceinline__ void law_hencky(const MatD& m, const double* F, StressIO<N>& o) {
+  double b[N * N], v[N * N], w[3] = {0.0, 0.0, 1.0};  // 2-D: third eigenvalue fixed at 1 (Hencky.c:48)
+  left_cauchy_green<N>(b, F);
+  sym_eigen<N>(w, v, b);
+  double Eh[3], Tp[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) Eh[a] = 0.5 * log(w[a]);
+  double d = m.lame + 2 * m.G;
+  Tp[0] = d * Eh[0] + m.lame * Eh[1] + m.lame * Eh[2];
+  Tp[1] = m.lame * Eh[0] + d * Eh[1] + m.lame * Eh[2];
+  Tp[2] = m.lame * Eh[0] + m.lame * Eh[1] + d * Eh[2];
+  ppal_to_xyz<N>(o.tau, Tp, v);
+  o.tau_zz = Tp[2];
+  o.W = 0.5 * (Tp[0] * Eh[0] + Tp[1] * Eh[1] + Tp[2] * Eh[2]);
+  if (isnan(w[0]) || isnan(w[1])) o.fail = 1;
+}
+
+// Drucker-Prager backward Euler in principal log-strain space.  Statement order follows
+// Drucker-Prager.c:319-613 (elastic :410-432, classical return :457-530, apex return :532-590,
+// corrector :593-610); eigenvectors by column everywhere.
+template <int N>
+__device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD& prm, const double* d_phi,
+                                                   const double* b_e_n, double b_e_n_zz, double kappa_n,
+                                                   double eps_n, StressIO<N>& o) {
+  double btr[N * N], v[N * N], w[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; k++)
+#pragma unroll
+        for (int l = 0; l < N; l++) s += d_phi[i * N + k] * b_e_n[k * N + l] * d_phi[j * N + l];
+      btr[i * N + j] = s;
+    }
+  sym_eigen<N>(w, v, btr);
+  if (N == 2) w[2] = b_e_n_zz;  // :655-657
+
+  double Etr[3] = {0.5 * log(w[0]), 0.5 * log(w[1]), 0.5 * log(w[2])};
+  const double K = m.K, G = m.G, p_ref = m.p_ref;
+  const double alpha_F = m.alpha_F, alpha_Q = m.alpha_Q, beta = m.beta_dp;
+  const double exp_param = m.exp_param, kappa_0 = m.kappa_0, eps_0 = m.eps_0;
+
+  double n[3] = {0, 0, 0}, dEp[3] = {0, 0, 0}, Tp[3];
+  double PHI, PHI_0, d_PHI;
+  double d_gamma_k = 0.0;
+  double eps_k = eps_n, kappa_k = kappa_n, d_kappa_k = 0.0;
+  const double TOL = prm.tol_radial;
+  const int MaxIter = prm.max_iter_radial;
+  int Iter = 0;
+  o.kappa = kappa_n;  // Constitutive.c:160-168: n+1 state starts from n
+  o.eps = eps_n;
+
+  double tr = Etr[0] + Etr[1] + Etr[2];
+  double Evol = (1.0 / 3.0) * tr;
+  double Tvol[3], Tdev[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    Tvol[a] = -p_ref - K * Evol;
+    Tdev[a] = 2 * G * (Etr[a] - Evol);
+  }
+  double pressure = (Tvol[0] + Tvol[1] + Tvol[2]) / 3.0;
+  double J2 = sqrt(Tdev[0] * Tdev[0] + Tdev[1] * Tdev[1] + Tdev[2] * Tdev[2]);
+
+#define NLPS_YIELD(dg, kap) \
+  (J2 - 2.0 * G * (dg)-3.0 * alpha_F * (pressure - 3.0 * K * alpha_Q * (dg)) - beta * (kap))
+
+  PHI = PHI_0 = NLPS_YIELD(d_gamma_k, kappa_k);
+
+  if (PHI_0 <= NLPS_TOL_NR) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) Tp[a] = -Tvol[a] + Tdev[a];
+  } else {
+    if (J2 > NLPS_TOL_NR) {
+      n[0] = Tdev[0] / J2;
+      n[1] = Tdev[1] / J2;
+      n[2] = Tdev[2] / J2;
+    }
+    {
+      double base = 1.0 + eps_n / eps_0;
+      if (base < 0.0) o.fail = 1;
+      d_kappa_k = (kappa_0 / (exp_param * eps_0)) * pow(base, 1.0 / exp_param - 1.0);
+    }
+    double ads = sqrt(1.0 + 3.0 * alpha_Q * alpha_Q);
+    if (alpha_F == 0.0) o.fail = 1;
+    double pressure_limit = 3.0 * alpha_Q * K / (2.0 * G) * J2 +
+                            beta / (3.0 * alpha_F) * ((J2 / (2.0 * G)) * d_kappa_k * ads + kappa_k);
+    if (-pressure < pressure_limit) {
+      while (fabs(PHI / PHI_0) >= TOL) {
+        Iter++;
+        if (Iter == MaxIter) break;
+        d_PHI = 9.0 * K * alpha_F * alpha_Q - 2.0 * G - beta * d_kappa_k * ads;
+        if (fabs(d_PHI) < TOL) { o.fail = 1; break; }
+        d_gamma_k += -PHI / d_PHI;
+        if (d_gamma_k < 0.0) { o.fail = 1; break; }
+        eps_k = eps_n + d_gamma_k * sqrt(3.0 * alpha_Q * alpha_Q + 1.0);
+        if (eps_k < 0.0) { o.fail = 1; break; }
+        double base = 1.0 + eps_k / eps_0;
+        if (base < 0.0) { o.fail = 1; break; }
+        kappa_k = kappa_0 * pow(base, 1.0 / exp_param);
+        if (kappa_k < 0.0) { o.fail = 1; break; }
+        d_kappa_k = (kappa_0 / (exp_param * eps_0)) * pow(base, 1.0 / exp_param - 1.0);
+        PHI = NLPS_YIELD(d_gamma_k, kappa_k);
+      }
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        Tp[a] = -Tvol[a] + Tdev[a] + d_gamma_k * (3 * K * alpha_Q - 2 * G * n[a]);
+        dEp[a] = d_gamma_k * (alpha_Q + n[a]);
+      }
+      o.eps = eps_k;
+      o.kappa = kappa_k;
+    } else {
+      double d_gamma_1 = J2 / (2.0 * G);
+      double d_gamma_2_k = 0.0;
+      d_gamma_k = d_gamma_1 + d_gamma_2_k;
+      while (fabs(PHI / PHI_0) >= TOL) {
+        Iter++;
+        if (Iter == MaxIter) break;
+        double rt = sqrt((d_gamma_1 * d_gamma_1) + 3.0 * (alpha_Q * alpha_Q) * (d_gamma_k * d_gamma_k));
+        d_PHI = 3.0 * alpha_Q * K + 3.0 * d_kappa_k * beta * (alpha_Q * alpha_Q) * d_gamma_k / (3.0 * alpha_F * rt);
+        if (fabs(d_PHI) < TOL) break;
+        d_gamma_2_k += -PHI / d_PHI;
+        if (d_gamma_2_k < 0.0) {
+          d_gamma_k = 0.0;
+          d_gamma_2_k = 0.0;
+          break;
+        } else {
+          d_gamma_k = d_gamma_1 + d_gamma_2_k;
+        }
+        PHI = (beta / (3.0 * alpha_F) *
+                   (kappa_k + d_kappa_k * sqrt((d_gamma_1 * d_gamma_1) +
+                                               3.0 * (alpha_Q * alpha_Q) * (d_gamma_k * d_gamma_k))) -
+               pressure + 3.0 * K * alpha_Q * d_gamma_k);
+      }
+      eps_k = eps_n + d_gamma_k * sqrt(3.0 * alpha_Q * alpha_Q + 1.0);
+      if (eps_k < 0.0) o.fail = 1;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        Tp[a] = -Tvol[a] + d_gamma_k * 3 * K * alpha_Q;
+        dEp[a] = d_gamma_k * alpha_Q + d_gamma_1 * n[a];
+      }
+      o.eps = eps_k;
+      o.kappa = kappa_k;
+    }
+  }
+#undef NLPS_YIELD
+  ppal_to_xyz<N>(o.tau, Tp, v);
+  o.tau_zz = Tp[2];
+  Etr[0] -= dEp[0];
+  Etr[1] -= dEp[1];
+  Etr[2] -= dEp[2];
+  o.W = 0.5 * (Tp[0] * Etr[0] + Tp[1] * Etr[1] + Tp[2] * Etr[2]);
+  double ev[3] = {exp(2 * Etr[0]), exp(2 * Etr[1]), exp(2 * Etr[2])};
+  ppal_to_xyz<N>(o.be, ev, v);
+  o.be_zz = ev[2];
+  if (isnan(w[0]) || isnan(w[1]) || isnan(w[2])) o.fail = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Separable LME context of one particle (one lane).
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+struct Lme {
+  static constexpr int KN = (ND == 3) ? 5 : 1;
+  double lx[5], ly[5], lz[KN];  // l_a components per stencil offset: x_p - x_a
+  double ex[5], ey[5], ez[KN];  // separable factors exp(-beta l^2 + lambda l)
+  int ijk[3];                   // lattice index of I0
+  int I0;
+  u64 mlo, mhi;                 // neighbourhood mask, bit = i + 5*j + 25*k
+
+  __device__ __forceinline__ bool on(int b) const {
+    return b < 64 ? ((mlo >> b) & 1ull) : ((mhi >> (b - 64)) & 1ull);
+  }
+
+  // l_a = x_p - Coordinates[a], with Coordinates = origin + h*idx evaluated exactly like the host
+  // mesh builder does (no FMA contraction: the file is compiled with -ffp-contract=off)
+  __device__ __forceinline__ void geom(const GridD& g, const double* x, int I0_) {
+    I0 = I0_;
+    ijk[0] = I0_ % g.n[0];
+    ijk[1] = (I0_ / g.n[0]) % g.n[1];
+    ijk[2] = I0_ / (g.n[0] * g.n[1]);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      lx[i] = x[0] - (g.o[0] + g.h * (double)(ijk[0] + i - 2));
+      ly[i] = x[1] - (g.o[1] + g.h * (double)(ijk[1] + i - 2));
+      if (ND == 3) lz[i % KN] = x[2 % ND] - (g.o[2] + g.h * (double)(ijk[2] + i - 2));
+    }
+  }
+
+  __device__ __forceinline__ void factors(const double* lam, double beta) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      ex[i] = exp(-beta * (lx[i] * lx[i]) + lam[0] * lx[i]);
+      ey[i] = exp(-beta * (ly[i] * ly[i]) + lam[1] * ly[i]);
+      if (ND == 3) ez[i % KN] = exp(-beta * (lz[i % KN] * lz[i % KN]) + lam[2 % ND] * lz[i % KN]);
+    }
+  }
+
+  __device__ __forceinline__ int node_offset(const GridD& g, int i, int j, int k) const {
+    return (i - 2) + g.n[0] * ((j - 2) + (ND == 3 ? g.n[1] * (k - 2) : 0));
+  }
+};
+
+// Visit every member of the neighbourhood: f(bit, i, j, k, e) with e the UNNORMALISED weight
+// Ex(i)Ey(j)Ez(k).  Fully unrolled so ex/ey/ez/lx/... stay in named registers.
+template <int ND, class F>
+__device__ __forceinline__ void for_each_nb(const Lme<ND>& c, F&& f) {
+#pragma unroll
+  for (int k = 0; k < Lme<ND>::KN; k++) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      double eyz = (ND == 3) ? c.ey[j] * c.ez[k] : c.ey[j];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        int b = i + 5 * j + 25 * k;
+        if (c.on(b)) f(b, i, j, k, c.ex[i] * eyz);
+      }
+    }
+  }
+}
+
+// Z, r = sum p l, J = sum p l(x)l - r(x)r at the current factors (LME.c:766-832).  Jm = full ND x ND.
+template <int ND>
+__device__ __forceinline__ void lme_moments(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
+  double Z = 0.0, s[ND], q[ND * ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) s[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < ND * ND; a++) q[a] = 0.0;
+  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+    double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
+    Z += e;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      double el = e * l[a];
+      s[a] += el;
+#pragma unroll
+      for (int b2 = a; b2 < ND; b2++) q[a * ND + b2] += el * l[b2];
+    }
+  });
+  Zinv = 1.0 / Z;
+#pragma unroll
+  for (int a = 0; a < ND; a++) r[a] = s[a] * Zinv;
+#pragma unroll
+  for (int a = 0; a < ND; a++)
+#pragma unroll
+    for (int b2 = a; b2 < ND; b2++) {
+      double v = q[a * ND + b2] * Zinv - r[a] * r[b2];
+      Jm[a * ND + b2] = v;
+      Jm[b2 * ND + a] = v;
+    }
+}
+
+}  // namespace nlps

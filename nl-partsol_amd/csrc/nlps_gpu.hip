@@ -1,0 +1,1649 @@
+// nlps_gpu.hip — MI355X (gfx950) kernels and C-ABI host code for NL-PartSol's particle<->grid +
+// stress-update hot path.  See include/nlps_gpu.h for the boundary and DESIGN.md for the layout.
+//
+// Layout in HBM
+//   particles : SoA, one contiguous run of `npad` doubles per scalar component (83 components),
+//               sorted by background-grid cell at upload; lane p of a wave reads consecutive
+//               doubles of every component => fully coalesced 512-B wave loads.
+//   nodes     : AoS per node in GRID numbering (x fastest, slab axis slowest): nm[node][1+d] =
+//               {mass, momentum}, dU[node][d], force[node][d], accel[node][d]; a slab halo is one
+//               contiguous byte range.  active[node], fixed[node][d] are bytes.
+// One lane = one particle.  All LME quantities (15 separable exp factors, Z, r, J, J^-1, DF, tau)
+// live in that lane's registers; no MFMA (<=3x3 contractions), no LDS in the gather kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/nlps_gpu.h"
+#include "nlps_device.hpp"
+#include "nlps_tables.hpp"
+
+using namespace nlps;
+
+// ------------------------------------------------------------------------------------------------
+// particle component table
+// ------------------------------------------------------------------------------------------------
+enum {
+  F_X = 0, F_DIS = 3, F_VEL = 6, F_ACC = 9, F_DDIS = 12,
+  F_FN = 15, F_FN1 = 24, F_DF = 33, F_TAU = 42, F_BEN = 51, F_BEN1 = 60,
+  F_JN = 69, F_JN1 = 70, F_RHO = 71, F_MASS = 72, F_VOL0 = 73, F_W = 74,
+  F_KN = 75, F_KN1 = 76, F_EN = 77, F_EN1 = 78, F_LAM = 79, F_BETA = 82, NFD = 83
+};
+
+struct PView {
+  int np;
+  size_t npad;
+  double* d;  // [NFD][npad]
+  int* I0;
+  int* mat;
+  int* nn;
+  int* status;
+  u64* mlo;
+  u64* mhi;
+};
+#define PF(P, f, p) ((P).d[(size_t)(f) * (P).npad + (size_t)(p)])
+
+struct NView {
+  unsigned char* active;  // [nnodes]
+  const double* h_avg;    // [nnodes]
+  double* nm;             // [nnodes][1+ND]
+  double* dU;             // [nnodes][ND]
+  double* force;          // [nnodes][ND]
+  double* accel;          // [nnodes][ND]
+  double* reaction;       // [nnodes][ND]
+  unsigned char* fixed;   // [nnodes][ND]
+};
+
+#define ST_NEWTON 1
+#define ST_CONNECT 2
+#define ST_JACOBIAN 4
+#define ST_CONSTITUTIVE 8
+#define ST_HALO 16
+
+static constexpr int BLK = 256;
+
+__device__ __forceinline__ void atomic_add_f64(double* addr, double v) { unsafeAtomicAdd(addr, v); }
+
+template <int ND>
+__device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
+  int c = 0, mul = 1;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int ca = (a < ND) ? (ijk[a] == 0 ? 0 : (ijk[a] == g.n[a] - 1 ? 2 : 1)) : 1;
+    c += ca * mul;
+    mul *= 3;
+  }
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S1a: closest-node update (LME.c:913-945, Nodes-Tools.c:476-538) + 1-ring activation (LME.c:949-960)
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__device__ __forceinline__ void activate_ring(const GridD& g, unsigned char* active, int I0) {
+  int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+#pragma unroll
+  for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
+#pragma unroll
+    for (int dj = -1; dj <= 1; dj++)
+#pragma unroll
+      for (int di = -1; di <= 1; di++) {
+        int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
+        if (i < 0 || i >= g.n[0] || j < 0 || j >= g.n[1]) continue;
+        if (ND == 3 && (k < 0 || k >= g.n[2])) continue;
+        active[i + g.n[0] * (j + g.n[1] * k)] = 1;
+      }
+}
+
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const uint8_t* __restrict__ rank1) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  double x[ND], aux = 0.0;
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    x[a] = PF(P, F_X + a, p);
+    aux += dsqr(PF(P, F_DIS + a, p));
+  }
+  int I0 = P.I0[p];
+  if (sqrt(aux) > 0.0) {  // norm__MatrixLib__(dis_p,2) > 0, LME.c:924
+    int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+    const uint8_t* rk = rank1 + 27 * class3_of<ND>(g, ijk);
+    double best = 0.0;
+    int bestrank = 256, bestnode = I0;
+#pragma unroll
+    for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
+#pragma unroll
+      for (int dj = -1; dj <= 1; dj++)
+#pragma unroll
+        for (int di = -1; di <= 1; di++) {
+          int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
+          if (i < 0 || i >= g.n[0] || j < 0 || j >= g.n[1]) continue;
+          if (ND == 3 && (k < 0 || k >= g.n[2])) continue;
+          int rank = rk[(di + 1) + 3 * (dj + 1) + 9 * (dk + 1)];
+          // point_distance__MeshTools__: sqrt(sum pow(x - x_I, 2)), Nodes-Tools.c:397-420
+          double D = 0.0, t;
+          t = x[0] - (g.o[0] + g.h * (double)i);
+          D += t * t;
+          t = x[1] - (g.o[1] + g.h * (double)j);
+          D += t * t;
+          if (ND == 3) {
+            t = x[ND - 1] - (g.o[2] + g.h * (double)k);
+            D += t * t;
+          }
+          D = sqrt(D);
+          // strict '<' walking the chain == lexicographic minimum of (distance, chain position)
+          if (bestrank == 256 || D < best || (D == best && rank < bestrank)) {
+            best = D;
+            bestrank = rank;
+            bestnode = i + g.n[0] * (j + g.n[1] * k);
+          }
+        }
+    I0 = bestnode;
+    P.I0[p] = I0;
+  }
+  activate_ring<ND>(g, N.active, I0);
+}
+
+// initialize__LME__ first loop (LME.c:63-115): element search + closest element node
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  double x[ND];
+  int c[3] = {0, 0, 0};
+  bool found = true;
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    x[a] = PF(P, F_X + a, p);
+    int nc = g.n[a] - 1;
+    int ci = (int)floor((x[a] - g.o[a]) / g.h);
+    ci = ci < 0 ? 0 : (ci > nc - 1 ? nc - 1 : ci);
+    while (ci > 0 && x[a] <= g.o[a] + g.h * (double)ci) ci--;
+    while (ci < nc - 1 && x[a] > g.o[a] + g.h * (double)(ci + 1)) ci++;
+    if (x[a] < g.o[a] + g.h * (double)ci || x[a] > g.o[a] + g.h * (double)(ci + 1)) found = false;
+    c[a] = ci;
+  }
+  if (!found) {
+    atomicOr(&P.status[p], ST_CONNECT);
+    return;
+  }
+  // connectivity chain = reverse GiD file order (Read-GID-Mesh.c:411-413): rank of corner (a,b,t)
+  const int fileQ[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+  double best = 0.0;
+  int bestrank = 256, bestnode = 0;
+#pragma unroll
+  for (int t = 0; t < (ND == 3 ? 2 : 1); t++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int filepos = 4 * t + q;
+      int nnod = (ND == 3) ? 8 : 4;
+      int rank = nnod - 1 - filepos;
+      int i = c[0] + fileQ[q][0], j = c[1] + fileQ[q][1], k = c[2] + t;
+      double D = 0.0, tt;
+      tt = x[0] - (g.o[0] + g.h * (double)i);
+      D += tt * tt;
+      tt = x[1] - (g.o[1] + g.h * (double)j);
+      D += tt * tt;
+      if (ND == 3) {
+        tt = x[ND - 1] - (g.o[2] + g.h * (double)k);
+        D += tt * tt;
+      }
+      D = sqrt(D);
+      if (bestrank == 256 || D < best || (D == best && rank < bestrank)) {
+        best = D;
+        bestrank = rank;
+        bestnode = i + g.n[0] * (j + g.n[1] * (ND == 3 ? k : 0));
+      }
+    }
+  P.I0[p] = bestnode;
+  activate_ring<ND>(g, N.active, bestnode);
+}
+
+// ------------------------------------------------------------------------------------------------
+// S1b (+S2): neighbour mask (tributary__LME__, LME.c:1019-1099), beta (LME.c:995-996), Newton for
+// lambda (LME.c:272-353); optionally the explicit predictor (U-Verlet.c:229-253) and the P2G scatter
+// of mass and m*dD (U-Verlet.c:160-223, 301-367 == U-Newmark-beta.c:528-597)
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__device__ __forceinline__ bool load_lme(const PView& P, const GridD& g, int p, Lme<ND>& c, double* lam, double& beta) {
+  double x[ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    x[a] = PF(P, F_X + a, p);
+    lam[a] = PF(P, F_LAM + a, p);
+  }
+  beta = PF(P, F_BETA, p);
+  c.geom(g, x, P.I0[p]);
+  c.mlo = P.mlo[p];
+  c.mhi = P.mhi[p];
+  c.factors(lam, beta);
+  return (c.mlo | c.mhi) != 0ull;
+}
+
+template <int ND, bool P2G>
+__global__ __launch_bounds__(BLK) void k_lists_newton(PView P, GridD g, NView N, ParamsD prm, double dt,
+                                                      double gamma_nm, int* __restrict__ gstatus) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double x[ND], lam[ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    x[a] = PF(P, F_X + a, p);
+    lam[a] = PF(P, F_LAM + a, p);
+  }
+  int I0 = P.I0[p];
+  c.geom(g, x, I0);
+  double beta_prev = PF(P, F_BETA, p);
+  double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052 (beta = 0 at init => +inf)
+  u64 mlo = 0ull, mhi = 0ull;
+#pragma unroll
+  for (int k = 0; k < Lme<ND>::KN; k++)
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        int gi = c.ijk[0] + i - 2, gj = c.ijk[1] + j - 2, gk = (ND == 3) ? c.ijk[2] + k - 2 : 0;
+        bool ok = gi >= 0 && gi < g.n[0] && gj >= 0 && gj < g.n[1] && (ND == 2 || (gk >= 0 && gk < g.n[2]));
+        if (ok) {
+          int node = gi + g.n[0] * (gj + g.n[1] * gk);
+          double sq = 0.0;
+          sq += c.lx[i] * c.lx[i];
+          sq += c.ly[j] * c.ly[j];
+          if (ND == 3) sq += c.lz[k % Lme<ND>::KN] * c.lz[k % Lme<ND>::KN];
+          ok = N.active[node] && (sqrt(sq) <= Ra);
+        }
+        int b = i + 5 * j + 25 * k;
+        if (ok) {
+          if (b < 64) mlo |= (1ull << b);
+          else mhi |= (1ull << (b - 64));
+        }
+      }
+  c.mlo = mlo;
+  c.mhi = mhi;
+  int nn = __popcll(mlo) + __popcll(mhi);
+  int st = 0;
+  if (nn < ND + 1) {  // LME.c:1087-1092
+    P.nn[p] = 0;
+    P.mlo[p] = 0ull;
+    P.mhi[p] = 0ull;
+    atomicOr(&P.status[p], ST_CONNECT);
+    atomicOr(gstatus, ST_CONNECT);
+    return;
+  }
+  double hv = N.h_avg[I0];
+  double beta = prm.gamma_lme / (hv * hv);  // beta__LME__, LME.c:177-185
+
+  int NumIter = 0;
+  double Zinv = 0.0;
+  while (NumIter <= prm.max_iter_lme) {
+    double r[ND], J[ND * ND], Jm1[ND * ND];
+    c.factors(lam, beta);
+    lme_moments<ND>(c, Zinv, r, J);
+    double aux = 0.0;
+#pragma unroll
+    for (int a = 0; a < ND; a++) aux += dsqr(r[a]);
+    if (sqrt(aux) > prm.tol_wrapper) {
+      if (rcond_ref<ND>(J) < 1E-8 || !inverse<ND>(Jm1, J)) {
+        st |= ST_NEWTON;
+        break;
+      }
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        double dl = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < ND; b2++) dl += Jm1[a * ND + b2] * r[b2];
+        lam[a] -= dl;
+      }
+      NumIter++;
+    } else {
+      break;
+    }
+  }
+  if (NumIter >= prm.max_iter_lme) st |= ST_NEWTON;
+
+  P.nn[p] = nn;
+  P.mlo[p] = mlo;
+  P.mhi[p] = mhi;
+  PF(P, F_BETA, p) = beta;
+#pragma unroll
+  for (int a = 0; a < ND; a++) PF(P, F_LAM + a, p) = lam[a];
+  if (st) {
+    atomicOr(&P.status[p], st);
+    atomicOr(gstatus, st);
+  }
+
+  if (P2G) {
+    double m = PF(P, F_MASS, p);
+    double dd[ND];
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      double v = PF(P, F_VEL + a, p), ac = PF(P, F_ACC + a, p);
+      dd[a] = dt * v + 0.5 * dsqr(dt) * ac;
+      PF(P, F_DDIS + a, p) = dd[a];
+      PF(P, F_VEL + a, p) = v + (1 - gamma_nm) * dt * ac;
+    }
+    double mz = m * Zinv;
+    for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+      int node = I0 + c.node_offset(g, i, j, k);
+      double w = mz * e;
+      double* dst = N.nm + (size_t)node * (1 + ND);
+      atomic_add_f64(dst, w);
+#pragma unroll
+      for (int a = 0; a < ND; a++) atomic_add_f64(dst + 1 + a, w * dd[a]);
+    });
+  }
+}
+
+// generic P2G of m*N*{1 | vel,acc}: __compute_nodal_lumped_mass (U-Newmark-beta.c:528-597) and the
+// accumulation loop of __get_nodal_field_n (:615-696).  out = [nnodes][NF]
+template <int ND, int MODE>  // MODE 0: mass (NF=1)   1: vel & acc (NF = 2*ND)
+__global__ __launch_bounds__(BLK) void k_p2g(PView P, GridD g, double* __restrict__ out) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  constexpr int NF = MODE == 0 ? 1 : 2 * ND;
+  double vals[NF];
+  if (MODE == 0) vals[0] = 1.0;
+  else {
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      vals[a] = PF(P, F_VEL + a, p);
+      vals[ND + a] = PF(P, F_ACC + a, p);
+    }
+  }
+  double Z = 0.0;
+  for_each_nb<ND>(c, [&](int, int, int, int, double e) { Z += e; });
+  double mz = PF(P, F_MASS, p) * (1.0 / Z);
+  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+    int node = c.I0 + c.node_offset(g, i, j, k);
+    double w = mz * e;
+#pragma unroll
+    for (int f = 0; f < NF; f++) atomic_add_f64(out + (size_t)node * NF + f, w * vals[f]);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3 (+S4): G2P of grad(dU) -> DF, F_n1, J (U-Newmark-beta.c:1064-1160 / U-Verlet.c:530-632), stress
+// (Constitutive.c:18-258), P2G of the internal force (U-Newmark-beta.c:1257-1374)
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__device__ __forceinline__ void load_block(const PView& P, int f0, int p, double* t, double& zz) {
+#pragma unroll
+  for (int s = 0; s < ND * ND; s++) t[s] = PF(P, f0 + s, p);
+  zz = (ND == 2) ? PF(P, f0 + 4, p) : 0.0;
+}
+template <int ND>
+__device__ __forceinline__ void store_block(const PView& P, int f0, int p, const double* t, double zz, bool with_zz) {
+#pragma unroll
+  for (int s = 0; s < ND * ND; s++) PF(P, f0 + s, p) = t[s];
+  if (ND == 2 && with_zz) PF(P, f0 + 4, p) = zz;
+}
+
+template <int ND>
+__device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* __restrict__ mats, const ParamsD& prm,
+                                             const double* Fn1, const double* DF, double J, double* tau) {
+  MatD m = mats[P.mat[p]];
+  StressIO<ND> o;
+  o.fail = 0;
+  o.kappa = 0.0;
+  o.eps = 0.0;
+  if (m.type == NLPS_MAT_NEO_HOOKEAN) {
+    law_neo_hookean<ND>(m, Fn1, J, o);
+  } else if (m.type == NLPS_MAT_HENCKY) {
+    law_hencky<ND>(m, Fn1, o);
+  } else {
+    double be[ND * ND], bzz;
+    load_block<ND>(P, F_BEN, p, be, bzz);
+    law_drucker_prager<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
+    store_block<ND>(P, F_BEN1, p, o.be, o.be_zz, true);
+    PF(P, F_KN1, p) = o.kappa;
+    PF(P, F_EN1, p) = o.eps;
+  }
+#pragma unroll
+  for (int s = 0; s < ND * ND; s++) tau[s] = o.tau[s];
+  store_block<ND>(P, F_TAU, p, o.tau, o.tau_zz, true);
+  PF(P, F_W, p) = o.W;
+  return o.fail ? ST_CONSTITUTIVE : 0;
+}
+
+// B[i][m] = sign * V0 * sum_jq tau[i][j] DF^-T[j][q] J^-1[q][m];  f_A = p_A * B l_A
+template <int ND>
+__device__ __forceinline__ bool force_operator(double* B, const double* tau, const double* DF, const double* Jm1,
+                                               double V0, double sign) {
+  double DFt[ND * ND], DFmT[ND * ND], M1[ND * ND];
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int j = 0; j < ND; j++) DFt[i * ND + j] = DF[j * ND + i];
+  if (!inverse<ND>(DFmT, DFt)) return false;  // compute_adjunt__TensorLib__, TensorLib.c:829-905
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int q = 0; q < ND; q++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; j++) s += tau[i * ND + j] * DFmT[j * ND + q];
+      M1[i * ND + q] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int m = 0; m < ND; m++) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < ND; q++) s += M1[i * ND + q] * Jm1[q * ND + m];
+      B[i * ND + m] = -sign * V0 * s;  // grad p_a = -p_a J^-1 l_a
+    }
+  return true;
+}
+
+template <int ND>
+__device__ __forceinline__ void scatter_force(const Lme<ND>& c, const GridD& g, double Zinv, const double* B,
+                                              double* __restrict__ force) {
+  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+    int node = c.I0 + c.node_offset(g, i, j, k);
+    double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
+    double pa = e * Zinv;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      double s = 0.0;
+#pragma unroll
+      for (int m = 0; m < ND; m++) s += B[a * ND + m] * l[m];
+      atomic_add_f64(force + (size_t)node * ND + a, pa * s);
+    }
+  });
+}
+
+// MODE 0: compatibility only (level B)   1: explicit fused (compat + density + stress + force scatter)
+template <int ND, int MODE>
+__global__ __launch_bounds__(BLK) void k_g2p_grad(PView P, GridD g, const double* __restrict__ dU,
+                                                  double* __restrict__ force, const MatD* __restrict__ mats,
+                                                  ParamsD prm, int* __restrict__ gstatus) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  double Z = 0.0, s[ND], q[ND * ND], G[ND * ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) s[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < ND * ND; a++) {
+    q[a] = 0.0;
+    G[a] = 0.0;
+  }
+  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+    int node = c.I0 + c.node_offset(g, i, j, k);
+    double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
+    double u[ND];
+#pragma unroll
+    for (int a = 0; a < ND; a++) u[a] = dU[(size_t)node * ND + a];
+    Z += e;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      double el = e * l[a];
+      s[a] += el;
+#pragma unroll
+      for (int b2 = a; b2 < ND; b2++) q[a * ND + b2] += el * l[b2];
+#pragma unroll
+      for (int b2 = 0; b2 < ND; b2++) G[b2 * ND + a] += el * u[b2];  // G[i][m] = sum p dU_i l_m
+    }
+  });
+  double Zinv = 1.0 / Z, r[ND], J[ND * ND], Jm1[ND * ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) r[a] = s[a] * Zinv;
+#pragma unroll
+  for (int a = 0; a < ND; a++)
+#pragma unroll
+    for (int b2 = a; b2 < ND; b2++) {
+      double v = q[a * ND + b2] * Zinv - r[a] * r[b2];
+      J[a * ND + b2] = v;
+      J[b2 * ND + a] = v;
+    }
+  int st = 0;
+  if (!inverse<ND>(Jm1, J)) st |= ST_NEWTON;
+  // DF = I + sum_A dU_A (x) grad N_A = I - (G/Z) J^-T           (compute-Strains.c:20-44)
+  double DF[ND * ND], Fn[ND * ND], Fn1[ND * ND], fzz;
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int j = 0; j < ND; j++) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < ND; m++) v += (G[i * ND + m] * Zinv) * Jm1[j * ND + m];
+      DF[i * ND + j] = ((i == j) ? 1.0 : 0.0) - v;
+    }
+  load_block<ND>(P, F_FN, p, Fn, fzz);
+#pragma unroll
+  for (int i = 0; i < ND; i++)  // update_Deformation_Gradient_n1__Particles__, compute-Strains.c:76-105
+#pragma unroll
+    for (int j = 0; j < ND; j++) {
+      double a2 = 0.0;
+#pragma unroll
+      for (int k2 = 0; k2 < ND; k2++) a2 += DF[i * ND + k2] * Fn[k2 * ND + j];
+      Fn1[i * ND + j] = a2;
+    }
+  double Jn1 = det<ND>(Fn1);
+  if (Jn1 <= 0.0) {
+    st |= ST_JACOBIAN;
+    if (MODE == 0) Jn1 = 0.0;  // implicit path clamps (U-Newmark-beta.c:1137-1142); explicit path fails (U-Verlet.c:608-613)
+  }
+  store_block<ND>(P, F_DF, p, DF, 0.0, false);
+  store_block<ND>(P, F_FN1, p, Fn1, 0.0, false);
+  PF(P, F_JN1, p) = Jn1;
+  if (MODE == 1) {
+    PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
+    double tau[ND * ND], B[ND * ND];
+    st |= stress_update<ND>(P, p, mats, prm, Fn1, DF, Jn1, tau);
+    if (force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0)) scatter_force<ND>(c, g, Zinv, B, force);
+    else st |= ST_JACOBIAN;
+  }
+  if (st) {
+    atomicOr(&P.status[p], st);
+    atomicOr(gstatus, st);
+  }
+}
+
+// __constitutive_update (U-Newmark-beta.c:1208-1242)
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict__ mats, ParamsD prm,
+                                                int* __restrict__ gstatus) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  double Fn1[ND * ND], DF[ND * ND], tau[ND * ND], z;
+  load_block<ND>(P, F_FN1, p, Fn1, z);
+  load_block<ND>(P, F_DF, p, DF, z);
+  int st = stress_update<ND>(P, p, mats, prm, Fn1, DF, PF(P, F_JN1, p), tau);
+  if (st) {
+    atomicOr(&P.status[p], st);
+    atomicOr(gstatus, st);
+  }
+}
+
+// __nodal_internal_forces (U-Newmark-beta.c:1257-1374): +V0 tau (DF^-T grad N) into force[nnodes][ND]
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_fint(PView P, GridD g, double* __restrict__ force, int* __restrict__ gstatus) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  double Zinv, r[ND], J[ND * ND], Jm1[ND * ND], tau[ND * ND], DF[ND * ND], B[ND * ND], z;
+  lme_moments<ND>(c, Zinv, r, J);
+  load_block<ND>(P, F_TAU, p, tau, z);
+  load_block<ND>(P, F_DF, p, DF, z);
+  if (inverse<ND>(Jm1, J) && force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), 1.0)) {
+    scatter_force<ND>(c, g, Zinv, B, force);
+  } else {
+    atomicOr(&P.status[p], ST_JACOBIAN);
+    atomicOr(gstatus, ST_JACOBIAN);
+  }
+}
+
+// S5 explicit: G2P of nodal acceleration and dU (U-Verlet.c:962-1010), corrector + roll (:1024-1084)
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_g2p_update(PView P, GridD g, const double* __restrict__ accel,
+                                                    const double* __restrict__ dU, double dt, double gamma_nm) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  double Z = 0.0, sa[ND], su[ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    sa[a] = 0.0;
+    su[a] = 0.0;
+  }
+  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+    int node = c.I0 + c.node_offset(g, i, j, k);
+    Z += e;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      sa[a] += e * accel[(size_t)node * ND + a];
+      su[a] += e * dU[(size_t)node * ND + a];
+    }
+  });
+  double Zinv = 1.0 / Z;
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    double ac = sa[a] * Zinv, dd = su[a] * Zinv;
+    PF(P, F_ACC + a, p) = ac;
+    PF(P, F_DDIS + a, p) = dd;
+    PF(P, F_VEL + a, p) = PF(P, F_VEL + a, p) + gamma_nm * dt * ac;
+    PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
+    PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
+  }
+  PF(P, F_JN, p) = PF(P, F_JN1, p);
+  PF(P, F_KN, p) = PF(P, F_KN1, p);
+  PF(P, F_EN, p) = PF(P, F_EN1, p);
+  constexpr int T = (ND == 2) ? 5 : 9;
+#pragma unroll
+  for (int s2 = 0; s2 < T; s2++) {
+    PF(P, F_BEN + s2, p) = PF(P, F_BEN1 + s2, p);
+    PF(P, F_FN + s2, p) = PF(P, F_FN1 + s2, p);
+  }
+}
+
+// __update_particles_kinetics_FLIP_PIC (U-Newmark-beta.c:1993-2072): 4 nodal arrays [nnodes][ND]
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_kinetics(PView P, GridD g, double alpha_blend, const double* __restrict__ dU,
+                                                  const double* __restrict__ Un_dt, const double* __restrict__ dU_dt,
+                                                  const double* __restrict__ dU_dt2) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  double Z = 0.0, s0[ND], s1[ND], s2[ND], s3[ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) s0[a] = s1[a] = s2[a] = s3[a] = 0.0;
+  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
+    size_t o = (size_t)(c.I0 + c.node_offset(g, i, j, k)) * ND;
+    Z += e;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      s0[a] += e * dU[o + a];
+      s1[a] += e * Un_dt[o + a];
+      s2[a] += e * dU_dt[o + a];
+      s3[a] += e * dU_dt2[o + a];
+    }
+  });
+  double Zinv = 1.0 / Z, beta_blend = 1 - alpha_blend;
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    double du = s0[a] * Zinv;
+    PF(P, F_ACC + a, p) = PF(P, F_ACC + a, p) + s3[a] * Zinv;
+    PF(P, F_VEL + a, p) = alpha_blend * PF(P, F_VEL + a, p) + (s2[a] * Zinv + beta_blend * (s1[a] * Zinv));
+    PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + du;
+    PF(P, F_X + a, p) = PF(P, F_X + a, p) + du;
+  }
+}
+
+// __update_particles_internal_variables (U-Newmark-beta.c:1917-1978)
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_roll(PView P) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  double J = PF(P, F_JN1, p);
+  PF(P, F_JN, p) = J;
+  PF(P, F_RHO, p) = PF(P, F_MASS, p) / (PF(P, F_VOL0, p) * J);
+  PF(P, F_KN, p) = PF(P, F_KN1, p);
+  PF(P, F_EN, p) = PF(P, F_EN1, p);
+  constexpr int T = (ND == 2) ? 5 : 9;
+#pragma unroll
+  for (int s = 0; s < T; s++) {
+    PF(P, F_BEN + s, p) = PF(P, F_BEN1 + s, p);
+    PF(P, F_FN + s, p) = PF(P, F_FN1 + s, p);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// nodal kernels (grid numbering)
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ void k_nodal_dU(int nnodes, NView N) {  // U-Verlet.c:357-362
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  bool act = N.active[A];
+  double M = N.nm[(size_t)A * (1 + ND)];
+#pragma unroll
+  for (int a = 0; a < ND; a++) N.dU[(size_t)A * ND + a] = act ? N.nm[(size_t)A * (1 + ND) + 1 + a] / M : 0.0;
+}
+
+template <int ND>
+__global__ void k_bc(const int* __restrict__ nodes, int n, int dim, int dirbits, double v0, double v1, double v2,
+                     NView N) {  // impose_Dirichlet_Boundary_Conditions, U-Verlet.c:455-527
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int A = nodes[q];
+  if (!N.active[A]) return;
+  double v[3] = {v0, v1, v2};
+#pragma unroll
+  for (int k = 0; k < ND; k++)
+    if (k < dim && ((dirbits >> k) & 1)) {
+      N.dU[(size_t)A * ND + k] = v[k];
+      N.fixed[(size_t)A * ND + k] = 1;
+    }
+}
+
+template <int ND>
+__global__ void k_nodal_accel(int nnodes, NView N, double g0, double g1, double g2) {  // U-Verlet.c:947-957
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  bool act = N.active[A];
+  double M = N.nm[(size_t)A * (1 + ND)];
+  double gv[3] = {g0, g1, g2};
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    size_t o = (size_t)A * ND + a;
+    double f = N.force[o];
+    bool fx = N.fixed[o];
+    N.accel[o] = (act && !fx) ? gv[a] + f / M : 0.0;
+    N.reaction[o] = (act && fx) ? f : 0.0;
+  }
+}
+
+// masked <-> grid numbering
+__global__ void k_expand(double* __restrict__ grid, const double* __restrict__ masked, const int* __restrict__ n2m,
+                         int nnodes, int nf) {
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  int m = n2m[A];
+  for (int f = 0; f < nf; f++) grid[(size_t)A * nf + f] = (m >= 0) ? masked[(size_t)m * nf + f] : 0.0;
+}
+
+// mode 0: out = grid[A*gstride + goff + (bcast?0:f)]
+// mode 1: out += ... skipping fixed dofs (d2m == -1)
+// mode 2: out = (fixed ? 0 : grid) / div[idx]
+__global__ void k_compact(double* __restrict__ out, const double* __restrict__ grid, const int* __restrict__ n2m,
+                          const int* __restrict__ d2m, const double* __restrict__ div, int nnodes, int nf, int gstride,
+                          int goff, int bcast, int mode) {
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  int m = n2m[A];
+  if (m < 0) return;
+  for (int f = 0; f < nf; f++) {
+    size_t idx = (size_t)m * nf + f;
+    double v = grid[(size_t)A * gstride + goff + (bcast ? 0 : f)];
+    if (mode == 0) out[idx] = v;
+    else if (mode == 1) {
+      if (d2m[idx] != -1) out[idx] += v;
+    } else {
+      out[idx] = ((d2m[idx] == -1) ? 0.0 : v) / div[idx];
+    }
+  }
+}
+
+// ---- exclusive scan of byte flags -> (flag ? running index : -1); 1024 items per block
+__global__ void k_scan_count(const unsigned char* __restrict__ flags, int n, int invert, int* __restrict__ bsum) {
+  __shared__ int sh[256];
+  int base = blockIdx.x * 1024 + threadIdx.x * 4, c = 0;
+  for (int q = 0; q < 4; q++)
+    if (base + q < n) c += ((flags[base + q] != 0) != (invert != 0));
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = sh[0];
+}
+__global__ void k_scan_top(int* __restrict__ bsum, int nb, int* __restrict__ total) {
+  // one 1024-thread block; each thread owns a contiguous chunk
+  __shared__ int sh[1024];
+  int chunk = (nb + 1023) / 1024;
+  int lo = threadIdx.x * chunk, hi = min(nb, lo + chunk), c = 0;
+  for (int q = lo; q < hi; q++) c += bsum[q];
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = ((int)threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = sh[threadIdx.x] - c;
+  for (int q = lo; q < hi; q++) {
+    int v = bsum[q];
+    bsum[q] = run;
+    run += v;
+  }
+  if (threadIdx.x == 1023) *total = sh[1023];
+}
+__global__ void k_scan_write(const unsigned char* __restrict__ flags, int n, int invert, const int* __restrict__ bsum,
+                             int* __restrict__ out) {
+  __shared__ int sh[256];
+  int base = blockIdx.x * 1024 + threadIdx.x * 4;
+  int f[4], c = 0;
+  for (int q = 0; q < 4; q++) {
+    f[q] = (base + q < n) ? ((flags[base + q] != 0) != (invert != 0)) : 0;
+    c += f[q];
+  }
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = ((int)threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = bsum[blockIdx.x] + sh[threadIdx.x] - c;
+  for (int q = 0; q < 4; q++)
+    if (base + q < n) {
+      out[base + q] = f[q] ? run : -1;
+      run += f[q];
+    }
+}
+// get_active_dofs__MeshTools__ marking loop (Nodes-Tools.c:96-135) in masked numbering
+__global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int dim, int dirbits, int ndof,
+                                    const int* __restrict__ n2m, unsigned char* __restrict__ fixedm) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  int m = n2m[nodes[q]];
+  if (m < 0) return;
+  for (int k = 0; k < dim; k++)
+    if ((dirbits >> k) & 1) fixedm[(size_t)m * ndof + k] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct BcDev {
+  const int* host_nodes;
+  int n;
+  int* dnodes;
+};
+
+struct nlps_gpu {
+  int nd, T;
+  GridD g;
+  ParamsD prm;
+  nlps_params hprm;
+  int nsteps;
+  hipStream_t stream;
+  bool own_stream;
+  std::string err;
+
+  PView P;
+  std::vector<int> perm;  // sorted slot -> caller's particle index
+  NView N;
+  double* h_avg_d;
+  MatD* mats_d;
+  int nmats;
+  uint8_t* rank1_d;
+  nlps_host::StencilTables tab;
+
+  // masks
+  int* n2m_d;
+  int* d2m_d;
+  unsigned char* fixedm_d;
+  int* bsum_d;
+  int* total_d;
+  int* gstatus_d;
+  int nactive, nfree;
+  bool masks_valid;
+
+  // scratch nodal arrays
+  double* gridA;  // [nnodes][2*ND] general purpose
+  double* gridB;  // [nnodes][ND] x4 for kinetics
+  double* maskedA;
+  size_t maskedA_cap;
+
+  std::vector<BcDev> bcs;
+
+  nlps_halo_fn halo;
+  void* halo_ctx;
+
+  bool timing;
+  hipEvent_t ev[8];
+  float ms[8];
+  int slab_lo, slab_hi;
+};
+
+#define HIPCHK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      fprintf(stderr, "\033[1;31mError in nlps_gpu: %s\033[0m\n", h->err.c_str());           \
+      return 1;                                                                              \
+    }                                                                                        \
+  } while (0)
+
+static inline int nblk(int n, int b = BLK) { return (n + b - 1) / b; }
+
+static bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+static MatD make_mat(const nlps_material& m, int nd) {
+  MatD d;
+  memset(&d, 0, sizeof(d));
+  d.type = m.type;
+  d.E = m.E;
+  d.nu = m.nu;
+  d.G = m.E / (2.0 * (1.0 + m.nu));
+  d.lame = m.nu * m.E / ((1 - m.nu * 2) * (1 + m.nu));
+  d.K = m.E / (3.0 * (1.0 - 2.0 * m.nu));
+  const double PI = 3.14159265358979323846;
+  double rf = (PI / 180.0) * m.phi_deg, rd = (PI / 180.0) * m.psi_deg;
+  auto sq = [](double a) { return a == 0.0 ? 0.0 : a * a; };
+  if (nd == 2) {  // Drucker-Prager.c:362-368
+    d.alpha_F = sqrt(2. / 3.) * tan(rf) / sqrt(3. + 4. * sq(tan(rf)));
+    d.alpha_Q = sqrt(2. / 3.) * tan(rd) / sqrt(3. + 4. * sq(tan(rd)));
+    d.beta_dp = sqrt(2. / 3.) * 3. / sqrt(3. + 4. * sq(tan(rf)));
+  } else {  // :370-375
+    d.alpha_F = sqrt(2 / 3.) * 2 * sin(rf) / (3 - sin(rf));
+    d.alpha_Q = sqrt(2 / 3.) * 2 * sin(rd) / (3 - sin(rd));
+    d.beta_dp = sqrt(2 / 3.) * 6 * cos(rf) / (3 - sin(rf));
+  }
+  d.kappa_0 = m.kappa_0;
+  d.exp_param = m.exponent_ortiz;
+  d.eps_0 = m.eps_0;
+  d.p_ref = m.p_ref;
+  return d;
+}
+
+// h_avg exactly as compute_nodal_distance_local does it (Read_GramsBox.c:460-507): chain order sum
+static void host_h_avg(const nlps_grid& G, const nlps_host::StencilTables& tab, std::vector<double>& out) {
+  int nd = G.ndim;
+  int n[3] = {G.n[0], G.n[1], nd == 3 ? G.n[2] : 1};
+  size_t nn = (size_t)n[0] * n[1] * n[2];
+  out.resize(nn);
+  // per class: offsets sorted by chain position
+  std::vector<std::vector<std::array<int, 3>>> chains(27);
+  for (int cls = 0; cls < 27; cls++) {
+    std::vector<std::pair<int, int>> v;
+    for (int o = 0; o < 27; o++)
+      if (tab.rank1[cls][o] != 255) v.push_back({tab.rank1[cls][o], o});
+    std::sort(v.begin(), v.end());
+    for (auto& pr : v) chains[cls].push_back({pr.second % 3 - 1, (pr.second / 3) % 3 - 1, pr.second / 9 - 1});
+  }
+  for (size_t I = 0; I < nn; I++) {
+    int ijk[3] = {(int)(I % n[0]), (int)((I / n[0]) % n[1]), (int)(I / ((size_t)n[0] * n[1]))};
+    int cls = 0, mul = 1;
+    for (int a = 0; a < 3; a++) {
+      int ca = a < nd ? nlps_host::class3(ijk[a], n[a]) : 1;
+      cls += ca * mul;
+      mul *= 3;
+    }
+    double avg = 0.0;
+    int cnt = 0;
+    for (auto& o : chains[cls]) {
+      if (o[0] == 0 && o[1] == 0 && o[2] == 0) continue;
+      double aux = 0.0;
+      for (int a = 0; a < nd; a++) {
+        double xb = G.origin[a] + G.h * (double)(ijk[a] + o[a]);
+        double xa = G.origin[a] + G.h * (double)ijk[a];
+        double d = xb - xa;
+        aux += (d == 0.0 ? 0.0 : d * d);
+      }
+      avg += pow(aux, 0.5);
+      cnt++;
+    }
+    out[I] = avg / (double)cnt;
+  }
+}
+
+template <class T>
+static int dev_alloc(nlps_gpu* h, T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), h->stream));
+  return 0;
+}
+
+static int ensure_masked(nlps_gpu* h, size_t n) {
+  if (n <= h->maskedA_cap) return 0;
+  if (h->maskedA) HIPCHK(hipFree(h->maskedA));
+  HIPCHK(hipMalloc((void**)&h->maskedA, n * sizeof(double)));
+  h->maskedA_cap = n;
+  return 0;
+}
+
+extern "C" const char* nlps_gpu_last_error(const nlps_gpu* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int nlps_gpu_synchronize(nlps_gpu* h) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int nlps_gpu_set_halo_exchange(nlps_gpu* h, nlps_halo_fn fn, void* ctx) {
+  h->halo = fn;
+  h->halo_ctx = ctx;
+  return 0;
+}
+
+extern "C" int nlps_gpu_touched_layers(nlps_gpu* h, int* lo, int* hi) {
+  *lo = h->slab_lo;
+  *hi = h->slab_hi;
+  return 0;
+}
+
+extern "C" int nlps_gpu_set_timing(nlps_gpu* h, int on) {
+  h->timing = on != 0;
+  return 0;
+}
+extern "C" int nlps_gpu_get_timing(nlps_gpu* h, float ms[8]) {
+  for (int i = 0; i < 8; i++) ms[i] = h->ms[i];
+  return 0;
+}
+
+static int upload_field(nlps_gpu* h, int f, int ncomp, const double* src, int stride, std::vector<double>& tmp,
+                        const double* dflt_diag /*identity rows*/, double dflt) {
+  // gathers component c of the caller's AoS rows into the sorted SoA slot
+  int np = h->P.np;
+  for (int c = 0; c < ncomp; c++) {
+    for (int s = 0; s < np; s++) {
+      int p = h->perm[s];
+      tmp[s] = src ? src[(size_t)p * stride + c] : (dflt_diag ? dflt_diag[c] : dflt);
+    }
+    for (size_t s = np; s < h->P.npad; s++) tmp[s] = 0.0;
+    HIPCHK(hipMemcpy(h->P.d + (size_t)(f + c) * h->P.npad, tmp.data(), h->P.npad * sizeof(double),
+                     hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps_params* prm,
+                               const nlps_material* mats, int nmats, const nlps_particles* host, int nsteps,
+                               void* hip_stream) {
+  nlps_gpu* h = new nlps_gpu();
+  *out = h;
+  h->nd = grid->ndim;
+  h->T = grid->ndim == 2 ? 5 : 9;
+  h->nsteps = nsteps;
+  h->halo = nullptr;
+  h->halo_ctx = nullptr;
+  h->timing = false;
+  h->masks_valid = false;
+  h->maskedA = nullptr;
+  h->maskedA_cap = 0;
+  memset(h->ms, 0, sizeof(h->ms));
+  if (grid->ndim != 2 && grid->ndim != 3) {
+    h->err = "ndim must be 2 or 3";
+    return 1;
+  }
+  for (int a = 0; a < grid->ndim; a++)
+    if (grid->n[a] < 5) {
+      h->err = "structured grid needs >= 5 nodes per axis";
+      return 1;
+    }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) {
+    h->err = "no HIP device: the MI355X path has no CPU fallback";
+    return 1;
+  }
+  if (hip_stream) {
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+  } else {
+    HIPCHK(hipStreamCreate(&h->stream));
+    h->own_stream = true;
+  }
+  for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&h->ev[i]));
+
+  GridD& g = h->g;
+  g.nd = grid->ndim;
+  for (int a = 0; a < 3; a++) {
+    g.n[a] = a < g.nd ? grid->n[a] : 1;
+    g.o[a] = a < g.nd ? grid->origin[a] : 0.0;
+  }
+  g.h = grid->h;
+  g.nnodes = g.n[0] * g.n[1] * g.n[2];
+  h->hprm = *prm;
+  h->prm.gamma_lme = prm->gamma_lme;
+  h->prm.neg_log_tol_zero = -log(prm->tol_zero_lme);
+  h->prm.tol_wrapper = prm->tol_wrapper_lme;
+  h->prm.max_iter_lme = prm->max_iter_lme;
+  h->prm.tol_radial = prm->tol_radial_returning;
+  h->prm.max_iter_radial = prm->max_iter_radial_returning;
+
+  h->tab = nlps_host::build_tables(g.nd);
+  HIPCHK(hipMalloc((void**)&h->rank1_d, 27 * 27));
+  HIPCHK(hipMemcpy(h->rank1_d, h->tab.rank1, 27 * 27, hipMemcpyHostToDevice));
+
+  // nodal arrays
+  size_t nn = (size_t)g.nnodes;
+  int ND = g.nd;
+  if (dev_alloc(h, &h->N.active, nn)) return 1;
+  if (dev_alloc(h, &h->N.nm, nn * (1 + ND))) return 1;
+  if (dev_alloc(h, &h->N.dU, nn * ND)) return 1;
+  if (dev_alloc(h, &h->N.force, nn * ND)) return 1;
+  if (dev_alloc(h, &h->N.accel, nn * ND)) return 1;
+  if (dev_alloc(h, &h->N.reaction, nn * ND)) return 1;
+  if (dev_alloc(h, &h->N.fixed, nn * ND)) return 1;
+  if (dev_alloc(h, &h->h_avg_d, nn)) return 1;
+  if (dev_alloc(h, &h->n2m_d, nn)) return 1;
+  if (dev_alloc(h, &h->d2m_d, nn * ND)) return 1;
+  if (dev_alloc(h, &h->fixedm_d, nn * ND)) return 1;
+  if (dev_alloc(h, &h->bsum_d, nn * ND / 1024 + 2)) return 1;
+  if (dev_alloc(h, &h->total_d, 4)) return 1;
+  if (dev_alloc(h, &h->gstatus_d, 4)) return 1;
+  if (dev_alloc(h, &h->gridA, nn * 2 * ND)) return 1;
+  if (dev_alloc(h, &h->gridB, nn * 4 * ND)) return 1;
+  {
+    std::vector<double> hv;
+    if (grid->h_avg) hv.assign(grid->h_avg, grid->h_avg + nn);
+    else host_h_avg(*grid, h->tab, hv);
+    HIPCHK(hipMemcpy(h->h_avg_d, hv.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    h->N.h_avg = h->h_avg_d;
+  }
+  // materials
+  h->nmats = nmats;
+  {
+    std::vector<MatD> md(nmats);
+    for (int i = 0; i < nmats; i++) md[i] = make_mat(mats[i], g.nd);
+    HIPCHK(hipMalloc((void**)&h->mats_d, sizeof(MatD) * nmats));
+    HIPCHK(hipMemcpy(h->mats_d, md.data(), sizeof(MatD) * nmats, hipMemcpyHostToDevice));
+  }
+
+  // particles: sort by background-grid cell
+  int np = host->np;
+  h->P.np = np;
+  h->P.npad = ((size_t)np + 255) / 256 * 256;
+  if (h->P.npad == 0) h->P.npad = 256;
+  h->perm.resize(np);
+  std::iota(h->perm.begin(), h->perm.end(), 0);
+  {
+    std::vector<long long> key(np);
+    int slab_axis = ND - 1;
+    int lo = 1 << 30, hi = -1;
+    for (int p = 0; p < np; p++) {
+      long long k = 0, mul = 1;
+      for (int a = 0; a < ND; a++) {
+        int nc = g.n[a] - 1;
+        int c = (int)floor((host->x_GC[(size_t)p * ND + a] - g.o[a]) / g.h);
+        c = c < 0 ? 0 : (c > nc - 1 ? nc - 1 : c);
+        k += mul * c;
+        mul *= nc;
+        if (a == slab_axis) {
+          lo = std::min(lo, c);
+          hi = std::max(hi, c + 1);
+        }
+      }
+      key[p] = k;
+    }
+    std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    h->slab_lo = std::max(0, lo - 3);
+    h->slab_hi = std::min(g.n[slab_axis] - 1, hi + 3);
+  }
+  HIPCHK(hipMalloc((void**)&h->P.d, (size_t)NFD * h->P.npad * sizeof(double)));
+  HIPCHK(hipMemset(h->P.d, 0, (size_t)NFD * h->P.npad * sizeof(double)));
+  if (dev_alloc(h, &h->P.I0, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.mat, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.nn, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.status, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.mlo, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.mhi, h->P.npad)) return 1;
+  {
+    std::vector<double> tmp(h->P.npad);
+    int T = h->T;
+    double idrow[9] = {0};
+    idrow[0] = 1.0;
+    idrow[ND + 1] = 1.0;
+    idrow[T - 1] = 1.0;
+    if (upload_field(h, F_X, ND, host->x_GC, ND, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_DIS, ND, host->dis, ND, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_VEL, ND, host->vel, ND, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_ACC, ND, host->acc, ND, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_FN, T, host->F_n, T, tmp, idrow, 0.0)) return 1;
+    if (upload_field(h, F_FN1, T, host->F_n1 ? host->F_n1 : host->F_n, T, tmp, idrow, 0.0)) return 1;
+    if (upload_field(h, F_DF, T, host->DF, T, tmp, idrow, 0.0)) return 1;
+    if (upload_field(h, F_TAU, T, host->Stress, T, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_BEN, T, host->b_e_n, T, tmp, idrow, 0.0)) return 1;
+    if (upload_field(h, F_BEN1, T, host->b_e_n1 ? host->b_e_n1 : host->b_e_n, T, tmp, idrow, 0.0)) return 1;
+    if (upload_field(h, F_JN, 1, host->J_n, 1, tmp, nullptr, 1.0)) return 1;
+    if (upload_field(h, F_JN1, 1, host->J_n1 ? host->J_n1 : host->J_n, 1, tmp, nullptr, 1.0)) return 1;
+    if (upload_field(h, F_RHO, 1, host->rho, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_MASS, 1, host->mass, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_VOL0, 1, host->Vol_0, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_W, 1, host->W, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_KN, 1, host->Kappa_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_KN1, 1, host->Kappa_n1 ? host->Kappa_n1 : host->Kappa_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_EN, 1, host->EPS_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_EN1, 1, host->EPS_n1 ? host->EPS_n1 : host->EPS_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_LAM, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_BETA, 1, host->Beta, 1, tmp, nullptr, 0.0)) return 1;
+    std::vector<int> it(h->P.npad, 0);
+    for (int s = 0; s < np; s++) it[s] = host->MatIdx ? host->MatIdx[h->perm[s]] : 0;
+    HIPCHK(hipMemcpy(h->P.mat, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
+    if (host->I0) {
+      for (int s = 0; s < np; s++) it[s] = host->I0[h->perm[s]];
+      HIPCHK(hipMemcpy(h->P.I0, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
+  if (!h) return 0;
+  (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.nm,
+                  h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
+                  h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
+                  h->rank1_d};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& b : h->bcs)
+    if (b.dnodes) (void)hipFree(b.dnodes);
+  for (int i = 0; i < 8; i++) (void)hipEventDestroy(h->ev[i]);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+static int download_field(nlps_gpu* h, int f, int ncomp, double* dst, int stride, std::vector<double>& tmp) {
+  if (!dst) return 0;
+  int np = h->P.np;
+  for (int c = 0; c < ncomp; c++) {
+    HIPCHK(hipMemcpy(tmp.data(), h->P.d + (size_t)(f + c) * h->P.npad, (size_t)np * sizeof(double),
+                     hipMemcpyDeviceToHost));
+    for (int s = 0; s < np; s++) dst[(size_t)h->perm[s] * stride + c] = tmp[s];
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int ND = h->nd, T = h->T, np = h->P.np;
+  std::vector<double> tmp(h->P.npad);
+  if (download_field(h, F_X, ND, o->x_GC, ND, tmp)) return 1;
+  if (download_field(h, F_DIS, ND, o->dis, ND, tmp)) return 1;
+  if (download_field(h, F_VEL, ND, o->vel, ND, tmp)) return 1;
+  if (download_field(h, F_ACC, ND, o->acc, ND, tmp)) return 1;
+  if (download_field(h, F_FN, T, o->F_n, T, tmp)) return 1;
+  if (download_field(h, F_FN1, T, o->F_n1, T, tmp)) return 1;
+  if (download_field(h, F_DF, T, o->DF, T, tmp)) return 1;
+  if (download_field(h, F_TAU, T, o->Stress, T, tmp)) return 1;
+  if (download_field(h, F_BEN, T, o->b_e_n, T, tmp)) return 1;
+  if (download_field(h, F_BEN1, T, o->b_e_n1, T, tmp)) return 1;
+  if (download_field(h, F_JN, 1, o->J_n, 1, tmp)) return 1;
+  if (download_field(h, F_JN1, 1, o->J_n1, 1, tmp)) return 1;
+  if (download_field(h, F_RHO, 1, o->rho, 1, tmp)) return 1;
+  if (download_field(h, F_MASS, 1, o->mass, 1, tmp)) return 1;
+  if (download_field(h, F_VOL0, 1, o->Vol_0, 1, tmp)) return 1;
+  if (download_field(h, F_W, 1, o->W, 1, tmp)) return 1;
+  if (download_field(h, F_KN, 1, o->Kappa_n, 1, tmp)) return 1;
+  if (download_field(h, F_KN1, 1, o->Kappa_n1, 1, tmp)) return 1;
+  if (download_field(h, F_EN, 1, o->EPS_n, 1, tmp)) return 1;
+  if (download_field(h, F_EN1, 1, o->EPS_n1, 1, tmp)) return 1;
+  if (download_field(h, F_LAM, ND, o->lambda, ND, tmp)) return 1;
+  if (download_field(h, F_BETA, 1, o->Beta, 1, tmp)) return 1;
+  if (o->I0) {
+    std::vector<int> it(np);
+    HIPCHK(hipMemcpy(it.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+    for (int s = 0; s < np; s++) o->I0[h->perm[s]] = it[s];
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_download_lists(nlps_gpu* h, int* nn_out, int* list) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int np = h->P.np, ND = h->nd;
+  std::vector<int> I0(np);
+  std::vector<u64> lo(np), hi(np);
+  HIPCHK(hipMemcpy(I0.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(lo.data(), h->P.mlo, (size_t)np * sizeof(u64), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hi.data(), h->P.mhi, (size_t)np * sizeof(u64), hipMemcpyDeviceToHost));
+  const GridD& g = h->g;
+  for (int s = 0; s < np; s++) {
+    int p = h->perm[s];
+    int ijk[3] = {I0[s] % g.n[0], (I0[s] / g.n[0]) % g.n[1], I0[s] / (g.n[0] * g.n[1])};
+    int cls = 0, mul = 1;
+    for (int a = 0; a < 3; a++) {
+      cls += (a < ND ? nlps_host::class5(ijk[a], g.n[a]) : 2) * mul;
+      mul *= 5;
+    }
+    // walk NodalLocality[I0] in chain order, keep members, then reverse (prepend-push, LME.c:1077)
+    int tmp[NLPS_MAXNB], nt = 0;
+    for (int q = 0; q < h->tab.count2[cls]; q++) {
+      int b = h->tab.order2[cls][q];
+      bool on = b < 64 ? ((lo[s] >> b) & 1ull) : ((hi[s] >> (b - 64)) & 1ull);
+      if (!on) continue;
+      int i = b % 5, j = (b / 5) % 5, k = b / 25;
+      tmp[nt++] = I0[s] + (i - 2) + g.n[0] * ((j - 2) + (ND == 3 ? g.n[1] * (k - 2) : 0));
+    }
+    nn_out[p] = nt;
+    for (int a = 0; a < nt; a++) list[(size_t)p * NLPS_MAXNB + a] = tmp[nt - 1 - a];
+    for (int a = nt; a < NLPS_MAXNB; a++) list[(size_t)p * NLPS_MAXNB + a] = -1;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_download_active(nlps_gpu* h, unsigned char* active) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(active, h->N.active, (size_t)h->g.nnodes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int nlps_gpu_status_flags(nlps_gpu* h, int* flags) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(flags, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind) {
+  if (!h->halo) return 0;
+  int st = h->halo(h->halo_ctx, dptr, nfield, elem, kind);
+  if (st) {
+    h->err = "halo exchange callback failed";
+    return 1;
+  }
+  return 0;
+}
+
+#define LAUNCH_ND(kern2, kern3, grid, ...)                                                     \
+  do {                                                                                         \
+    if (h->nd == 2) hipLaunchKernelGGL(kern2, dim3(grid), dim3(BLK), 0, h->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern3, dim3(grid), dim3(BLK), 0, h->stream, __VA_ARGS__);          \
+  } while (0)
+
+static int compute_node_mask(nlps_gpu* h) {
+  int nn = h->g.nnodes, nb = (nn + 1023) / 1024;
+  hipLaunchKernelGGL(k_scan_count, dim3(nb), dim3(256), 0, h->stream, h->N.active, nn, 0, h->bsum_d);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, h->stream, h->bsum_d, nb, h->total_d);
+  hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(256), 0, h->stream, h->N.active, nn, 0, h->bsum_d, h->n2m_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm) {
+  int np = h->P.np;
+  HIPCHK(hipMemsetAsync(h->N.active, 0, (size_t)h->g.nnodes, h->stream));  // Shape-Functions.c:38-46
+  if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N);
+  else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d);
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->N.active, 1, 1, 1)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+  if (p2g) LAUNCH_ND((k_lists_newton<2, true>), (k_lists_newton<3, true>), nblk(np), h->P, h->g, h->N, h->prm, dt,
+                     gamma_nm, h->gstatus_d);
+  else LAUNCH_ND((k_lists_newton<2, false>), (k_lists_newton<3, false>), nblk(np), h->P, h->g, h->N, h->prm, dt,
+                 gamma_nm, h->gstatus_d);
+  HIPCHK(hipGetLastError());
+  h->masks_valid = false;
+  return 0;
+}
+
+static int check_status(nlps_gpu* h, int fatal_mask, const char* where) {
+  int st = 0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(&st, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost));
+  if (st & fatal_mask) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "Error in %s: particle failure flags 0x%x (1 Newton, 2 connectivity, 4 J<=0, 8 law)",
+             where, st);
+    h->err = buf;
+    fprintf(stderr, "\033[1;31m%s\033[0m\n", buf);
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_initialize_lme(nlps_gpu* h) {
+  // beta and lambda start at zero (Generate-One-Phase-Analysis.c:190-192) => first list is the
+  // whole active 2-ring (LME.c:150-154)
+  HIPCHK(hipMemsetAsync(h->P.d + (size_t)F_LAM * h->P.npad, 0, 4 * h->P.npad * sizeof(double), h->stream));
+  if (search_and_lists(h, true, false, 0.0, 0.0)) return 1;
+  if (compute_node_mask(h)) return 1;
+  return check_status(h, ST_NEWTON | ST_CONNECT, "initialize__LME__()");
+}
+
+extern "C" int nlps_gpu_local_search(nlps_gpu* h) {
+  if (search_and_lists(h, false, false, 0.0, 0.0)) return 1;
+  if (compute_node_mask(h)) return 1;
+  return check_status(h, ST_NEWTON | ST_CONNECT, "local_search__LME__()");
+}
+
+static int ensure_bcs(nlps_gpu* h, const nlps_bcc* bcc, int nbcc) {
+  bool same = (int)h->bcs.size() == nbcc;
+  for (int i = 0; same && i < nbcc; i++) same = h->bcs[i].host_nodes == bcc[i].nodes && h->bcs[i].n == bcc[i].nnodes;
+  if (same) return 0;
+  for (auto& b : h->bcs)
+    if (b.dnodes) (void)hipFree(b.dnodes);
+  h->bcs.clear();
+  for (int i = 0; i < nbcc; i++) {
+    BcDev b{bcc[i].nodes, bcc[i].nnodes, nullptr};
+    if (b.n > 0) {
+      HIPCHK(hipMalloc((void**)&b.dnodes, (size_t)b.n * sizeof(int)));
+      HIPCHK(hipMemcpy(b.dnodes, bcc[i].nodes, (size_t)b.n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    h->bcs.push_back(b);
+  }
+  return 0;
+}
+
+static int dirbits_of(const nlps_bcc& b, int step, int nsteps) {
+  int bits = 0;
+  for (int k = 0; k < b.dim && k < 3; k++)
+    if (b.dir[(size_t)k * nsteps + step] == 1) bits |= 1 << k;
+  return bits;
+}
+
+extern "C" int nlps_gpu_active_masks(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, int* nactive,
+                                     int* nfree_dofs, int* nodes2mask, int* dofs2mask) {
+  int ND = h->nd, nn = h->g.nnodes;
+  if (compute_node_mask(h)) return 1;
+  HIPCHK(hipMemcpyAsync(&h->nactive, h->total_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int order = h->nactive * ND;
+  if (ensure_bcs(h, bcc, nbcc)) return 1;
+  HIPCHK(hipMemsetAsync(h->fixedm_d, 0, (size_t)nn * ND, h->stream));
+  for (int i = 0; i < nbcc; i++) {
+    if (h->bcs[i].n == 0) continue;
+    hipLaunchKernelGGL(k_mark_fixed_masked, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes,
+                       h->bcs[i].n, bcc[i].dim, dirbits_of(bcc[i], step, h->nsteps), ND, h->n2m_d, h->fixedm_d);
+  }
+  int nb = (order + 1023) / 1024;
+  if (order > 0) {
+    hipLaunchKernelGGL(k_scan_count, dim3(nb), dim3(256), 0, h->stream, h->fixedm_d, order, 1, h->bsum_d);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, h->stream, h->bsum_d, nb, h->total_d + 1);
+    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(256), 0, h->stream, h->fixedm_d, order, 1, h->bsum_d, h->d2m_d);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&h->nfree, h->total_d + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (order == 0) h->nfree = 0;
+  if (nactive) *nactive = h->nactive;
+  if (nfree_dofs) *nfree_dofs = h->nfree;
+  if (nodes2mask) HIPCHK(hipMemcpy(nodes2mask, h->n2m_d, (size_t)nn * sizeof(int), hipMemcpyDeviceToHost));
+  if (dofs2mask && order) HIPCHK(hipMemcpy(dofs2mask, h->d2m_d, (size_t)order * sizeof(int), hipMemcpyDeviceToHost));
+  h->masks_valid = true;
+  return 0;
+}
+
+// masked nodal vector of the caller (host or device) -> grid-numbered device array
+static int to_grid(nlps_gpu* h, double* grid, const double* masked, int nf) {
+  size_t n = (size_t)h->nactive * nf;
+  const double* src = masked;
+  if (!is_device_ptr(masked)) {
+    if (ensure_masked(h, n)) return 1;
+    HIPCHK(hipMemcpyAsync(h->maskedA, masked, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    src = h->maskedA;
+  }
+  hipLaunchKernelGGL(k_expand, dim3(nblk(h->g.nnodes)), dim3(BLK), 0, h->stream, grid, src, h->n2m_d, h->g.nnodes, nf);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// grid-numbered device array -> caller's masked vector (mode: see k_compact)
+static int from_grid(nlps_gpu* h, double* masked, const double* grid, int nf, int gstride, int goff, int bcast, int mode,
+                     const double* div_masked) {
+  size_t n = (size_t)h->nactive * nf;
+  if (n == 0) return 0;
+  bool dev_out = is_device_ptr(masked);
+  if (ensure_masked(h, 2 * n)) return 1;
+  double* dst = dev_out ? masked : h->maskedA;
+  if (!dev_out && mode == 1) HIPCHK(hipMemcpyAsync(dst, masked, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const double* div = div_masked;
+  if (div_masked && !is_device_ptr(div_masked)) {
+    HIPCHK(hipMemcpyAsync(h->maskedA + n, div_masked, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    div = h->maskedA + n;
+  }
+  hipLaunchKernelGGL(k_compact, dim3(nblk(h->g.nnodes)), dim3(BLK), 0, h->stream, dst, grid, h->n2m_d, h->d2m_d, div,
+                     h->g.nnodes, nf, gstride, goff, bcast, mode);
+  HIPCHK(hipGetLastError());
+  if (!dev_out) {
+    HIPCHK(hipMemcpyAsync(masked, dst, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+static int need_masks(nlps_gpu* h, const char* who) {
+  if (h->masks_valid) return 0;
+  h->err = std::string(who) + ": call nlps_gpu_active_masks() after the local search first";
+  return 1;
+}
+
+extern "C" int nlps_gpu_lumped_mass(nlps_gpu* h, double* M) {
+  if (need_masks(h, "nlps_gpu_lumped_mass")) return 1;
+  int ND = h->nd;
+  HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * sizeof(double), h->stream));
+  LAUNCH_ND((k_p2g<2, 0>), (k_p2g<3, 0>), nblk(h->P.np), h->P, h->g, h->gridA);
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->gridA, 1, 8, 0)) return 1;
+  return from_grid(h, M, h->gridA, ND, 1, 0, 1, 0, nullptr);
+}
+
+extern "C" int nlps_gpu_nodal_field_n(nlps_gpu* h, double* V, double* A, const double* M) {
+  if (need_masks(h, "nlps_gpu_nodal_field_n")) return 1;
+  int ND = h->nd;
+  HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * 2 * ND * sizeof(double), h->stream));
+  LAUNCH_ND((k_p2g<2, 1>), (k_p2g<3, 1>), nblk(h->P.np), h->P, h->g, h->gridA);
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->gridA, 2 * ND, 8, 0)) return 1;
+  if (from_grid(h, V, h->gridA, ND, 2 * ND, 0, 0, 2, M)) return 1;
+  return from_grid(h, A, h->gridA, ND, 2 * ND, ND, 0, 2, M);
+}
+
+extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const double* dU_dt) {
+  (void)dU_dt;  // rate tensors: consumed only by the out-of-scope Newtonian-fluid law (Constitutive.c:84-108)
+  if (need_masks(h, "nlps_gpu_compatibility")) return 1;
+  if (to_grid(h, h->N.dU, dU, h->nd)) return 1;
+  LAUNCH_ND((k_g2p_grad<2, 0>), (k_g2p_grad<3, 0>), nblk(h->P.np), h->P, h->g, h->N.dU, (double*)nullptr, h->mats_d,
+            h->prm, h->gstatus_d);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nlps_gpu_constitutive(nlps_gpu* h) {
+  LAUNCH_ND((k_stress<2>), (k_stress<3>), nblk(h->P.np), h->P, h->mats_d, h->prm, h->gstatus_d);
+  HIPCHK(hipGetLastError());
+  return check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()");
+}
+
+extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
+  if (need_masks(h, "nlps_gpu_internal_forces")) return 1;
+  int ND = h->nd;
+  HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
+  LAUNCH_ND((k_fint<2>), (k_fint<3>), nblk(h->P.np), h->P, h->g, h->N.force, h->gstatus_d);
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->N.force, ND, 8, 0)) return 1;
+  return from_grid(h, R, h->N.force, ND, ND, 0, 0, 1, nullptr);
+}
+
+extern "C" int nlps_gpu_roll_state(nlps_gpu* h) {
+  LAUNCH_ND((k_roll<2>), (k_roll<3>), nblk(h->P.np), h->P);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const double* dU, const double* Un_dt,
+                                        const double* dU_dt, const double* dU_dt2) {
+  if (need_masks(h, "nlps_gpu_update_kinetics")) return 1;
+  int ND = h->nd;
+  size_t st = (size_t)h->g.nnodes * ND;
+  if (to_grid(h, h->gridB, dU, ND)) return 1;
+  if (to_grid(h, h->gridB + st, Un_dt, ND)) return 1;
+  if (to_grid(h, h->gridB + 2 * st, dU_dt, ND)) return 1;
+  if (to_grid(h, h->gridB + 3 * st, dU_dt2, ND)) return 1;
+  LAUNCH_ND((k_kinetics<2>), (k_kinetics<3>), nblk(h->P.np), h->P, h->g, alpha_blend, h->gridB, h->gridB + st,
+            h->gridB + 2 * st, h->gridB + 3 * st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, double dt, double gamma_nm,
+                                      const double* gravity) {
+  int ND = h->nd, np = h->P.np, nn = h->g.nnodes;
+  if (ensure_bcs(h, bcc, nbcc)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(hipMemsetAsync(h->N.nm, 0, (size_t)nn * (1 + ND) * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)nn * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.fixed, 0, (size_t)nn * ND, h->stream));
+  // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel)
+  if (search_and_lists(h, false, true, dt, gamma_nm)) return 1;
+  if (halo(h, h->N.nm, 1 + ND, 8, 0)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+  // nodal: dU = (sum m N dD) / M, Dirichlet values
+  if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N);
+  else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N);
+  for (int i = 0; i < nbcc; i++) {
+    if (h->bcs[i].n == 0) continue;
+    double v[3] = {0, 0, 0};
+    for (int k = 0; k < bcc[i].dim && k < 3; k++) v[k] = bcc[i].value[(size_t)k * h->nsteps + step];
+    int bits = dirbits_of(bcc[i], step, h->nsteps);
+    if (ND == 2)
+      hipLaunchKernelGGL(k_bc<2>, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n,
+                         bcc[i].dim, bits, v[0], v[1], v[2], h->N);
+    else
+      hipLaunchKernelGGL(k_bc<3>, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n,
+                         bcc[i].dim, bits, v[0], v[1], v[2], h->N);
+  }
+  HIPCHK(hipGetLastError());
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+  // S3 + S4
+  LAUNCH_ND((k_g2p_grad<2, 1>), (k_g2p_grad<3, 1>), nblk(np), h->P, h->g, h->N.dU, h->N.force, h->mats_d, h->prm,
+            h->gstatus_d);
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->N.force, ND, 8, 0)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
+  double gv[3] = {0, 0, 0};
+  if (gravity)
+    for (int a = 0; a < ND; a++) gv[a] = gravity[a];
+  if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N, gv[0], gv[1], gv[2]);
+  else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N, gv[0], gv[1], gv[2]);
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
+  // S5
+  LAUNCH_ND((k_g2p_update<2>), (k_g2p_update<3>), nblk(np), h->P, h->g, h->N.accel, h->N.dU, dt, gamma_nm);
+  HIPCHK(hipGetLastError());
+  if (h->timing) {
+    HIPCHK(hipEventRecord(h->ev[6], h->stream));
+    HIPCHK(hipEventSynchronize(h->ev[6]));
+    float t01, t12, t23, t34, t45, t56;
+    HIPCHK(hipEventElapsedTime(&t01, h->ev[0], h->ev[1]));
+    HIPCHK(hipEventElapsedTime(&t12, h->ev[1], h->ev[2]));
+    HIPCHK(hipEventElapsedTime(&t23, h->ev[2], h->ev[3]));
+    HIPCHK(hipEventElapsedTime(&t34, h->ev[3], h->ev[4]));
+    HIPCHK(hipEventElapsedTime(&t45, h->ev[4], h->ev[5]));
+    HIPCHK(hipEventElapsedTime(&t56, h->ev[5], h->ev[6]));
+    h->ms[0] = t01;
+    h->ms[1] = t12;
+    h->ms[2] = t34;
+    h->ms[3] = t56;
+    h->ms[4] = t23 + t45;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_num_active(nlps_gpu* h, int* nactive) {
+  if (compute_node_mask(h)) return 1;
+  HIPCHK(hipMemcpyAsync(&h->nactive, h->total_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *nactive = h->nactive;
+  return 0;
+}
+
+extern "C" int nlps_gpu_explicit_nodal(nlps_gpu* h, double* mass, double* dU, double* force, double* accel,
+                                       double* reaction) {
+  int ND = h->nd;
+  if (compute_node_mask(h)) return 1;
+  HIPCHK(hipMemcpyAsync(&h->nactive, h->total_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (mass && from_grid(h, mass, h->N.nm, ND, 1 + ND, 0, 1, 0, nullptr)) return 1;
+  if (dU && from_grid(h, dU, h->N.dU, ND, ND, 0, 0, 0, nullptr)) return 1;
+  if (force && from_grid(h, force, h->N.force, ND, ND, 0, 0, 0, nullptr)) return 1;
+  if (accel && from_grid(h, accel, h->N.accel, ND, ND, 0, 0, 0, nullptr)) return 1;
+  if (reaction && from_grid(h, reaction, h->N.reaction, ND, ND, 0, 0, 0, nullptr)) return 1;
+  return check_status(h, ST_NEWTON | ST_CONNECT | ST_JACOBIAN | ST_CONSTITUTIVE, "nlps_gpu_explicit_step()");
+}

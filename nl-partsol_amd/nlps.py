@@ -1,0 +1,352 @@
+"""ctypes binding of libnlps_gpu.so (include/nlps_gpu.h) and a thin host-side mirror of the
+reference's stage interface.
+
+Method names follow the reference's functions so that parity tests read like the reference driver
+(nl-partsol/src/Formulations/Displacements/U-Newmark-beta.c:192-409):
+    local_search__MeshTools__  -> Solver.local_search()
+    get_active_nodes/dofs      -> Solver.active_masks()
+    __compute_nodal_lumped_mass-> Solver.compute_nodal_lumped_mass() ...
+The library is REQUIRED: a missing .so or a missing GPU raises, there is no CPU fallback here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAXNB = 128
+MAT_NEO_HOOKEAN, MAT_HENCKY, MAT_DRUCKER_PRAGER = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class Grid(C.Structure):
+    _fields_ = [("ndim", C.c_int), ("n", C.c_int * 3), ("origin", C.c_double * 3), ("h", C.c_double),
+                ("h_avg", _dp)]
+
+
+class Params(C.Structure):
+    _fields_ = [("gamma_lme", C.c_double), ("tol_zero_lme", C.c_double), ("tol_wrapper_lme", C.c_double),
+                ("max_iter_lme", C.c_int), ("tol_radial_returning", C.c_double),
+                ("max_iter_radial_returning", C.c_int)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int), ("E", C.c_double), ("nu", C.c_double), ("phi_deg", C.c_double),
+                ("psi_deg", C.c_double), ("kappa_0", C.c_double), ("exponent_ortiz", C.c_double),
+                ("eps_0", C.c_double), ("p_ref", C.c_double)]
+
+
+_PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e_n1", "J_n", "J_n1", "rho",
+       "mass", "Vol_0", "W", "Kappa_n", "Kappa_n1", "EPS_n", "EPS_n1"]
+
+
+class Particles(C.Structure):
+    _fields_ = ([("np", C.c_int)] + [(k, _dp) for k in _PD] +
+                [("MatIdx", _ip), ("I0", _ip), ("lambda_", _dp), ("Beta", _dp)])
+
+
+class Bcc(C.Structure):
+    _fields_ = [("nnodes", C.c_int), ("nodes", _ip), ("dim", C.c_int), ("dir", _ip), ("value", _dp)]
+
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
+
+_LIB = None
+
+# every symbol include/nlps_gpu.h declares
+SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_gpu_synchronize",
+           "nlps_gpu_download_state", "nlps_gpu_download_lists", "nlps_gpu_download_active",
+           "nlps_gpu_status_flags", "nlps_gpu_initialize_lme", "nlps_gpu_local_search", "nlps_gpu_active_masks",
+           "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
+           "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
+           "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
+           "nlps_gpu_touched_layers", "nlps_gpu_set_timing", "nlps_gpu_get_timing"]
+
+
+def lib():
+    """Loads the HIP library; raises if it is missing (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB
+        try:
+            # torch bundles its own libamdhip64.so.7; loading it FIRST makes this library bind to that
+            # same runtime (one HIP runtime per process), otherwise torch.cuda sees no device afterwards.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        if not os.path.exists(path):
+            raise RuntimeError("libnlps_gpu.so is not built: run __graft_entry__.build() "
+                               "(nl-partsol_amd has no CPU fallback)")
+        L = C.CDLL(path)
+        L.nlps_gpu_last_error.restype = C.c_char_p
+        L.nlps_gpu_last_error.argtypes = [C.c_void_p]
+        L.nlps_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Grid), C.POINTER(Params),
+                                      C.POINTER(Material), C.c_int, C.POINTER(Particles), C.c_int, C.c_void_p]
+        for name in ["nlps_gpu_destroy", "nlps_gpu_synchronize", "nlps_gpu_initialize_lme",
+                     "nlps_gpu_local_search", "nlps_gpu_constitutive", "nlps_gpu_roll_state"]:
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.nlps_gpu_download_state.argtypes = [C.c_void_p, C.POINTER(Particles)]
+        L.nlps_gpu_download_lists.argtypes = [C.c_void_p, _ip, _ip]
+        L.nlps_gpu_download_active.argtypes = [C.c_void_p, C.c_void_p]
+        L.nlps_gpu_status_flags.argtypes = [C.c_void_p, _ip]
+        L.nlps_gpu_active_masks.argtypes = [C.c_void_p, C.POINTER(Bcc), C.c_int, C.c_int, _ip, _ip, _ip, _ip]
+        L.nlps_gpu_lumped_mass.argtypes = [C.c_void_p, C.c_void_p]
+        L.nlps_gpu_nodal_field_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nlps_gpu_compatibility.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nlps_gpu_internal_forces.argtypes = [C.c_void_p, C.c_void_p]
+        L.nlps_gpu_update_kinetics.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        L.nlps_gpu_explicit_step.argtypes = [C.c_void_p, C.POINTER(Bcc), C.c_int, C.c_int, C.c_double,
+                                             C.c_double, _dp]
+        L.nlps_gpu_explicit_nodal.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.nlps_gpu_num_active.argtypes = [C.c_void_p, _ip]
+        L.nlps_gpu_set_halo_exchange.argtypes = [C.c_void_p, HALO_FN, C.c_void_p]
+        L.nlps_gpu_touched_layers.argtypes = [C.c_void_p, _ip, _ip]
+        L.nlps_gpu_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.nlps_gpu_get_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _LIB = L
+    return _LIB
+
+
+def default_params():
+    return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _vp(a):
+    """numpy array (host) or torch tensor / int (device pointer) -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+class BccSet:
+    """FEM_Mesh.Bounds: list of dicts {nodes, dim, dir[dim][nsteps], value[dim][nsteps]}."""
+
+    def __init__(self, bcs):
+        self.keep = []
+        self.n = len(bcs)
+        self.arr = (Bcc * max(1, self.n))()
+        for k, b in enumerate(bcs):
+            nodes = np.ascontiguousarray(b["nodes"], dtype=np.int32)
+            d = np.ascontiguousarray(b["dir"], dtype=np.int32)
+            v = np.ascontiguousarray(b["value"], dtype=np.float64)
+            self.keep += [nodes, d, v]
+            self.arr[k] = Bcc(len(nodes), _i(nodes), int(b["dim"]), _i(d), _d(v))
+
+
+class NlpsError(RuntimeError):
+    pass
+
+
+class Solver:
+    """Device-resident particle set + background grid; one method per reference stage function."""
+
+    def __init__(self, ndim, grid_n, origin, h, cloud, materials, params=None, nsteps=1, stream=None,
+                 h_avg=None):
+        self.L = lib()
+        self.ndim = int(ndim)
+        self.T = 5 if ndim == 2 else 9
+        self.np = int(cloud["x"].shape[0])
+        n3 = list(grid_n) + [1] * (3 - len(grid_n))
+        o3 = list(origin) + [0.0] * (3 - len(origin))
+        self.grid_n = n3
+        self.nnodes = n3[0] * n3[1] * n3[2]
+        self._h_avg = None if h_avg is None else np.ascontiguousarray(h_avg, dtype=np.float64)
+        g = Grid(self.ndim, (C.c_int * 3)(*n3), (C.c_double * 3)(*o3), float(h), _d(self._h_avg))
+        self.params = params or default_params()
+        mats = (Material * len(materials))()
+        for k, m in enumerate(materials):
+            mats[k] = Material(int(m["type"]), float(m["E"]), float(m["nu"]), float(m.get("phi_deg", 0.0)),
+                               float(m.get("psi_deg", 0.0)), float(m.get("kappa_0", 0.0)),
+                               float(m.get("exponent_ortiz", 1.0)), float(m.get("eps_0", 1.0)),
+                               float(m.get("p_ref", 0.0)))
+        self._host = {}
+        hp = Particles()
+        hp.np = self.np
+        keymap = {"x_GC": "x", "dis": "dis", "vel": "vel", "acc": "acc", "F_n": "F_n", "b_e_n": "b_e_n",
+                  "J_n": "J_n", "rho": "rho", "mass": "mass", "Vol_0": "vol0", "Kappa_n": "kappa_n",
+                  "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta"}
+        for ck, k in keymap.items():
+            if k in cloud and cloud[k] is not None:
+                a = np.ascontiguousarray(cloud[k], dtype=np.float64)
+                self._host[ck] = a
+                setattr(hp, ck, _d(a))
+        mi = np.ascontiguousarray(cloud["matidx"], dtype=np.int32)
+        self._host["MatIdx"] = mi
+        hp.MatIdx = _i(mi)
+        if cloud.get("I0") is not None:
+            i0 = np.ascontiguousarray(cloud["I0"], dtype=np.int32)
+            self._host["I0"] = i0
+            hp.I0 = _i(i0)
+        self.nsteps = int(nsteps)
+        self.h = C.c_void_p()
+        st = self.L.nlps_gpu_create(C.byref(self.h), C.byref(g), C.byref(self.params), mats, len(materials),
+                                    C.byref(hp), self.nsteps, C.c_void_p(stream) if stream else None)
+        if st:
+            raise NlpsError(self.L.nlps_gpu_last_error(self.h).decode())
+        self.nactive = 0
+        self.nfree = 0
+        self._halo_cb = None
+
+    # ------------------------------------------------------------------ helpers
+    def _chk(self, st):
+        if st:
+            raise NlpsError(self.L.nlps_gpu_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.nlps_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._chk(self.L.nlps_gpu_synchronize(self.h))
+
+    # ------------------------------------------------------------------ reference stages
+    def initialise_shapefun(self):          # initialise_shapefun__MeshTools__ -> initialize__LME__
+        self._chk(self.L.nlps_gpu_initialize_lme(self.h))
+
+    def local_search(self):                 # local_search__MeshTools__
+        self._chk(self.L.nlps_gpu_local_search(self.h))
+
+    def active_masks(self, bcs, step, download=True):   # get_active_nodes/_dofs__MeshTools__
+        na, nf = C.c_int(0), C.c_int(0)
+        n2m = np.zeros(self.nnodes, dtype=np.int32) if download else None
+        d2m = np.zeros(self.nnodes * self.ndim, dtype=np.int32) if download else None
+        self._chk(self.L.nlps_gpu_active_masks(self.h, bcs.arr, bcs.n, step, C.byref(na), C.byref(nf), _i(n2m),
+                                               _i(d2m)))
+        self.nactive, self.nfree = na.value, nf.value
+        if download:
+            return n2m, d2m[: self.nactive * self.ndim]
+        return None, None
+
+    def compute_nodal_lumped_mass(self, out=None):      # __compute_nodal_lumped_mass
+        M = np.zeros(self.nactive * self.ndim) if out is None else out
+        self._chk(self.L.nlps_gpu_lumped_mass(self.h, _vp(M)))
+        return M
+
+    def get_nodal_field_n(self, M, V=None, A=None):     # __get_nodal_field_n
+        V = np.zeros(self.nactive * self.ndim) if V is None else V
+        A = np.zeros(self.nactive * self.ndim) if A is None else A
+        self._chk(self.L.nlps_gpu_nodal_field_n(self.h, _vp(V), _vp(A), _vp(M)))
+        return V, A
+
+    def local_compatibility_conditions(self, dU, dU_dt=None):   # __local_compatibility_conditions
+        self._chk(self.L.nlps_gpu_compatibility(self.h, _vp(dU), _vp(dU_dt)))
+
+    def constitutive_update(self):                      # __constitutive_update
+        self._chk(self.L.nlps_gpu_constitutive(self.h))
+
+    def nodal_internal_forces(self, R):                 # __nodal_internal_forces (accumulates into R)
+        self._chk(self.L.nlps_gpu_internal_forces(self.h, _vp(R)))
+        return R
+
+    def update_particles_internal_variables(self):      # __update_particles_internal_variables
+        self._chk(self.L.nlps_gpu_roll_state(self.h))
+
+    def update_particles_kinetics_FLIP_PIC(self, alpha_blend, dU, Un_dt, dU_dt, dU_dt2):
+        self._chk(self.L.nlps_gpu_update_kinetics(self.h, float(alpha_blend), _vp(dU), _vp(Un_dt), _vp(dU_dt),
+                                                  _vp(dU_dt2)))
+
+    def explicit_step(self, bcs, step, dt, gamma=0.5, gravity=None):
+        g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float64)
+        self._chk(self.L.nlps_gpu_explicit_step(self.h, bcs.arr, bcs.n, int(step), float(dt), float(gamma), _d(g)))
+
+    def explicit_nodal(self):
+        """Nodal results of the last explicit step in masked numbering (host arrays)."""
+        na = C.c_int(0)
+        self._chk(self.L.nlps_gpu_num_active(self.h, C.byref(na)))
+        self.nactive = na.value
+        out = {k: np.zeros(self.nactive * self.ndim) for k in ("mass", "dU", "force", "accel", "reaction")}
+        self._chk(self.L.nlps_gpu_explicit_nodal(self.h, *[_vp(out[k]) for k in
+                                                           ("mass", "dU", "force", "accel", "reaction")]))
+        return out
+
+    # ------------------------------------------------------------------ downloads
+    def download_state(self):
+        n, d, T = self.np, self.ndim, self.T
+        o = {"x_GC": np.zeros((n, d)), "dis": np.zeros((n, d)), "vel": np.zeros((n, d)), "acc": np.zeros((n, d)),
+             "F_n": np.zeros((n, T)), "F_n1": np.zeros((n, T)), "DF": np.zeros((n, T)), "Stress": np.zeros((n, T)),
+             "b_e_n": np.zeros((n, T)), "b_e_n1": np.zeros((n, T)), "J_n": np.zeros(n), "J_n1": np.zeros(n),
+             "rho": np.zeros(n), "mass": np.zeros(n), "Vol_0": np.zeros(n), "W": np.zeros(n),
+             "Kappa_n": np.zeros(n), "Kappa_n1": np.zeros(n), "EPS_n": np.zeros(n), "EPS_n1": np.zeros(n),
+             "lambda_": np.zeros((n, d)), "Beta": np.zeros(n)}
+        i0 = np.zeros(n, dtype=np.int32)
+        hp = Particles()
+        hp.np = n
+        for k, a in o.items():
+            setattr(hp, k, _d(a))
+        hp.I0 = _i(i0)
+        self._chk(self.L.nlps_gpu_download_state(self.h, C.byref(hp)))
+        o["I0"] = i0
+        o["x"] = o["x_GC"]
+        o["lambda"] = o["lambda_"]
+        o["beta"] = o["Beta"]
+        return o
+
+    def download_lists(self):
+        nn = np.zeros(self.np, dtype=np.int32)
+        lst = np.zeros((self.np, MAXNB), dtype=np.int32)
+        self._chk(self.L.nlps_gpu_download_lists(self.h, _i(nn), _i(lst)))
+        return nn, lst
+
+    def download_active(self):
+        a = np.zeros(self.nnodes, dtype=np.uint8)
+        self._chk(self.L.nlps_gpu_download_active(self.h, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def status_flags(self):
+        f = C.c_int(0)
+        self._chk(self.L.nlps_gpu_status_flags(self.h, C.byref(f)))
+        return f.value
+
+    # ------------------------------------------------------------------ multi-GPU / measurement
+    def set_halo_exchange(self, pyfunc):
+        """pyfunc(dptr:int, nfield:int, elem_bytes:int, kind:int) -> int"""
+        if pyfunc is None:
+            self._halo_cb = None
+            self._chk(self.L.nlps_gpu_set_halo_exchange(self.h, C.cast(None, HALO_FN), None))
+            return
+
+        def _cb(ctx, dptr, nfield, elem, kind):
+            try:
+                return int(pyfunc(dptr, nfield, elem, kind) or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                print("halo exchange failed:", repr(e))
+                return 1
+
+        self._halo_cb = HALO_FN(_cb)
+        self._chk(self.L.nlps_gpu_set_halo_exchange(self.h, self._halo_cb, None))
+
+    def touched_layers(self):
+        lo, hi = C.c_int(0), C.c_int(0)
+        self._chk(self.L.nlps_gpu_touched_layers(self.h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def set_timing(self, on=True):
+        self._chk(self.L.nlps_gpu_set_timing(self.h, 1 if on else 0))
+
+    def get_timing(self):
+        ms = (C.c_float * 8)()
+        self._chk(self.L.nlps_gpu_get_timing(self.h, ms))
+        return list(ms)

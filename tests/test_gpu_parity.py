@@ -1,0 +1,247 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact for index maps (I0, neighbour lists, ActiveNode, Nodes2Mask, dof masks);
+FP64 fields to the tolerances of BASELINE.md §4: 1e-10 relative to the field's magnitude for particle
+fields, 1e-10 for nodal sums (atomics reorder them)."""
+import numpy as np
+import pytest
+
+from util import (DP, HENCKY, NH, assert_close, dirichlet_plane, gpu_setup, make_case, nlps, oracle_setup, orc)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def small_case(ndim, material=NH, velocity=None, **kw):
+    if ndim == 2:
+        return make_case(2, [14, 12], [3, 3], [7, 6], material=material, velocity=velocity, **kw)
+    return make_case(3, [11, 10, 9], [3, 3, 2], [5, 4, 4], material=material, velocity=velocity, **kw)
+
+
+def lists_equal(nn, a, b):
+    """rows compared up to NumberNodes[p] (the oracle keeps stale entries behind the end of a list)"""
+    col = np.arange(a.shape[1])[None, :]
+    valid = col < nn[:, None]
+    return bool(np.all(np.where(valid, a, 0) == np.where(valid, b[:, : a.shape[1]], 0)))
+
+
+def compare_search(S, P, M, what):
+    o = orc()
+    st = S.download_state()
+    assert np.array_equal(st["I0"], P["I0"]), f"{what}: I0 differs"
+    nn, lst = S.download_lists()
+    assert np.array_equal(nn, P["nn"]), f"{what}: NumberNodes differs"
+    assert lists_equal(nn, lst, P["list"]), f"{what}: ListNodes differ (order included)"
+    assert np.array_equal(S.download_active(), M.active()), f"{what}: ActiveNode differs"
+    assert np.array_equal(st["beta"], P["beta"]), f"{what}: beta differs"
+    assert_close(st["lambda"], P["lambda"], 1e-9, f"{what}: lambda")
+    return st
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_initialize_lme(ndim):
+    case = small_case(ndim)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case)
+    compare_search(S, P, M, "initialize__LME__")
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_initialize_lme_cell_centre_ties(ndim):
+    """1 particle per cell at the exact centre: every corner is equidistant, the chain order decides."""
+    case = small_case(ndim, jitter=0.0, ppc=1)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case)
+    compare_search(S, P, M, "ties")
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_grid_boundary_particles(ndim):
+    """Particles filling the whole grid: truncated stencils, boundary classes of the order tables."""
+    if ndim == 2:
+        case = make_case(2, [8, 7], [0, 0], [8, 7])
+    else:
+        case = make_case(3, [6, 5, 5], [0, 0, 0], [6, 5, 5])
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case)
+    compare_search(S, P, M, "boundary")
+
+
+def masks(S, M, bcs_list, step, nsteps):
+    o = orc()
+    n = nlps()
+    n2m_o, na = o.active_nodes(M)
+    ob = o.BccSet(bcs_list)
+    d2m_o, nfree = o.active_dofs(n2m_o, na, S.ndim, ob, step, nsteps)
+    gb = n.BccSet(bcs_list)
+    n2m_g, d2m_g = S.active_masks(gb, step)
+    assert S.nactive == na and S.nfree == nfree
+    assert np.array_equal(n2m_g, n2m_o), "Nodes2Mask differs"
+    assert np.array_equal(d2m_g, d2m_o), "dof mask differs"
+    return n2m_o, d2m_o, na
+
+
+@pytest.mark.parametrize("ndim,material", [(2, NH), (3, NH), (2, HENCKY), (3, HENCKY), (2, DP), (3, DP)])
+def test_stage_functions(ndim, material):
+    """One pass through the stage functions of U_Newmark_Beta in the order of U-Newmark-beta.c:192-409."""
+    o = orc()
+    vel = [1.0, -2.0] if ndim == 2 else [1.0, -2.0, 0.5]
+    case = small_case(ndim, material=material, velocity=vel)
+    rng = np.random.default_rng(7)
+    case["cloud"]["acc"][:] = rng.normal(size=case["cloud"]["acc"].shape)
+    nsteps = 3
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+
+    # move the particles a little so that the search does real work
+    dx = 0.37 * case["h"] * rng.uniform(-1, 1, size=P["x"].shape)
+    P["x"][:] += dx
+    P["dis"][:] += dx
+    S.close()
+    case2 = dict(case)
+    cloud2 = dict(case["cloud"])
+    cloud2.update(x=P["x"].copy(), dis=P["dis"].copy(), I0=P["I0"].copy(), **{"lambda": P["lambda"].copy()},
+                  beta=P["beta"].copy())
+    case2["cloud"] = cloud2
+    S = gpu_setup(case2, init=False, nsteps=nsteps)
+
+    assert o.local_search(P, M, prm) == 0
+    S.local_search()
+    compare_search(S, P, M, "local_search__LME__")
+    n2m, d2m, na = masks(S, M, bcs_list, 1, nsteps)
+
+    Mv_o = o.lumped_mass(P, M, n2m, na)
+    Mv_g = S.compute_nodal_lumped_mass()
+    assert_close(Mv_g, Mv_o, TOL, "lumped mass")
+    assert_close(Mv_g.reshape(-1, ndim)[:, 0].sum(), P["mass"].sum(), 1e-12, "mass conservation")
+
+    V_o, A_o = o.nodal_field_n(Mv_o, P, M, n2m, d2m, na)
+    V_g, A_g = S.get_nodal_field_n(Mv_g)
+    assert_close(V_g, V_o, TOL, "nodal velocity")
+    assert_close(A_g, A_o, TOL, "nodal acceleration")
+
+    dU = 1e-3 * rng.normal(size=na * ndim)
+    assert o.compatibility(dU, None, P, M, n2m) == 0
+    S.local_compatibility_conditions(dU)
+    assert o.constitutive(P, mats, prm) == 0
+    S.constitutive_update()
+    st = S.download_state()
+    for k, ok in (("DF", "DF"), ("F_n1", "F_n1"), ("J_n1", "J_n1"), ("Stress", "stress"), ("W", "W"),
+                  ("b_e_n1", "b_e_n1"), ("Kappa_n1", "kappa_n1"), ("EPS_n1", "eps_n1")):
+        if material["type"] != 2 and k in ("b_e_n1", "Kappa_n1", "EPS_n1"):
+            continue
+        assert_close(st[k], P[ok], TOL, f"{k} after compatibility+constitutive")
+
+    R_o, s = o.internal_forces(P, M, n2m, d2m, na)
+    assert s == 0
+    R_g = S.nodal_internal_forces(np.zeros(na * ndim))
+    assert_close(R_g, R_o, TOL, "internal forces")
+    free = d2m != -1
+    assert np.all(R_g[~free] == 0.0)
+
+    o.roll_state(P)
+    S.update_particles_internal_variables()
+    dV = 1e-2 * rng.normal(size=na * ndim)
+    dA = 1e-1 * rng.normal(size=na * ndim)
+    o.update_kinetics(1.0, dU, V_o, dV, dA, P, M, n2m)
+    S.update_particles_kinetics_FLIP_PIC(1.0, dU, V_g, dV, dA)
+    st = S.download_state()
+    for k, ok in (("x", "x"), ("dis", "dis"), ("vel", "vel"), ("acc", "acc"), ("F_n", "F_n"), ("J_n", "J_n"),
+                  ("rho", "rho")):
+        assert_close(st[k], P[ok], TOL, f"{k} after roll+kinetics")
+
+
+@pytest.mark.parametrize("ndim,material", [(2, NH), (3, NH), (2, HENCKY), (3, DP), (2, DP)])
+def test_explicit_steps(ndim, material):
+    """Several fused explicit predictor-corrector steps against the oracle's composition."""
+    o = orc()
+    n = nlps()
+    vel = [0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0]
+    if material["type"] == 2:
+        vel = [v * 0.02 for v in vel]
+    case = small_case(ndim, material=material, velocity=vel)
+    nsteps = 6
+    bcs_list = [dirichlet_plane(case, ndim - 1, 2, nsteps)]
+    grav = [0.0] * (ndim - 1) + [-9.81]
+    dt = 0.1 * case["h"] / np.sqrt(material["E"] / 1000.0)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps, gravity=grav)
+    gb = n.BccSet(bcs_list)
+    for t in range(nsteps):
+        assert stepper.step(t, dt) == 0
+        S.explicit_step(gb, t, dt, 0.5, grav)
+        nod = S.explicit_nodal()
+        assert S.nactive == stepper.out.nactive
+        for k in ("mass", "dU", "force", "accel", "reaction"):
+            assert_close(nod[k], stepper.nodal(k), 1e-9, f"step {t} nodal {k}")
+        st = S.download_state()
+        assert np.array_equal(st["I0"], P["I0"]), f"step {t}: I0"
+        nn, lst = S.download_lists()
+        assert np.array_equal(nn, P["nn"]) and lists_equal(nn, lst, P["list"]), f"step {t}: lists"
+        for k, ok in (("x", "x"), ("dis", "dis"), ("vel", "vel"), ("acc", "acc"), ("F_n", "F_n"), ("DF", "DF"),
+                      ("Stress", "stress"), ("J_n", "J_n"), ("rho", "rho"), ("W", "W"), ("lambda", "lambda"),
+                      ("b_e_n", "b_e_n"), ("Kappa_n", "kappa_n"), ("EPS_n", "eps_n")):
+            assert_close(st[k], P[ok], 1e-9, f"step {t} {k}")
+
+
+def test_device_pointer_nodal_vectors():
+    """Nodal Vec arrays may live on the device (torch tensors) as well as on the host."""
+    import torch
+    o = orc()
+    case = small_case(3, velocity=[1.0, 2.0, 3.0])
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case)
+    n2m, d2m, na = masks(S, M, [], 0, 1)
+    Mt = torch.zeros(na * 3, dtype=torch.float64, device="cuda")
+    S.compute_nodal_lumped_mass(out=Mt)
+    Mh = S.compute_nodal_lumped_mass()
+    torch.cuda.synchronize()
+    assert np.array_equal(Mt.cpu().numpy() > 0, Mh > 0)
+    assert_close(Mt.cpu().numpy(), Mh, 1e-12, "device vs host output")
+
+
+def test_failure_is_reported_not_fatal():
+    """< d+1 neighbours => EXIT_FAILURE + message (the reference exit()s, LME.c:1087-1092)."""
+    n = nlps()
+    case = small_case(2)
+    # cut-off radius ~ 0 from the second search on (beta = 0 at initialisation => Ra = +inf)
+    S = n.Solver(2, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"],
+                 params=n.Params(3.0, 1.0 - 1e-9, 1e-10, 10, 1e-14, 10))
+    S.initialise_shapefun()
+    with pytest.raises(n.NlpsError):
+        S.local_search()
+    assert S.status_flags() & 2
+
+
+@pytest.mark.parametrize("ndim", [3])
+def test_full_size_properties(ndim):
+    """BASELINE configs[1] size (1 M particles, 3-D): size-independent properties only."""
+    n = nlps()
+    case = make_case(3, [60, 60, 60], [5, 5, 5], [50, 50, 50], velocity=[0.0, 0.0, -10.0])
+    S = gpu_setup(case, nsteps=4)
+    assert S.np == 1_000_000
+    gb = n.BccSet([dirichlet_plane(case, 2, 0, 4)])
+    cloud = case["cloud"]
+    dt = 1e-3
+    mass0 = cloud["mass"].sum()
+    for t in range(2):
+        S.explicit_step(gb, t, dt, 0.5, None)
+        nod = S.explicit_nodal()
+        # mass conservation: sum_A M_A = sum_p m_p  (partition of unity of the LME basis)
+        assert abs(nod["mass"].reshape(-1, 3)[:, 0].sum() / mass0 - 1.0) < 1e-12
+        # momentum conservation of the dD projection: sum_A M_A dU_A = sum_p m_p dD_p
+        mom_nodes = (nod["mass"] * nod["dU"]).reshape(-1, 3).sum(0)
+        v = np.array([0.0, 0.0, -10.0]) if t == 0 else None
+        if v is not None:
+            assert_close(mom_nodes, mass0 * v * dt, 1e-10, "momentum of dD projection")
+        # Newton's third law: internal forces sum to zero
+        f = nod["force"].reshape(-1, 3).sum(0)
+        assert np.all(np.abs(f) <= 1e-9 * np.abs(nod["force"]).max() * np.sqrt(f.size) + 1e-9)
+    st = S.download_state()
+    assert np.all(st["J_n"] > 0)
+    assert np.allclose(st["Stress"][:, [1, 2, 5]], st["Stress"][:, [3, 6, 7]], rtol=0, atol=1e-6 * np.abs(st["Stress"]).max())
+    nn, _ = S.download_lists()
+    assert nn.min() >= 4 and nn.max() <= 125
+    assert S.status_flags() == 0
