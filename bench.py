@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cells", type=int, default=50, help="cells per axis of one rank's block (50 -> 1 M particles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=24, help="cells per axis of the CPU-baseline sample")
+    ap.add_argument("--cpu-cells", type=int, default=16, help="cells per axis of the CPU-baseline sample")
     ap.add_argument("--halo", choices=["p2p", "allreduce"], default="p2p")
     return ap.parse_args()
 
@@ -121,35 +121,45 @@ def _as_tensor(torch, dptr, n, dtype):
     return torch.as_tensor(h, device="cuda")
 
 
-def cpu_baseline(cells):
-    """Times the oracle's explicit step (a from-scratch CPU port, OpenMP, the reference's critical-section
-    structure) on a bounded 3-D sample of the same workload, on all host cores of this box."""
+def cpu_baseline(cells, budget_s=25.0):
+    """Times the oracle's explicit step (a from-scratch CPU port with OpenMP and the reference's
+    omp-critical nodal accumulation, U-Newmark-beta.c:582-586) on a bounded 3-D sample of the same
+    workload.  The critical sections make the port scale badly, so a few thread counts are tried inside
+    a time budget and the best is reported with the thread count that produced it."""
     os.environ.pop("OMP_NUM_THREADS", None)
     from oracle import orc
     synth = importlib.import_module("nl-partsol_amd.synth")
     margin = 5
     gc = [cells + 2 * margin] * 3
-    cloud = synth.make_cloud(3, gc, [margin] * 3, [cells] * 3, velocity=[0.0, 0.0, -10.0])
-    M = orc.OracleMesh(3, synth.grid_nodes(gc), [0.0] * 3, 1.0)
-    P = orc.OracleParticles(cloud)
+    gn = synth.grid_nodes(gc)
+    M = orc.OracleMesh(3, gn, [0.0] * 3, 1.0)
     prm = orc.default_params()
     mats = orc.make_materials([{"type": 0, "E": 1.0e7, "nu": 0.3}])
-    assert orc.initialize_lme(P, M, prm) == 0
     nsteps = 3
-    nodes = synth.plane_nodes(synth.grid_nodes(gc), 2, 0)
+    nodes = synth.plane_nodes(gn, 2, 0)
     bcs = orc.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nsteps), dtype=np.int32),
                        "value": np.zeros((3, nsteps))}])
-    st = orc.ExplicitStepper(P, M, mats, prm, bcs, nsteps)
-    assert st.step(0, 1e-3) == 0  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2:
-        assert st.step(n + 1, 1e-3) == 0
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": P.np * n / dt, "unit": "particle-steps/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "%d^3 cells x 8 = %d particles, 3-D LME Neo-Hookean explicit step, %d steps, oracle/nlps_oracle.c "
-                      "with OpenMP (omp critical nodal accumulation as in U-Newmark-beta.c)" % (cells, P.np, n)}
+    ncpu = os.cpu_count() or 1
+    best = None
+    t_begin = time.perf_counter()
+    for nthr in sorted({1, min(8, ncpu), min(32, ncpu)}):
+        if best is not None and time.perf_counter() - t_begin > budget_s:
+            break
+        orc.set_num_threads(nthr)
+        cloud = synth.make_cloud(3, gc, [margin] * 3, [cells] * 3, velocity=[0.0, 0.0, -10.0])
+        P = orc.OracleParticles(cloud)
+        assert orc.initialize_lme(P, M, prm) == 0
+        st = orc.ExplicitStepper(P, M, mats, prm, bcs, nsteps)
+        t0 = time.perf_counter()
+        assert st.step(0, 1e-3) == 0
+        dt = time.perf_counter() - t0
+        rate = P.np / dt
+        if best is None or rate > best[0]:
+            best = (rate, nthr, P.np)
+    return {"value": best[0], "unit": "particle-steps/s", "cores": best[1], "kind": "port",
+            "sample": "%d^3 cells x 8 = %d particles, 3-D LME Neo-Hookean, one explicit step per thread count "
+                      "(best of 1/8/32 threads inside %.0f s), oracle/nlps_oracle.c with OpenMP and the "
+                      "reference's omp-critical nodal accumulation" % (cells, best[2], budget_s)}
 
 
 def main():

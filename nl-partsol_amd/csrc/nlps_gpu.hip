@@ -47,6 +47,8 @@ struct PView {
   int* status;
   u64* mlo;
   u64* mhi;
+  int* tile;  // tile of I0 (per-step binning)
+  int* rank;  // arrival rank inside the tile
 };
 #define PF(P, f, p) ((P).d[(size_t)(f) * (P).npad + (size_t)(p)])
 
@@ -68,6 +70,23 @@ struct NView {
 #define ST_HALO 16
 
 static constexpr int BLK = 256;
+
+struct TileCnt {
+  int nt[3];
+  int* count;  // [ntiles] particles per tile, nullptr = no binning
+};
+template <int ND>
+struct TileCfg;
+template <int ND>
+__device__ __forceinline__ int tile_of_node(const GridD& g, const int* nt, int I0);
+
+template <int ND>
+__device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, const TileCnt& tc, int p, int I0) {
+  if (!tc.count) return;
+  int t = tile_of_node<ND>(g, tc.nt, I0);
+  P.tile[p] = t;
+  P.rank[p] = atomicAdd(&tc.count[t], 1);
+}
 
 __device__ __forceinline__ void atomic_add_f64(double* addr, double v) { unsafeAtomicAdd(addr, v); }
 
@@ -103,7 +122,7 @@ __device__ __forceinline__ void activate_ring(const GridD& g, unsigned char* act
 }
 
 template <int ND>
-__global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const uint8_t* __restrict__ rank1) {
+__global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const uint8_t* __restrict__ rank1, TileCnt tc) {
   int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
   double x[ND], aux = 0.0;
@@ -150,11 +169,12 @@ __global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const
     P.I0[p] = I0;
   }
   activate_ring<ND>(g, N.active, I0);
+  bin_particle<ND>(P, g, tc, p, I0);
 }
 
 // initialize__LME__ first loop (LME.c:63-115): element search + closest element node
 template <int ND>
-__global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N) {
+__global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N, TileCnt tc) {
   int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
   double x[ND];
@@ -205,6 +225,7 @@ __global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N) {
     }
   P.I0[p] = bestnode;
   activate_ring<ND>(g, N.active, bestnode);
+  bin_particle<ND>(P, g, tc, p, bestnode);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -837,6 +858,8 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
     if ((dirbits >> k) & 1) fixedm[(size_t)m * ndof + k] = 1;
 }
 
+#include "nlps_tile_kernels.hpp"
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -882,6 +905,12 @@ struct nlps_gpu {
   size_t maskedA_cap;
 
   std::vector<BcDev> bcs;
+
+  // per-step tile binning
+  int nt[3], ntiles;
+  int* tile_count_d;
+  int* tile_start_d;
+  int* order_d;
 
   nlps_halo_fn halo;
   void* halo_ctx;
@@ -1089,6 +1118,11 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   }
   g.h = grid->h;
   g.nnodes = g.n[0] * g.n[1] * g.n[2];
+  {
+    int TB = g.nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
+    for (int a = 0; a < 3; a++) h->nt[a] = a < g.nd ? (g.n[a] + TB - 1) / TB : 1;
+    h->ntiles = h->nt[0] * h->nt[1] * h->nt[2];
+  }
   h->hprm = *prm;
   h->prm.gamma_lme = prm->gamma_lme;
   h->prm.neg_log_tol_zero = -log(prm->tol_zero_lme);
@@ -1147,20 +1181,24 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     std::vector<long long> key(np);
     int slab_axis = ND - 1;
     int lo = 1 << 30, hi = -1;
+    const int TB = ND == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
     for (int p = 0; p < np; p++) {
-      long long k = 0, mul = 1;
+      // tile-major: (tile of the cell, then the cell inside the tile, x fastest)
+      long long kt = 0, kc = 0, mt = 1, mc = 1;
       for (int a = 0; a < ND; a++) {
         int nc = g.n[a] - 1;
         int c = (int)floor((host->x_GC[(size_t)p * ND + a] - g.o[a]) / g.h);
         c = c < 0 ? 0 : (c > nc - 1 ? nc - 1 : c);
-        k += mul * c;
-        mul *= nc;
+        kt += mt * (c / TB);
+        mt *= h->nt[a];
+        kc += mc * (c % TB);
+        mc *= TB;
         if (a == slab_axis) {
           lo = std::min(lo, c);
           hi = std::max(hi, c + 1);
         }
       }
-      key[p] = k;
+      key[p] = kt * mc + kc;
     }
     std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     h->slab_lo = std::max(0, lo - 3);
@@ -1174,6 +1212,11 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->P.status, h->P.npad)) return 1;
   if (dev_alloc(h, &h->P.mlo, h->P.npad)) return 1;
   if (dev_alloc(h, &h->P.mhi, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.tile, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.rank, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->order_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->tile_count_d, (size_t)h->ntiles + 1)) return 1;
+  if (dev_alloc(h, &h->tile_start_d, (size_t)h->ntiles + 1)) return 1;
   {
     std::vector<double> tmp(h->P.npad);
     int T = h->T;
@@ -1221,7 +1264,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d};
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -1347,18 +1390,49 @@ static int compute_node_mask(nlps_gpu* h) {
   return 0;
 }
 
+static TileCnt tile_cnt(nlps_gpu* h, bool on) {
+  TileCnt tc;
+  for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
+  tc.count = on ? h->tile_count_d : nullptr;
+  return tc;
+}
+static TileD tile_view(nlps_gpu* h) {
+  TileD td;
+  for (int a = 0; a < 3; a++) td.nt[a] = h->nt[a];
+  td.ntiles = h->ntiles;
+  td.start = h->tile_start_d;
+  td.count = h->tile_count_d;
+  td.order = h->order_d;
+  return td;
+}
+
+// S1: closest node + activation (+ binning of the particles to I0-tiles when `tiled`), then lists,
+// beta and the Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`, tiled form only)
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm) {
   int np = h->P.np;
+  bool tiled = p2g;
   HIPCHK(hipMemsetAsync(h->N.active, 0, (size_t)h->g.nnodes, h->stream));  // Shape-Functions.c:38-46
-  if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N);
-  else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d);
+  if (tiled) HIPCHK(hipMemsetAsync(h->tile_count_d, 0, ((size_t)h->ntiles + 1) * sizeof(int), h->stream));
+  TileCnt tc = tile_cnt(h, tiled);
+  if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
+  else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
   HIPCHK(hipGetLastError());
+  if (tiled) {
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d, h->tile_start_d, h->ntiles);
+    hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank,
+                       h->tile_start_d, h->order_d);
+    HIPCHK(hipGetLastError());
+  }
   if (halo(h, h->N.active, 1, 1, 1)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  if (p2g) LAUNCH_ND((k_lists_newton<2, true>), (k_lists_newton<3, true>), nblk(np), h->P, h->g, h->N, h->prm, dt,
-                     gamma_nm, h->gstatus_d);
-  else LAUNCH_ND((k_lists_newton<2, false>), (k_lists_newton<3, false>), nblk(np), h->P, h->g, h->N, h->prm, dt,
-                 gamma_nm, h->gstatus_d);
+  if (tiled) {
+    TileD td = tile_view(h);
+    if (h->nd == 2) hipLaunchKernelGGL(k2_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    else hipLaunchKernelGGL(k2_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+  } else {
+    LAUNCH_ND((k_lists_newton<2, false>), (k_lists_newton<3, false>), nblk(np), h->P, h->g, h->N, h->prm, dt,
+              gamma_nm, h->gstatus_d);
+  }
   HIPCHK(hipGetLastError());
   h->masks_valid = false;
   return 0;
@@ -1565,7 +1639,7 @@ extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const d
 
 extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, double dt, double gamma_nm,
                                       const double* gravity) {
-  int ND = h->nd, np = h->P.np, nn = h->g.nnodes;
+  int ND = h->nd, nn = h->g.nnodes;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   HIPCHK(hipMemsetAsync(h->N.nm, 0, (size_t)nn * (1 + ND) * sizeof(double), h->stream));
@@ -1593,8 +1667,11 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
   // S3 + S4
-  LAUNCH_ND((k_g2p_grad<2, 1>), (k_g2p_grad<3, 1>), nblk(np), h->P, h->g, h->N.dU, h->N.force, h->mats_d, h->prm,
-            h->gstatus_d);
+  {
+    TileD td = tile_view(h);
+    if (ND == 2) hipLaunchKernelGGL(k3_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
+    else hipLaunchKernelGGL(k3_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
+  }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.force, ND, 8, 0)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
@@ -1605,7 +1682,11 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N, gv[0], gv[1], gv[2]);
   if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
   // S5
-  LAUNCH_ND((k_g2p_update<2>), (k_g2p_update<3>), nblk(np), h->P, h->g, h->N.accel, h->N.dU, dt, gamma_nm);
+  {
+    TileD td = tile_view(h);
+    if (ND == 2) hipLaunchKernelGGL(k5_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm);
+    else hipLaunchKernelGGL(k5_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm);
+  }
   HIPCHK(hipGetLastError());
   if (h->timing) {
     HIPCHK(hipEventRecord(h->ev[6], h->stream));

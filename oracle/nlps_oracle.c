@@ -23,6 +23,14 @@
 /* DSQR, Macros.h:49-50: (a == 0 ? 0 : a*a) */
 static inline double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

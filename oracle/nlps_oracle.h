@@ -144,6 +144,7 @@ int orc_explicit_step(orc_particles *P, orc_mesh *M, const orc_material *mats, c
                       const double *gravity, orc_step_out *out);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -343,3 +343,7 @@ def rcond_ref(A):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
