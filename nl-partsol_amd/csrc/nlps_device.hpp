@@ -48,6 +48,14 @@ struct ParamsD {
 
 #define NLPS_TOL_NR 10E-6  // Macros.h:40
 
+// The 5 stencil planes are unrolled (static register names, no indirect addressing) but fenced: the
+// scheduler may not interleave two planes, which keeps the live ranges (hoisted LDS reads, partial
+// sums) of one plane only and the VGPR count far below the 256 cap.
+#define NLPS_PLANE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// compiler-level memory fence between stencil rows: LDS reads of later rows may not be hoisted above
+// it, so at most one row of window reads is in flight per lane (bounded live ranges, no spills)
+#define NLPS_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 __device__ __forceinline__ double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }  // Macros.h:49-50
 
 // ------------------------------------------------------------------------------------------------
@@ -504,6 +512,163 @@ __device__ __forceinline__ void lme_moments(const Lme<ND>& c, double& Zinv, doub
       Jm[a * ND + b2] = v;
       Jm[b2 * ND + a] = v;
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Hierarchical (row -> plane -> total) evaluation.  The weights are separable, only the membership
+// mask is not: the innermost loop over i touches three masked adds per member, everything that does
+// not depend on i is applied once per (j,k) row, everything that only depends on k once per plane.
+// ------------------------------------------------------------------------------------------------
+
+// 5 membership bits of row (j,k): bits [5(j+5k), 5(j+5k)+5) of the 125-bit mask
+template <int ND>
+__device__ __forceinline__ unsigned row_bits(const Lme<ND>& c, int j, int k) {
+  const int s = 5 * (j + 5 * k);
+  if (s + 5 <= 64) return (unsigned)(c.mlo >> s) & 31u;
+  if (s >= 64) return (unsigned)(c.mhi >> (s - 64)) & 31u;
+  return (unsigned)((c.mlo >> s) | (c.mhi << (64 - s))) & 31u;
+}
+
+// 25 membership bits of plane k (k may be a run-time, wave-uniform loop counter)
+template <int ND>
+__device__ __forceinline__ unsigned plane_bits(const Lme<ND>& c, int k) {
+  const int s = 25 * k;
+  u64 v;
+  if (s == 0) v = c.mlo;
+  else if (s < 64) v = (c.mlo >> s) | (c.mhi << (64 - s));
+  else v = c.mhi >> (s - 64);
+  return (unsigned)v & 0x1FFFFFFu;
+}
+
+// a[k] for a wave-uniform run-time k without indirect register addressing
+__device__ __forceinline__ double sel5(const double* a, int k) {
+  double v = a[0];
+  v = (k == 1) ? a[1] : v;
+  v = (k == 2) ? a[2] : v;
+  v = (k == 3) ? a[3] : v;
+  v = (k == 4) ? a[4] : v;
+  return v;
+}
+
+template <int ND>
+__device__ __forceinline__ double sel5z(const double* a, int k) {  // a has Lme<ND>::KN entries
+  if (ND == 3) return sel5(a, k);
+  return a[0];
+}
+
+// y/z factors and offsets as plain LOCAL arrays (not struct members: only those are promoted to
+// registers): the (j,k) row loops are real loops whose wave-uniform counters index them through
+// v_cndmask chains instead of scratch.
+#define NLPS_YZ_LOCALS(c)                                         \
+  double ey5[5], ly5[5], ez5[5], lz5[5];                          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 5; i_++) {              \
+    ey5[i_] = (c).ey[i_];                                         \
+    ly5[i_] = (c).ly[i_];                                         \
+    ez5[i_] = (ND == 3) ? (c).ez[i_ % Lme<ND>::KN] : 1.0;         \
+    lz5[i_] = (ND == 3) ? (c).lz[i_ % Lme<ND>::KN] : 0.0;         \
+  }
+
+template <int ND>
+struct LmeX {  // per-evaluation x-axis products: ex*lx, ex*lx^2
+  double x1[5], x2[5];
+  __device__ __forceinline__ void prep(const Lme<ND>& c) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      x1[i] = c.ex[i] * c.lx[i];
+      x2[i] = x1[i] * c.lx[i];
+    }
+  }
+};
+
+// Z^-1, r = sum p l, J = sum p l(x)l - r(x)r  (LME.c:766-832) by rows and planes
+template <int ND>
+__device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
+  LmeX<ND> X;
+  X.prep(c);
+  NLPS_YZ_LOCALS(c);
+  double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
+  // real (not unrolled) plane and row loops: compact code, short live ranges
+#pragma unroll 1
+  for (int k = 0; k < Lme<ND>::KN; k++) {
+    const unsigned pb = plane_bits<ND>(c, k);
+    double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < 5; j++) {
+      const unsigned bits = (pb >> (5 * j)) & 31u;
+      // branch-free: non-members enter with weight 0 (straight-line code, 2 v_cndmask per value)
+      double A0 = 0.0, A1 = 0.0, A2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        const bool on = (bits >> i) & 1u;
+        A0 += on ? c.ex[i] : 0.0;
+        A1 += on ? X.x1[i] : 0.0;
+        A2 += on ? X.x2[i] : 0.0;
+      }
+      const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
+      P00 = fma(y0, A0, P00);
+      P10 = fma(y0, A1, P10);
+      P20 = fma(y0, A2, P20);
+      P01 = fma(y1, A0, P01);
+      P11 = fma(y1, A1, P11);
+      P02 = fma(y2, A0, P02);
+    }
+    if (ND == 3) {
+      const double z0 = ez5[k], lzk = lz5[k], z1 = z0 * lzk, z2 = z1 * lzk;
+      Z = fma(z0, P00, Z);
+      rx = fma(z0, P10, rx);
+      ry = fma(z0, P01, ry);
+      rz = fma(z1, P00, rz);
+      Jxx = fma(z0, P20, Jxx);
+      Jxy = fma(z0, P11, Jxy);
+      Jxz = fma(z1, P10, Jxz);
+      Jyy = fma(z0, P02, Jyy);
+      Jyz = fma(z1, P01, Jyz);
+      Jzz = fma(z2, P00, Jzz);
+    } else {
+      Z = P00;
+      rx = P10;
+      ry = P01;
+      Jxx = P20;
+      Jxy = P11;
+      Jyy = P02;
+    }
+  }
+  Zinv = 1.0 / Z;
+  rx *= Zinv;
+  ry *= Zinv;
+  rz *= Zinv;
+  r[0] = rx;
+  r[1] = ry;
+  if (ND == 3) r[ND - 1] = rz;
+  if (ND == 2) {
+    Jm[0] = Jxx * Zinv - rx * rx;
+    Jm[1] = Jm[2] = Jxy * Zinv - rx * ry;
+    Jm[3] = Jyy * Zinv - ry * ry;
+  } else {
+    Jm[0] = Jxx * Zinv - rx * rx;
+    Jm[1] = Jm[3 % (ND * ND)] = Jxy * Zinv - rx * ry;
+    Jm[2] = Jm[6 % (ND * ND)] = Jxz * Zinv - rx * rz;
+    Jm[4 % (ND * ND)] = Jyy * Zinv - ry * ry;
+    Jm[5 % (ND * ND)] = Jm[7 % (ND * ND)] = Jyz * Zinv - ry * rz;
+    Jm[8 % (ND * ND)] = Jzz * Zinv - rz * rz;
+  }
+}
+
+// Largest t with fl(sqrt(t)) <= Ra: the reference's test `sqrt(|l|^2) <= Ra` (LME.c:1076,
+// MatrixOp.c:895-920) is then exactly `|l|^2 <= t`, without 125 square roots per particle.
+__device__ __forceinline__ double sqrt_threshold(double Ra) {
+  double t = Ra * Ra;
+  if (isinf(Ra) || isnan(t)) return Ra;
+#pragma unroll 1
+  for (int it = 0; it < 8 && sqrt(t) > Ra; it++) t = __longlong_as_double(__double_as_longlong(t) - 1);
+#pragma unroll 1
+  for (int it = 0; it < 8; it++) {
+    double tn = __longlong_as_double(__double_as_longlong(t) + 1);
+    if (sqrt(tn) <= Ra) t = tn;
+    else break;
+  }
+  return t;
 }
 
 }  // namespace nlps

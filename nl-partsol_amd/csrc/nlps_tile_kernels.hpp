@@ -96,26 +96,58 @@ __global__ void k_fill_order(int np, const int* __restrict__ tile, const int* __
   order[start[tile[p]] + rank[p]] = p;
 }
 
+// membership bits of row (j,k) into the 125-bit mask
+__device__ __forceinline__ void put_row(u64& mlo, u64& mhi, unsigned bits, int s) {
+  if (s + 5 <= 64) mlo |= (u64)bits << s;
+  else if (s >= 64) mhi |= (u64)bits << (s - 64);
+  else {
+    mlo |= (u64)bits << s;
+    mhi |= (u64)bits >> (64 - s);
+  }
+}
+
+// 25 membership bits of plane k (run-time k) into the 125-bit mask
+__device__ __forceinline__ void put_plane(u64& mlo, u64& mhi, unsigned bits, int k) {
+  const int s = 25 * k;
+  if (s < 64) {
+    mlo |= (u64)bits << s;
+    if (s + 25 > 64) mhi |= (u64)bits >> (64 - s);
+  } else {
+    mhi |= (u64)bits << (s - 64);
+  }
+}
+
+template <int ND>
+struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
+  static constexpr int W = TileCfg<ND>::W;
+  static constexpr int NROWS = (ND == 3) ? W * W : W;
+};
+
 // ------------------------------------------------------------------------------------------------
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
 template <int ND>
 __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
-  constexpr int NW = TileCfg<ND>::NW, NF = 1 + ND;
+  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
+  constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NW];
-  __shared__ unsigned char act[NW];
+  __shared__ unsigned actrow[NROWS];
   const int tile = blockIdx.x;
   const int cnt = td.count[tile];
   if (cnt == 0) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
+  for (int r = threadIdx.x; r < NROWS; r += BLK) actrow[r] = 0u;
+  for (int idx = threadIdx.x; idx < NW; idx += BLK) {
+#pragma unroll
+    for (int f = 0; f < NF; f++) acc[f * NW + idx] = 0.0;
+  }
+  __syncthreads();
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
     bool in;
     int node = window_node<ND>(g, w0, idx, in);
-    act[idx] = in ? N.active[node] : 0;
-#pragma unroll
-    for (int f = 0; f < NF; f++) acc[f * NW + idx] = 0.0;
+    if (in && N.active[node]) atomicOr(&actrow[idx / W], 1u << (idx % W));
   }
   __syncthreads();
   const int start = td.start[tile];
@@ -130,31 +162,44 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
     }
     const int I0 = P.I0[p];
     c.geom(g, x, I0);
-    const int base = window_base<ND>(c.ijk, w0);
-    double beta_prev = PF(P, F_BETA, p);
-    double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);
+    const int bx = c.ijk[0] - w0[0], by = c.ijk[1] - w0[1], bz = (ND == 3) ? c.ijk[2] - w0[2] : 0;
+    const int base = bx + W * (by + (ND == 3 ? W * bz : 0));
+    const double beta_prev = PF(P, F_BETA, p);
+    const double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052
+    const double T2 = sqrt_threshold(Ra);                       // sqrt(|l|^2) <= Ra  <=>  |l|^2 <= T2
+    double lx2[5], ly2[5], lz2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      lx2[i] = c.lx[i] * c.lx[i];
+      ly2[i] = c.ly[i] * c.ly[i];
+      if (ND == 3) lz2[i] = c.lz[i % KN] * c.lz[i % KN];
+    }
     u64 mlo = 0ull, mhi = 0ull;
-#pragma unroll
-    for (int k = 0; k < Lme<ND>::KN; k++)
-#pragma unroll
-      for (int j = 0; j < 5; j++)
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const double lz2k = (ND == 3) ? lz2[k] : 0.0;
+      unsigned pbits = 0u;
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const int row = (by + j - 2) + (ND == 3 ? W * (bz + k - 2) : 0);
+        const unsigned actbits = (actrow[row] >> (bx - 2)) & 31u;
+        unsigned rb = 0u;
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-          double sq = 0.0;
-          sq += c.lx[i] * c.lx[i];
-          sq += c.ly[j] * c.ly[j];
-          if (ND == 3) sq += c.lz[k % Lme<ND>::KN] * c.lz[k % Lme<ND>::KN];
-          bool ok = act[wl<ND>(base, i, j, k)] && (sqrt(sq) <= Ra);
-          int b = i + 5 * j + 25 * k;
-          if (ok) {
-            if (b < 64) mlo |= (1ull << b);
-            else mhi |= (1ull << (b - 64));
-          }
+          double sq = 0.0;  // same left-to-right sum as generalised_Euclidean_distance (MatrixOp.c:895-920)
+          sq += lx2[i];
+          sq += ly2[j];
+          if (ND == 3) sq += lz2k;
+          rb |= (sq <= T2) ? (1u << i) : 0u;
         }
+        pbits |= (rb & actbits) << (5 * j);
+      }
+      put_plane(mlo, mhi, pbits, k);
+    }
     c.mlo = mlo;
     c.mhi = mhi;
-    int nn = __popcll(mlo) + __popcll(mhi);
-    if (nn < ND + 1) {
+    const int nn = __popcll(mlo) + __popcll(mhi);
+    if (nn < ND + 1) {  // LME.c:1087-1092
       P.nn[p] = 0;
       P.mlo[p] = 0ull;
       P.mhi[p] = 0ull;
@@ -162,14 +207,14 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
       atomicOr(gstatus, ST_CONNECT);
       continue;
     }
-    double hv = N.h_avg[I0];
-    double beta = prm.gamma_lme / (hv * hv);
+    const double hv = N.h_avg[I0];
+    const double beta = prm.gamma_lme / (hv * hv);
     int st = 0, NumIter = 0;
     double Zinv = 0.0;
-    while (NumIter <= prm.max_iter_lme) {
+    while (NumIter <= prm.max_iter_lme) {  // __lambda_Newton_Rapson, LME.c:272-353
       double r[ND], J[ND * ND], Jm1[ND * ND];
       c.factors(lam, beta);
-      lme_moments<ND>(c, Zinv, r, J);
+      lme_moments_h<ND>(c, Zinv, r, J);
       double aux = 0.0;
 #pragma unroll
       for (int a = 0; a < ND; a++) aux += dsqr(r[a]);
@@ -182,7 +227,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
         for (int a = 0; a < ND; a++) {
           double dl = 0.0;
 #pragma unroll
-          for (int b2 = 0; b2 < ND; b2++) dl += Jm1[a * ND + b2] * r[b2];
+          for (int b2 = 0; b2 < ND; b2++) dl = fma(Jm1[a * ND + b2], r[b2], dl);
           lam[a] -= dl;
         }
         NumIter++;
@@ -209,14 +254,28 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
       PF(P, F_DDIS + a, p) = dd[a];
       PF(P, F_VEL + a, p) = v + (1 - gamma_nm) * dt * ac;
     }
-    double mz = PF(P, F_MASS, p) * Zinv;
-    for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-      int li = wl<ND>(base, i, j, k);
-      double w = mz * e;
-      atomicAdd(&acc[li], w);
+    const double mz = PF(P, F_MASS, p) * Zinv;
+    NLPS_YZ_LOCALS(c);
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const unsigned pb = plane_bits<ND>(c, k);
+      const double wz = mz * ez5[k];
+      const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const unsigned bits = (pb >> (5 * j)) & 31u;
+        const double w = wz * ey5[j];
 #pragma unroll
-      for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NW + li], w * dd[a]);
-    });
+        for (int i = 0; i < 5; i++)
+          if ((bits >> i) & 1u) {
+            const int li = basek + (i - 2) + W * (j - 2);
+            const double v0 = w * c.ex[i];
+            atomicAdd(&acc[li], v0);
+#pragma unroll
+            for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NW + li], v0 * dd[a]);
+          }
+      }
+    }
   }
   __syncthreads();
   for (int q = threadIdx.x; q < NW * NF; q += BLK) {
@@ -236,7 +295,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
 template <int ND>
 __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus) {
-  constexpr int NW = TileCfg<ND>::NW;
+  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double du[ND * NW];
   __shared__ double fac[ND * NW];
   const int tile = blockIdx.x;
@@ -261,44 +320,109 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     const int base = window_base<ND>(c.ijk, w0);
-    double Z = 0.0, sm[ND], q[ND * ND], G[ND * ND];
+    LmeX<ND> X;
+    X.prep(c);
+    NLPS_YZ_LOCALS(c);
+    // pass 1: moments (rows -> planes) and G[a][m] = sum e dU_a l_m (rows)
+    double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
+    double G[ND * ND];
 #pragma unroll
-    for (int a = 0; a < ND; a++) sm[a] = 0.0;
+    for (int a = 0; a < ND * ND; a++) G[a] = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const unsigned pb = plane_bits<ND>(c, k);
+      const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+      double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;
+      double Gx[ND], Gy[ND], Gz[ND];  // plane partial sums of G[.][x], G[.][y], G[.][z]/lz
 #pragma unroll
-    for (int a = 0; a < ND * ND; a++) {
-      q[a] = 0.0;
-      G[a] = 0.0;
+      for (int a = 0; a < ND; a++) Gx[a] = Gy[a] = Gz[a] = 0.0;
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const unsigned bits = (pb >> (5 * j)) & 31u;
+        double A0 = 0.0, A1 = 0.0, A2 = 0.0, R0[ND], R1[ND];
+#pragma unroll
+        for (int a = 0; a < ND; a++) R0[a] = R1[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
+          const bool on = (bits >> i) & 1u;
+          const int li = basek + (i - 2) + W * (j - 2);
+          const double m0 = on ? c.ex[i] : 0.0, m1 = on ? X.x1[i] : 0.0;
+          A0 += m0;
+          A1 += m1;
+          A2 += on ? X.x2[i] : 0.0;
+#pragma unroll
+          for (int a = 0; a < ND; a++) {
+            const double u = du[a * NW + li];
+            R0[a] = fma(m0, u, R0[a]);
+            R1[a] = fma(m1, u, R1[a]);
+          }
+        }
+        const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
+        P00 = fma(y0, A0, P00);
+        P10 = fma(y0, A1, P10);
+        P20 = fma(y0, A2, P20);
+        P01 = fma(y1, A0, P01);
+        P11 = fma(y1, A1, P11);
+        P02 = fma(y2, A0, P02);
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          Gx[a] = fma(y0, R1[a], Gx[a]);
+          Gy[a] = fma(y1, R0[a], Gy[a]);
+          Gz[a] = fma(y0, R0[a], Gz[a]);
+        }
+      }
+      if (ND == 3) {
+        const double z0 = ez5[k], lzk = lz5[k], z1 = z0 * lzk, z2 = z1 * lzk;
+        Z = fma(z0, P00, Z);
+        rx = fma(z0, P10, rx);
+        ry = fma(z0, P01, ry);
+        rz = fma(z1, P00, rz);
+        Jxx = fma(z0, P20, Jxx);
+        Jxy = fma(z0, P11, Jxy);
+        Jxz = fma(z1, P10, Jxz);
+        Jyy = fma(z0, P02, Jyy);
+        Jyz = fma(z1, P01, Jyz);
+        Jzz = fma(z2, P00, Jzz);
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          G[a * ND + 0] = fma(z0, Gx[a], G[a * ND + 0]);
+          G[a * ND + 1] = fma(z0, Gy[a], G[a * ND + 1]);
+          G[a * ND + (2 % ND)] = fma(z1, Gz[a], G[a * ND + (2 % ND)]);
+        }
+      } else {
+        Z = P00;
+        rx = P10;
+        ry = P01;
+        Jxx = P20;
+        Jxy = P11;
+        Jyy = P02;
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          G[a * ND + 0] = Gx[a];
+          G[a * ND + 1] = Gy[a];
+        }
+      }
     }
-    for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-      int li = wl<ND>(base, i, j, k);
-      double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
-      double u[ND];
-#pragma unroll
-      for (int a = 0; a < ND; a++) u[a] = du[a * NW + li];
-      Z += e;
-#pragma unroll
-      for (int a = 0; a < ND; a++) {
-        double el = e * l[a];
-        sm[a] += el;
-#pragma unroll
-        for (int b2 = a; b2 < ND; b2++) q[a * ND + b2] += el * l[b2];
-#pragma unroll
-        for (int b2 = 0; b2 < ND; b2++) G[b2 * ND + a] += el * u[b2];
-      }
-    });
-    double Zinv = 1.0 / Z, r[ND], J[ND * ND], Jm1[ND * ND];
-#pragma unroll
-    for (int a = 0; a < ND; a++) r[a] = sm[a] * Zinv;
-#pragma unroll
-    for (int a = 0; a < ND; a++)
-#pragma unroll
-      for (int b2 = a; b2 < ND; b2++) {
-        double v = q[a * ND + b2] * Zinv - r[a] * r[b2];
-        J[a * ND + b2] = v;
-        J[b2 * ND + a] = v;
-      }
+    const double Zinv = 1.0 / Z;
+    rx *= Zinv;
+    ry *= Zinv;
+    rz *= Zinv;
+    double J[ND * ND], Jm1[ND * ND];
+    if (ND == 2) {
+      J[0] = Jxx * Zinv - rx * rx;
+      J[1] = J[2] = Jxy * Zinv - rx * ry;
+      J[3] = Jyy * Zinv - ry * ry;
+    } else {
+      J[0] = Jxx * Zinv - rx * rx;
+      J[1] = J[3 % (ND * ND)] = Jxy * Zinv - rx * ry;
+      J[2] = J[6 % (ND * ND)] = Jxz * Zinv - rx * rz;
+      J[4 % (ND * ND)] = Jyy * Zinv - ry * ry;
+      J[5 % (ND * ND)] = J[7 % (ND * ND)] = Jyz * Zinv - ry * rz;
+      J[8 % (ND * ND)] = Jzz * Zinv - rz * rz;
+    }
     int st = 0;
     if (!inverse<ND>(Jm1, J)) st |= ST_NEWTON;
+    // DF = I + sum_A dU_A (x) grad N_A = I - (G/Z) J^-T            (compute-Strains.c:20-44)
     double DF[ND * ND], Fn[ND * ND], Fn1[ND * ND], fzz;
 #pragma unroll
     for (int i = 0; i < ND; i++)
@@ -306,7 +430,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
       for (int j = 0; j < ND; j++) {
         double v = 0.0;
 #pragma unroll
-        for (int m = 0; m < ND; m++) v += (G[i * ND + m] * Zinv) * Jm1[j * ND + m];
+        for (int m = 0; m < ND; m++) v = fma(G[i * ND + m] * Zinv, Jm1[j * ND + m], v);
         DF[i * ND + j] = ((i == j) ? 1.0 : 0.0) - v;
       }
     load_block<ND>(P, F_FN, p, Fn, fzz);
@@ -319,27 +443,45 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
         for (int k2 = 0; k2 < ND; k2++) a2 += DF[i * ND + k2] * Fn[k2 * ND + j];
         Fn1[i * ND + j] = a2;
       }
-    double Jn1 = det<ND>(Fn1);
-    if (Jn1 <= 0.0) st |= ST_JACOBIAN;
+    const double Jn1 = det<ND>(Fn1);
+    if (Jn1 <= 0.0) st |= ST_JACOBIAN;  // fatal in the explicit scheme, U-Verlet.c:608-613
     store_block<ND>(P, F_DF, p, DF, 0.0, false);
     store_block<ND>(P, F_FN1, p, Fn1, 0.0, false);
     PF(P, F_JN1, p) = Jn1;
-    PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);
+    PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
     double tau[ND * ND], B[ND * ND];
     st |= stress_update<ND>(P, p, mats, prm, Fn1, DF, Jn1, tau);
     if (force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0)) {
-      for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-        int li = wl<ND>(base, i, j, k);
-        double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
-        double pa = e * Zinv;
+      // pass 2: -f_A = p_A * (B l_A), B l = B[.][x] lx_i + (B[.][y] ly_j + B[.][z] lz_k)
+      double bx[ND][5];
 #pragma unroll
-        for (int a = 0; a < ND; a++) {
-          double sv = 0.0;
+      for (int a = 0; a < ND; a++)
 #pragma unroll
-          for (int m = 0; m < ND; m++) sv += B[a * ND + m] * l[m];
-          atomicAdd(&fac[a * NW + li], pa * sv);
+        for (int i = 0; i < 5; i++) bx[a][i] = B[a * ND + 0] * c.lx[i];
+#pragma unroll 1
+      for (int k = 0; k < KN; k++) {
+        const unsigned pb = plane_bits<ND>(c, k);
+        const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+        const double wz = Zinv * ez5[k];
+        const double lzk = lz5[k];
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) {
+          const unsigned bits = (pb >> (5 * j)) & 31u;
+          const double w = wz * ey5[j];
+          double cr[ND];
+#pragma unroll
+          for (int a = 0; a < ND; a++)
+            cr[a] = (ND == 3) ? fma(B[a * ND + 1], ly5[j], B[a * ND + (2 % ND)] * lzk) : B[a * ND + 1] * ly5[j];
+#pragma unroll
+          for (int i = 0; i < 5; i++)
+            if ((bits >> i) & 1u) {
+              const int li = basek + (i - 2) + W * (j - 2);
+              const double we = w * c.ex[i];
+#pragma unroll
+              for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * (bx[a][i] + cr[a]));
+            }
         }
-      });
+      }
     } else {
       st |= ST_JACOBIAN;
     }
@@ -365,7 +507,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
 // ------------------------------------------------------------------------------------------------
 template <int ND>
 __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
-  constexpr int NW = TileCfg<ND>::NW;
+  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double du[ND * NW];
   __shared__ double ac[ND * NW];
   const int tile = blockIdx.x;
@@ -390,22 +532,42 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     const int base = window_base<ND>(c.ijk, w0);
+    NLPS_YZ_LOCALS(c);
     double Z = 0.0, sa[ND], su[ND];
 #pragma unroll
-    for (int a = 0; a < ND; a++) {
-      sa[a] = 0.0;
-      su[a] = 0.0;
-    }
-    for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-      int li = wl<ND>(base, i, j, k);
-      Z += e;
+    for (int a = 0; a < ND; a++) sa[a] = su[a] = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const unsigned pb = plane_bits<ND>(c, k);
+      const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+      const double z0 = ez5[k];
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const unsigned bits = (pb >> (5 * j)) & 31u;
+        double A0 = 0.0, Ra_[ND], Ru_[ND];
 #pragma unroll
-      for (int a = 0; a < ND; a++) {
-        sa[a] += e * ac[a * NW + li];
-        su[a] += e * du[a * NW + li];
+        for (int a = 0; a < ND; a++) Ra_[a] = Ru_[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
+          const int li = basek + (i - 2) + W * (j - 2);
+          const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+          A0 += m0;
+#pragma unroll
+          for (int a = 0; a < ND; a++) {
+            Ra_[a] = fma(m0, ac[a * NW + li], Ra_[a]);
+            Ru_[a] = fma(m0, du[a * NW + li], Ru_[a]);
+          }
+        }
+        const double w = ey5[j] * z0;
+        Z = fma(w, A0, Z);
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          sa[a] = fma(w, Ra_[a], sa[a]);
+          su[a] = fma(w, Ru_[a], su[a]);
+        }
       }
-    });
-    double Zinv = 1.0 / Z;
+    }
+    const double Zinv = 1.0 / Z;
 #pragma unroll
     for (int a = 0; a < ND; a++) {
       double av = sa[a] * Zinv, dd = su[a] * Zinv;
