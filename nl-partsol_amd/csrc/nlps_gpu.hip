@@ -80,15 +80,36 @@ struct TileCfg;
 template <int ND>
 __device__ __forceinline__ int tile_of_node(const GridD& g, const int* nt, int I0);
 
-template <int ND>
-__device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, const TileCnt& tc, int p, int I0) {
-  if (!tc.count) return;
-  int t = tile_of_node<ND>(g, tc.nt, I0);
-  P.tile[p] = t;
-  P.rank[p] = atomicAdd(&tc.count[t], 1);
-}
-
 __device__ __forceinline__ void atomic_add_f64(double* addr, double v) { unsafeAtomicAdd(addr, v); }
+
+// Bins a particle to the tile of its I0.  Wave-aggregated: one returning atomic per (wave, tile); the
+// lanes of a wave that share a tile get CONSECUTIVE slots in lane order, so order[] keeps runs of 64
+// memory-consecutive particles together (coalesced loads in the tile kernels).  Every lane of the wave
+// must call this (invalid lanes pass valid = false).
+template <int ND>
+__device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, const TileCnt& tc, int p, int I0,
+                                             bool valid) {
+  if (!tc.count) return;
+  const int t = valid ? tile_of_node<ND>(g, tc.nt, I0) : -1;
+  const int lane = threadIdx.x & 63;
+  int rank = valid ? -1 : 0;
+  while (true) {
+    const u64 todo = __ballot(rank < 0);
+    if (!todo) break;
+    const int leader = __ffsll((unsigned long long)todo) - 1;
+    const int t0 = __shfl(t, leader);
+    const bool mine = (rank < 0) && (t == t0);
+    const u64 same = __ballot(mine);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&tc.count[t0], (int)__popcll(same));
+    base = __shfl(base, leader);
+    if (mine) rank = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+  }
+  if (valid) {
+    P.tile[p] = t;
+    P.rank[p] = rank;
+  }
+}
 
 template <int ND>
 __device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
@@ -123,109 +144,129 @@ __device__ __forceinline__ void activate_ring(const GridD& g, unsigned char* act
 
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const uint8_t* __restrict__ rank1, TileCnt tc) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  double x[ND], aux = 0.0;
+  const int p = blockIdx.x * BLK + threadIdx.x;
+  const bool valid = p < P.np;
+  int I0 = 0;
+  if (valid) {
+    double x[ND], aux = 0.0;
 #pragma unroll
-  for (int a = 0; a < ND; a++) {
-    x[a] = PF(P, F_X + a, p);
-    aux += dsqr(PF(P, F_DIS + a, p));
-  }
-  int I0 = P.I0[p];
-  if (sqrt(aux) > 0.0) {  // norm__MatrixLib__(dis_p,2) > 0, LME.c:924
-    int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
-    const uint8_t* rk = rank1 + 27 * class3_of<ND>(g, ijk);
-    double best = 0.0;
-    int bestrank = 256, bestnode = I0;
+    for (int a = 0; a < ND; a++) {
+      x[a] = PF(P, F_X + a, p);
+      aux += dsqr(PF(P, F_DIS + a, p));
+    }
+    I0 = P.I0[p];
+    if (sqrt(aux) > 0.0) {  // norm__MatrixLib__(dis_p,2) > 0, LME.c:924
+      int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+      const uint8_t* rk = rank1 + 27 * class3_of<ND>(g, ijk);
+      // squared distances of the 3^d candidates, summed like point_distance__MeshTools__
+      // (Nodes-Tools.c:397-420: DIST += pow(d,2) in axis order)
+      double D[27];
+      double Dmin = 1.0e300;
 #pragma unroll
-    for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
+      for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
 #pragma unroll
-      for (int dj = -1; dj <= 1; dj++)
+        for (int dj = -1; dj <= 1; dj++)
 #pragma unroll
-        for (int di = -1; di <= 1; di++) {
-          int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
-          if (i < 0 || i >= g.n[0] || j < 0 || j >= g.n[1]) continue;
-          if (ND == 3 && (k < 0 || k >= g.n[2])) continue;
-          int rank = rk[(di + 1) + 3 * (dj + 1) + 9 * (dk + 1)];
-          // point_distance__MeshTools__: sqrt(sum pow(x - x_I, 2)), Nodes-Tools.c:397-420
-          double D = 0.0, t;
-          t = x[0] - (g.o[0] + g.h * (double)i);
-          D += t * t;
-          t = x[1] - (g.o[1] + g.h * (double)j);
-          D += t * t;
-          if (ND == 3) {
-            t = x[ND - 1] - (g.o[2] + g.h * (double)k);
-            D += t * t;
+          for (int di = -1; di <= 1; di++) {
+            const int c = (di + 1) + 3 * (dj + 1) + 9 * (dk + 1);
+            const int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
+            const bool ok = i >= 0 && i < g.n[0] && j >= 0 && j < g.n[1] && (ND == 2 || (k >= 0 && k < g.n[2]));
+            double Dc = 0.0, t;
+            t = x[0] - (g.o[0] + g.h * (double)i);
+            Dc += t * t;
+            t = x[1] - (g.o[1] + g.h * (double)j);
+            Dc += t * t;
+            if (ND == 3) {
+              t = x[ND - 1] - (g.o[2] + g.h * (double)k);
+              Dc += t * t;
+            }
+            D[c] = ok ? Dc : 1.0e300;
+            Dmin = (ok && Dc < Dmin) ? Dc : Dmin;
           }
-          D = sqrt(D);
-          // strict '<' walking the chain == lexicographic minimum of (distance, chain position)
-          if (bestrank == 256 || D < best || (D == best && rank < bestrank)) {
-            best = D;
+      // the reference compares sqrt(D) with strict '<' walking the chain (Nodes-Tools.c:476-538) ==
+      // lexicographic minimum of (sqrt(D), chain position).  sqrt is monotone, so only candidates within
+      // rounding reach of the minimum can tie after the square root: resolve just those exactly.
+      const double thr = Dmin * (1.0 + 1.0e-14);
+      double best = 0.0;
+      int bestrank = 256, bestc = 13;
+#pragma unroll
+      for (int c = (ND == 3 ? 0 : 9); c < (ND == 3 ? 27 : 18); c++) {
+        if (D[c] <= thr) {
+          const double d = sqrt(D[c]);
+          const int rank = rk[c];
+          if (bestrank == 256 || d < best || (d == best && rank < bestrank)) {
+            best = d;
             bestrank = rank;
-            bestnode = i + g.n[0] * (j + g.n[1] * k);
+            bestc = c;
           }
         }
-    I0 = bestnode;
-    P.I0[p] = I0;
+      }
+      I0 = (ijk[0] + bestc % 3 - 1) + g.n[0] * ((ijk[1] + (bestc / 3) % 3 - 1) + g.n[1] * (ijk[2] + bestc / 9 - 1));
+      P.I0[p] = I0;
+    }
+    activate_ring<ND>(g, N.active, I0);
   }
-  activate_ring<ND>(g, N.active, I0);
-  bin_particle<ND>(P, g, tc, p, I0);
+  bin_particle<ND>(P, g, tc, p, I0, valid);
 }
 
 // initialize__LME__ first loop (LME.c:63-115): element search + closest element node
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N, TileCnt tc) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  double x[ND];
-  int c[3] = {0, 0, 0};
-  bool found = true;
+  const int p = blockIdx.x * BLK + threadIdx.x;
+  bool valid = p < P.np;
+  int bestnode = 0;
+  if (valid) {
+    double x[ND];
+    int c[3] = {0, 0, 0};
+    bool found = true;
 #pragma unroll
-  for (int a = 0; a < ND; a++) {
-    x[a] = PF(P, F_X + a, p);
-    int nc = g.n[a] - 1;
-    int ci = (int)floor((x[a] - g.o[a]) / g.h);
-    ci = ci < 0 ? 0 : (ci > nc - 1 ? nc - 1 : ci);
-    while (ci > 0 && x[a] <= g.o[a] + g.h * (double)ci) ci--;
-    while (ci < nc - 1 && x[a] > g.o[a] + g.h * (double)(ci + 1)) ci++;
-    if (x[a] < g.o[a] + g.h * (double)ci || x[a] > g.o[a] + g.h * (double)(ci + 1)) found = false;
-    c[a] = ci;
-  }
-  if (!found) {
-    atomicOr(&P.status[p], ST_CONNECT);
-    return;
-  }
-  // connectivity chain = reverse GiD file order (Read-GID-Mesh.c:411-413): rank of corner (a,b,t)
-  const int fileQ[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
-  double best = 0.0;
-  int bestrank = 256, bestnode = 0;
-#pragma unroll
-  for (int t = 0; t < (ND == 3 ? 2 : 1); t++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int filepos = 4 * t + q;
-      int nnod = (ND == 3) ? 8 : 4;
-      int rank = nnod - 1 - filepos;
-      int i = c[0] + fileQ[q][0], j = c[1] + fileQ[q][1], k = c[2] + t;
-      double D = 0.0, tt;
-      tt = x[0] - (g.o[0] + g.h * (double)i);
-      D += tt * tt;
-      tt = x[1] - (g.o[1] + g.h * (double)j);
-      D += tt * tt;
-      if (ND == 3) {
-        tt = x[ND - 1] - (g.o[2] + g.h * (double)k);
-        D += tt * tt;
-      }
-      D = sqrt(D);
-      if (bestrank == 256 || D < best || (D == best && rank < bestrank)) {
-        best = D;
-        bestrank = rank;
-        bestnode = i + g.n[0] * (j + g.n[1] * (ND == 3 ? k : 0));
-      }
+    for (int a = 0; a < ND; a++) {
+      x[a] = PF(P, F_X + a, p);
+      int nc = g.n[a] - 1;
+      int ci = (int)floor((x[a] - g.o[a]) / g.h);
+      ci = ci < 0 ? 0 : (ci > nc - 1 ? nc - 1 : ci);
+      while (ci > 0 && x[a] <= g.o[a] + g.h * (double)ci) ci--;
+      while (ci < nc - 1 && x[a] > g.o[a] + g.h * (double)(ci + 1)) ci++;
+      if (x[a] < g.o[a] + g.h * (double)ci || x[a] > g.o[a] + g.h * (double)(ci + 1)) found = false;
+      c[a] = ci;
     }
-  P.I0[p] = bestnode;
-  activate_ring<ND>(g, N.active, bestnode);
-  bin_particle<ND>(P, g, tc, p, bestnode);
+    if (!found) {
+      atomicOr(&P.status[p], ST_CONNECT);
+      valid = false;
+    } else {
+      // connectivity chain = reverse GiD file order (Read-GID-Mesh.c:411-413): rank of corner (a,b,t)
+      const int fileQ[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+      double best = 0.0;
+      int bestrank = 256;
+#pragma unroll
+      for (int t = 0; t < (ND == 3 ? 2 : 1); t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int filepos = 4 * t + q;
+          int nnod = (ND == 3) ? 8 : 4;
+          int rank = nnod - 1 - filepos;
+          int i = c[0] + fileQ[q][0], j = c[1] + fileQ[q][1], k = c[2] + t;
+          double D = 0.0, tt;
+          tt = x[0] - (g.o[0] + g.h * (double)i);
+          D += tt * tt;
+          tt = x[1] - (g.o[1] + g.h * (double)j);
+          D += tt * tt;
+          if (ND == 3) {
+            tt = x[ND - 1] - (g.o[2] + g.h * (double)k);
+            D += tt * tt;
+          }
+          D = sqrt(D);
+          if (bestrank == 256 || D < best || (D == best && rank < bestrank)) {
+            best = D;
+            bestrank = rank;
+            bestnode = i + g.n[0] * (j + g.n[1] * (ND == 3 ? k : 0));
+          }
+        }
+      P.I0[p] = bestnode;
+      activate_ring<ND>(g, N.active, bestnode);
+    }
+  }
+  bin_particle<ND>(P, g, tc, p, bestnode, valid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -411,7 +452,9 @@ __device__ __forceinline__ void store_block(const PView& P, int f0, int p, const
   if (ND == 2 && with_zz) PF(P, f0 + 4, p) = zz;
 }
 
-template <int ND>
+// LAW = -1: dispatch on the particle's material at run time (mixed clouds); LAW = 0/1/2: the whole
+// cloud uses that one law, so only its code (and register footprint) is compiled into the kernel.
+template <int ND, int LAW = -1>
 __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* __restrict__ mats, const ParamsD& prm,
                                              const double* Fn1, const double* DF, double J, double* tau) {
   MatD m = mats[P.mat[p]];
@@ -419,9 +462,10 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
   o.fail = 0;
   o.kappa = 0.0;
   o.eps = 0.0;
-  if (m.type == NLPS_MAT_NEO_HOOKEAN) {
+  const int law = (LAW >= 0) ? LAW : m.type;
+  if (law == NLPS_MAT_NEO_HOOKEAN) {
     law_neo_hookean<ND>(m, Fn1, J, o);
-  } else if (m.type == NLPS_MAT_HENCKY) {
+  } else if (law == NLPS_MAT_HENCKY) {
     law_hencky<ND>(m, Fn1, o);
   } else {
     double be[ND * ND], bzz;
@@ -885,6 +929,7 @@ struct nlps_gpu {
   double* h_avg_d;
   MatD* mats_d;
   int nmats;
+  int uniform_law;  // material law shared by every particle, or -1
   uint8_t* rank1_d;
   nlps_host::StencilTables tab;
 
@@ -1163,6 +1208,9 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   }
   // materials
   h->nmats = nmats;
+  h->uniform_law = nmats > 0 ? mats[0].type : -1;
+  for (int i = 1; i < nmats; i++)
+    if (mats[i].type != mats[0].type) h->uniform_law = -1;
   {
     std::vector<MatD> md(nmats);
     for (int i = 0; i < nmats; i++) md[i] = make_mat(mats[i], g.nd);
@@ -1669,8 +1717,22 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // S3 + S4
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL(k3_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
-    else hipLaunchKernelGGL(k3_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
+#define NLPS_K3(NDv, LAWv)                                                                                      \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
+                     h->prm, h->gstatus_d)
+    const int law = h->uniform_law;
+    if (ND == 2) {
+      if (law == 0) NLPS_K3(2, 0);
+      else if (law == 1) NLPS_K3(2, 1);
+      else if (law == 2) NLPS_K3(2, 2);
+      else NLPS_K3(2, -1);
+    } else {
+      if (law == 0) NLPS_K3(3, 0);
+      else if (law == 1) NLPS_K3(3, 1);
+      else if (law == 2) NLPS_K3(3, 2);
+      else NLPS_K3(3, -1);
+    }
+#undef NLPS_K3
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.force, ND, 8, 0)) return 1;

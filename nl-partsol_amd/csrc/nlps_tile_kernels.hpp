@@ -13,13 +13,16 @@
 
 template <int ND>
 struct TileCfg;
+// PS = LDS stride between z-planes of the window.  8x8 planes padded to 68 doubles: the 64 possible
+// I0 positions of a tile then spread evenly over the 32 b64 LDS banks (with 64 every z maps to the
+// same bank: 4-way conflicts on every window read / atomic).
 template <>
 struct TileCfg<3> {
-  static constexpr int TB = 4, W = 8, NW = 512;
+  static constexpr int TB = 4, W = 8, PS = 68, NW = 8 * 68;
 };
 template <>
 struct TileCfg<2> {
-  static constexpr int TB = 16, W = 20, NW = 400;
+  static constexpr int TB = 16, W = 20, PS = 400, NW = 400;
 };
 
 struct TileD {
@@ -46,26 +49,33 @@ __device__ __forceinline__ void tile_origin(const TileD& td, int tile, int* w0) 
   w0[2] = (ND == 3) ? tz * TB - 2 : 0;
 }
 
+// global node of window slot idx (inside = false for slots outside the grid and for padding slots);
+// row = index of the slot's x-row
 template <int ND>
-__device__ __forceinline__ int window_node(const GridD& g, const int* w0, int idx, bool& inside) {
-  constexpr int W = TileCfg<ND>::W;
-  int li = idx % W, lj = (idx / W) % W, lk = (ND == 3) ? idx / (W * W) : 0;
-  int gi = w0[0] + li, gj = w0[1] + lj, gk = (ND == 3) ? w0[2] + lk : 0;
-  inside = gi >= 0 && gi < g.n[0] && gj >= 0 && gj < g.n[1] && (ND == 2 || (gk >= 0 && gk < g.n[2]));
+__device__ __forceinline__ int window_node(const GridD& g, const int* w0, int idx, bool& inside, int* row = nullptr,
+                                           int* col = nullptr) {
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS;
+  const int lk = (ND == 3) ? idx / PS : 0;
+  const int rem = (ND == 3) ? idx % PS : idx;
+  const int li = rem % W, lj = rem / W;
+  const int gi = w0[0] + li, gj = w0[1] + lj, gk = (ND == 3) ? w0[2] + lk : 0;
+  inside = (lj < W) && gi >= 0 && gi < g.n[0] && gj >= 0 && gj < g.n[1] && (ND == 2 || (gk >= 0 && gk < g.n[2]));
+  if (row) *row = lj + (ND == 3 ? W * lk : 0);
+  if (col) *col = li;
   return gi + g.n[0] * (gj + g.n[1] * gk);
 }
 
 // window-local index of the stencil member (i,j,k) of a particle whose I0 has local index `base`
 template <int ND>
 __device__ __forceinline__ int wl(int base, int i, int j, int k) {
-  constexpr int W = TileCfg<ND>::W;
-  return base + (i - 2) + W * (j - 2) + (ND == 3 ? W * W * (k - 2) : 0);
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS;
+  return base + (i - 2) + W * (j - 2) + (ND == 3 ? PS * (k - 2) : 0);
 }
 
 template <int ND>
 __device__ __forceinline__ int window_base(const int* ijk, const int* w0) {
-  constexpr int W = TileCfg<ND>::W;
-  return (ijk[0] - w0[0]) + W * ((ijk[1] - w0[1]) + (ND == 3 ? W * (ijk[2] - w0[2]) : 0));
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS;
+  return (ijk[0] - w0[0]) + W * (ijk[1] - w0[1]) + (ND == 3 ? PS * (ijk[2] - w0[2]) : 0);
 }
 
 // exclusive scan of the per-tile particle counts (one 1024-thread block)
@@ -129,7 +139,7 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 template <int ND>
 __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
-  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
   constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NW];
   __shared__ unsigned actrow[NROWS];
@@ -146,8 +156,9 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
   __syncthreads();
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
     bool in;
-    int node = window_node<ND>(g, w0, idx, in);
-    if (in && N.active[node]) atomicOr(&actrow[idx / W], 1u << (idx % W));
+    int row, col;
+    int node = window_node<ND>(g, w0, idx, in, &row, &col);
+    if (in && N.active[node]) atomicOr(&actrow[row], 1u << col);
   }
   __syncthreads();
   const int start = td.start[tile];
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
     const int I0 = P.I0[p];
     c.geom(g, x, I0);
     const int bx = c.ijk[0] - w0[0], by = c.ijk[1] - w0[1], bz = (ND == 3) ? c.ijk[2] - w0[2] : 0;
-    const int base = bx + W * (by + (ND == 3 ? W * bz : 0));
+    const int base = bx + W * by + (ND == 3 ? PS * bz : 0);
     const double beta_prev = PF(P, F_BETA, p);
     const double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052
     const double T2 = sqrt_threshold(Ra);                       // sqrt(|l|^2) <= Ra  <=>  |l|^2 <= T2
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const double wz = mz * ez5[k];
-      const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
 #pragma unroll 1
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
@@ -270,9 +281,13 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
           if ((bits >> i) & 1u) {
             const int li = basek + (i - 2) + W * (j - 2);
             const double v0 = w * c.ex[i];
+#ifndef NLPS_EXP_NO_K2_SCATTER
             atomicAdd(&acc[li], v0);
 #pragma unroll
             for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NW + li], v0 * dd[a]);
+#else
+            if (v0 == 12345.0) acc[li] = v0 * dd[0];
+#endif
           }
       }
     }
@@ -292,10 +307,10 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
 // ------------------------------------------------------------------------------------------------
 // K3: G2P grad(dU) -> DF, F, J, density; stress; P2G of -f_int            (S3 + S4)
 // ------------------------------------------------------------------------------------------------
-template <int ND>
+template <int ND, int LAW>
 __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus) {
-  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double du[ND * NW];
   __shared__ double fac[ND * NW];
   const int tile = blockIdx.x;
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
-      const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
       double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;
       double Gx[ND], Gy[ND], Gz[ND];  // plane partial sums of G[.][x], G[.][y], G[.][z]/lz
 #pragma unroll
@@ -450,7 +465,11 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
     PF(P, F_JN1, p) = Jn1;
     PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
     double tau[ND * ND], B[ND * ND];
-    st |= stress_update<ND>(P, p, mats, prm, Fn1, DF, Jn1, tau);
+#ifndef NLPS_EXP_NO_STRESS
+    st |= stress_update<ND, LAW>(P, p, mats, prm, Fn1, DF, Jn1, tau);
+#else
+    for (int q2 = 0; q2 < ND * ND; q2++) tau[q2] = Fn1[q2];
+#endif
     if (force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0)) {
       // pass 2: -f_A = p_A * (B l_A), B l = B[.][x] lx_i + (B[.][y] ly_j + B[.][z] lz_k)
       double bx[ND][5];
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll 1
       for (int k = 0; k < KN; k++) {
         const unsigned pb = plane_bits<ND>(c, k);
-        const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+        const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
         const double wz = Zinv * ez5[k];
         const double lzk = lz5[k];
 #pragma unroll 1
@@ -478,7 +497,11 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
               const int li = basek + (i - 2) + W * (j - 2);
               const double we = w * c.ex[i];
 #pragma unroll
+#ifndef NLPS_EXP_NO_K3_SCATTER
               for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * (bx[a][i] + cr[a]));
+#else
+              for (int a = 0; a < ND; a++) if (we * (bx[a][i] + cr[a]) == 12345.0) fac[a * NW + li] = we;
+#endif
             }
         }
       }
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
 // ------------------------------------------------------------------------------------------------
 template <int ND>
 __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
-  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double du[ND * NW];
   __shared__ double ac[ND * NW];
   const int tile = blockIdx.x;
@@ -539,7 +562,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
-      const int basek = base + (ND == 3 ? W * W * (k - 2) : 0);
+      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
       const double z0 = ez5[k];
 #pragma unroll 1
       for (int j = 0; j < 5; j++) {
