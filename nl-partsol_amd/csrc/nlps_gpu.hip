@@ -286,7 +286,7 @@ __device__ __forceinline__ bool load_lme(const PView& P, const GridD& g, int p, 
   c.geom(g, x, P.I0[p]);
   c.mlo = P.mlo[p];
   c.mhi = P.mhi[p];
-  c.factors(lam, beta);
+  c.factors(lam, beta, g.h);
   return (c.mlo | c.mhi) != 0ull;
 }
 
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLK) void k_lists_newton(PView P, GridD g, NView N,
   double Zinv = 0.0;
   while (NumIter <= prm.max_iter_lme) {
     double r[ND], J[ND * ND], Jm1[ND * ND];
-    c.factors(lam, beta);
+    c.factors(lam, beta, g.h);
     lme_moments<ND>(c, Zinv, r, J);
     double aux = 0.0;
 #pragma unroll
@@ -1231,22 +1231,31 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     int lo = 1 << 30, hi = -1;
     const int TB = ND == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
     for (int p = 0; p < np; p++) {
-      // tile-major: (tile of the cell, then the cell inside the tile, x fastest)
-      long long kt = 0, kc = 0, mt = 1, mc = 1;
+      // Physical order = (tile of the closest node, corner type, closest node inside the tile).
+      // "Corner type" = which corner of its cell the closest node is.  Particles that share a closest
+      // node come from different cells, i.e. have different corner types, so any 64 consecutive
+      // particles (one wave) have 64 DISTINCT closest nodes: their window accesses (LDS atomics of
+      // the scatter, LDS reads of the gather) never collide on an address and spread over all banks.
+      long long kt = 0, kn = 0, kc = 0, mt = 1, mn = 1, mc = 1;
       for (int a = 0; a < ND; a++) {
         int nc = g.n[a] - 1;
-        int c = (int)floor((host->x_GC[(size_t)p * ND + a] - g.o[a]) / g.h);
+        double xi = (host->x_GC[(size_t)p * ND + a] - g.o[a]) / g.h;
+        int c = (int)floor(xi);
         c = c < 0 ? 0 : (c > nc - 1 ? nc - 1 : c);
-        kt += mt * (c / TB);
+        int nd = (int)floor(xi + 0.5);
+        nd = nd < 0 ? 0 : (nd > g.n[a] - 1 ? g.n[a] - 1 : nd);
+        kt += mt * (nd / TB);
         mt *= h->nt[a];
-        kc += mc * (c % TB);
-        mc *= TB;
+        kn += mn * (nd % TB);
+        mn *= TB;
+        kc += mc * (nd > c ? 1 : 0);
+        mc *= 2;
         if (a == slab_axis) {
           lo = std::min(lo, c);
           hi = std::max(hi, c + 1);
         }
       }
-      key[p] = kt * mc + kc;
+      key[p] = (kt * mc + kc) * mn + kn;
     }
     std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     h->slab_lo = std::max(0, lo - 3);

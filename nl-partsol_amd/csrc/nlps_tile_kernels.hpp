@@ -186,6 +186,10 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
       if (ND == 3) lz2[i] = c.lz[i % KN] * c.lz[i % KN];
     }
     u64 mlo = 0ull, mhi = 0ull;
+#ifdef NLPS_EXP_K2_REUSE_MASK
+    mlo = P.mlo[p]; mhi = P.mhi[p];
+    if ((mlo | mhi) == 0ull)
+#endif
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const double lz2k = (ND == 3) ? lz2[k] : 0.0;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
     double Zinv = 0.0;
     while (NumIter <= prm.max_iter_lme) {  // __lambda_Newton_Rapson, LME.c:272-353
       double r[ND], J[ND * ND], Jm1[ND * ND];
-      c.factors(lam, beta);
+      c.factors(lam, beta, g.h);
       lme_moments_h<ND>(c, Zinv, r, J);
       double aux = 0.0;
 #pragma unroll
@@ -281,12 +285,13 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
           if ((bits >> i) & 1u) {
             const int li = basek + (i - 2) + W * (j - 2);
             const double v0 = w * c.ex[i];
-#ifndef NLPS_EXP_NO_K2_SCATTER
+#ifndef NLPS_EXP_K2_MASS_ONLY
             atomicAdd(&acc[li], v0);
 #pragma unroll
             for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NW + li], v0 * dd[a]);
 #else
-            if (v0 == 12345.0) acc[li] = v0 * dd[0];
+            atomicAdd(&acc[li], v0);
+            if (v0 * dd[0] == 12345.0) acc[li] = v0 * dd[1];
 #endif
           }
       }
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
           const double m0 = on ? c.ex[i] : 0.0, m1 = on ? X.x1[i] : 0.0;
           A0 += m0;
           A1 += m1;
-          A2 += on ? X.x2[i] : 0.0;
+          A2 = fma(m0, X.x2[i], A2);
 #pragma unroll
           for (int a = 0; a < ND; a++) {
             const double u = du[a * NW + li];
