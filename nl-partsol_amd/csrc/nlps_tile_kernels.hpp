@@ -186,10 +186,6 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
       if (ND == 3) lz2[i] = c.lz[i % KN] * c.lz[i % KN];
     }
     u64 mlo = 0ull, mhi = 0ull;
-#ifdef NLPS_EXP_K2_REUSE_MASK
-    mlo = P.mlo[p]; mhi = P.mhi[p];
-    if ((mlo | mhi) == 0ull)
-#endif
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const double lz2k = (ND == 3) ? lz2[k] : 0.0;
@@ -285,14 +281,9 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
           if ((bits >> i) & 1u) {
             const int li = basek + (i - 2) + W * (j - 2);
             const double v0 = w * c.ex[i];
-#ifndef NLPS_EXP_K2_MASS_ONLY
             atomicAdd(&acc[li], v0);
 #pragma unroll
             for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NW + li], v0 * dd[a]);
-#else
-            atomicAdd(&acc[li], v0);
-            if (v0 * dd[0] == 12345.0) acc[li] = v0 * dd[1];
-#endif
           }
       }
     }
@@ -470,11 +461,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
     PF(P, F_JN1, p) = Jn1;
     PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
     double tau[ND * ND], B[ND * ND];
-#ifndef NLPS_EXP_NO_STRESS
     st |= stress_update<ND, LAW>(P, p, mats, prm, Fn1, DF, Jn1, tau);
-#else
-    for (int q2 = 0; q2 < ND * ND; q2++) tau[q2] = Fn1[q2];
-#endif
     if (force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0)) {
       // pass 2: -f_A = p_A * (B l_A), B l = B[.][x] lx_i + (B[.][y] ly_j + B[.][z] lz_k)
       double bx[ND][5];
@@ -502,11 +489,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
               const int li = basek + (i - 2) + W * (j - 2);
               const double we = w * c.ex[i];
 #pragma unroll
-#ifndef NLPS_EXP_NO_K3_SCATTER
               for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * (bx[a][i] + cr[a]));
-#else
-              for (int a = 0; a < ND; a++) if (we * (bx[a][i] + cr[a]) == 12345.0) fac[a * NW + li] = we;
-#endif
             }
         }
       }
