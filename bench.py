@@ -53,74 +53,6 @@ def build_case(rank, world, cells, margin=5):
             "cloud": cloud, "materials": [{"type": 0, "E": 1.0e7, "nu": 0.3}], "block_lo": lo}
 
 
-class SlabHalo:
-    """Ghost-node exchange for a z-slab partition.  Rank r contributes to node layers
-    [zlo_r, zhi_r]; the layers it shares with rank r+-1 are summed (doubles) or OR-ed (bytes) with that
-    neighbour only (xGMI is point-to-point: two concurrent neighbour transfers, no ring).  Nodes are
-    x-fastest / z-slowest, so a range of z layers is one contiguous slice of the nodal array."""
-
-    def __init__(self, torch, dist, rank, world, grid_n, cells, margin, reach=4, mode="p2p"):
-        self.torch, self.dist, self.rank, self.world, self.mode = torch, dist, rank, world, mode
-        self.plane = grid_n[0] * grid_n[1]
-        self.nz = grid_n[2]
-        # rank r's particles live in cells [margin + r*cells, margin + (r+1)*cells); closest node I0 may be
-        # any node plane of those cells, its 5^3 stencil reaches 2 planes further; `reach` adds drift room
-        self.lo = [max(0, margin + r * cells - reach) for r in range(world)]
-        self.hi = [min(self.nz - 1, margin + (r + 1) * cells + reach) for r in range(world)]
-        self.bufs = {}
-
-    def overlap(self, a, b):
-        lo, hi = max(self.lo[a], self.lo[b]), min(self.hi[a], self.hi[b])
-        return (lo, hi) if lo <= hi else None
-
-    def __call__(self, dptr, nfield, elem, kind):
-        torch, dist = self.torch, self.dist
-        dtype = torch.float64 if elem == 8 else torch.uint8
-        n = self.plane * self.nz * nfield
-        arr = _as_tensor(torch, dptr, n, dtype)
-        if self.mode == "allreduce":
-            dist.all_reduce(arr, op=dist.ReduceOp.SUM if kind == 0 else dist.ReduceOp.MAX)
-            return 0
-        ops, recv = [], []
-        for nb in (self.rank - 1, self.rank + 1):
-            if nb < 0 or nb >= self.world:
-                continue
-            ov = self.overlap(self.rank, nb)
-            if ov is None:
-                continue
-            sl = arr[ov[0] * self.plane * nfield:(ov[1] + 1) * self.plane * nfield]
-            key = (nb, nfield, elem)
-            if key not in self.bufs:
-                self.bufs[key] = (torch.empty_like(sl), torch.empty_like(sl))
-            sbuf, rbuf = self.bufs[key]
-            sbuf.copy_(sl)
-            ops.append(dist.P2POp(dist.isend, sbuf, nb))
-            ops.append(dist.P2POp(dist.irecv, rbuf, nb))
-            recv.append((sl, rbuf))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for sl, rbuf in recv:
-            if kind == 0:
-                sl.add_(rbuf)
-            else:
-                torch.maximum(sl, rbuf, out=sl)
-        return 0
-
-
-def _as_tensor(torch, dptr, n, dtype):
-    """Wraps a raw device pointer owned by the library as a torch tensor (no copy)."""
-    itemsize = 8 if dtype == torch.float64 else 1
-
-    class _Holder:
-        pass
-
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8" if itemsize == 8 else "|u1",
-                                  "data": (int(dptr), False), "version": 2}
-    return torch.as_tensor(h, device="cuda")
-
-
 def cpu_baseline(cells, budget_s=25.0):
     """Times the oracle's explicit step (a from-scratch CPU port with OpenMP and the reference's
     omp-critical nodal accumulation, U-Newmark-beta.c:582-586) on a bounded 3-D sample of the same
@@ -191,8 +123,16 @@ def main():
     bcs = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, total_steps), dtype=np.int32),
                         "value": np.zeros((3, total_steps))}])
     if world > 1:
-        halo = SlabHalo(torch, dist, rank, world, case["grid_n"], a.cells, margin, mode=a.halo)
-        S.set_halo_exchange(halo)
+        halo_mod = importlib.import_module("nl-partsol_amd.halo")
+        gn = case["grid_n"]
+        lo, hi = halo_mod.SlabHalo.layer_ranges(world, a.cells, margin, gn[2])
+        halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)
+        nnodes = gn[0] * gn[1] * gn[2]
+
+        def exchange(dptr, nfield, elem, kind):
+            return halo.exchange(halo_mod.device_tensor(torch, dptr, nnodes * nfield, elem), nfield, kind)
+
+        S.set_halo_exchange(exchange)
     S.initialise_shapefun()
     dt = 0.1 * case["h"] / 100.0  # CFL 0.1, celerity sqrt(E/rho) = 100
 

@@ -192,6 +192,15 @@ int nlps_gpu_set_halo_exchange(nlps_gpu *h, nlps_halo_fn fn, void *ctx);
 /* Range of node layers along the slab axis this rank's particles may touch (5^d stencil reach). */
 int nlps_gpu_touched_layers(nlps_gpu *h, int *lo, int *hi);
 
+/* ------------------------------------------------------------------ host-only helpers (no GPU needed) */
+
+/* Stencil-order tables the library derives for the canonical grid numbering (see csrc/nlps_tables.hpp):
+ * rank1[27][27]  chain position of each 3^d offset of NodalLocality_0 per 1-ring boundary class,
+ * order2[125][125] / count2[125]  walk order of NodalLocality per 2-ring boundary class,
+ * h_avg1[27]     mean 1-ring distance per class for h = 1 (Read_GramsBox.c:460-507). */
+int nlps_host_stencil_tables(int ndim, unsigned char *rank1, unsigned char *order2, unsigned char *count2,
+                             double *h_avg1);
+
 /* ------------------------------------------------------------------ measurement */
 
 /* Time (ms, HIP events on the handle's stream) of the kernels of the last explicit step:

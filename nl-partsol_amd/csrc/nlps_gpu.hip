@@ -1072,6 +1072,17 @@ static int ensure_masked(nlps_gpu* h, size_t n) {
   return 0;
 }
 
+extern "C" int nlps_host_stencil_tables(int ndim, unsigned char* rank1, unsigned char* order2, unsigned char* count2,
+                                        double* h_avg1) {
+  if (ndim != 2 && ndim != 3) return 1;
+  nlps_host::StencilTables t = nlps_host::build_tables(ndim);
+  if (rank1) memcpy(rank1, t.rank1, sizeof(t.rank1));
+  if (order2) memcpy(order2, t.order2, sizeof(t.order2));
+  if (count2) memcpy(count2, t.count2, sizeof(t.count2));
+  if (h_avg1) memcpy(h_avg1, t.h_avg1, sizeof(t.h_avg1));
+  return 0;
+}
+
 extern "C" const char* nlps_gpu_last_error(const nlps_gpu* h) { return h ? h->err.c_str() : "null handle"; }
 
 extern "C" int nlps_gpu_synchronize(nlps_gpu* h) {

@@ -63,7 +63,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_touched_layers", "nlps_gpu_set_timing", "nlps_gpu_get_timing"]
+           "nlps_gpu_touched_layers", "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
 
 
 def lib():
@@ -113,6 +113,21 @@ def lib():
 
 def default_params():
     return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10)
+
+
+def host_stencil_tables(ndim):
+    """Host-only: the stencil order tables of csrc/nlps_tables.hpp (no GPU needed)."""
+    rank1 = np.zeros((27, 27), dtype=np.uint8)
+    order2 = np.zeros((125, 125), dtype=np.uint8)
+    count2 = np.zeros(125, dtype=np.uint8)
+    h1 = np.zeros(27)
+    f = lib().nlps_host_stencil_tables
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = f(int(ndim), rank1.ctypes.data_as(C.c_void_p), order2.ctypes.data_as(C.c_void_p),
+           count2.ctypes.data_as(C.c_void_p), h1.ctypes.data_as(C.c_void_p))
+    if st:
+        raise NlpsError("nlps_host_stencil_tables failed")
+    return rank1, order2, count2, h1
 
 
 def _d(a):

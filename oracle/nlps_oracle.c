@@ -656,6 +656,25 @@ int orc_local_search(orc_particles *P, orc_mesh *M, const orc_params *prm) {
   return lists_and_lambda(P, M, prm);
 }
 
+/* The two halves of orc_local_search, exposed so that multi-rank tests can exchange ActiveNode[]
+ * between them (the build's slab partition ORs the flags of the ghost layers at that point). */
+int orc_search_phase1(orc_particles *P, orc_mesh *M) {
+  int ndim = M->ndim;
+  memset(M->active, 0, (size_t)M->nnodes);
+  for (int p = 0; p < P->np; p++) {
+    double aux = 0.0;
+    for (int i = 0; i < ndim; i++) aux += dsqr(P->dis[p * ndim + i]);
+    if (pow(aux, 0.5) > 0.0) {
+      int I0 = P->I0[p];
+      P->I0[p] = closest_node(&P->x[p * ndim], &M->r1[M->r1_ptr[I0]], M->r1_ptr[I0 + 1] - M->r1_ptr[I0],
+                              M->coords, ndim);
+    }
+  }
+  activate_one_rings(P, M);
+  return 0;
+}
+int orc_search_phase2(orc_particles *P, orc_mesh *M, const orc_params *prm) { return lists_and_lambda(P, M, prm); }
+
 /* compute_N__MeshTools__, Shape-Functions.c:163-195 (LME branch) */
 int orc_compute_N(double *N, const orc_particles *P, const orc_mesh *M, int p) {
   double l[ORC_MAXNB * 3];

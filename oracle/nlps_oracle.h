@@ -102,6 +102,8 @@ int orc_sym_eigen(double *eigval, double *eigvec, const double *A, int n);
 
 int orc_initialize_lme(orc_particles *P, orc_mesh *M, const orc_params *prm);
 int orc_local_search(orc_particles *P, orc_mesh *M, const orc_params *prm);
+int orc_search_phase1(orc_particles *P, orc_mesh *M);
+int orc_search_phase2(orc_particles *P, orc_mesh *M, const orc_params *prm);
 int orc_compute_N(double *N, const orc_particles *P, const orc_mesh *M, int p);
 int orc_compute_dN(double *dN, const orc_particles *P, const orc_mesh *M, int p);
 

@@ -214,6 +214,14 @@ def local_search(P, M, prm):
     return lib().orc_local_search(C.byref(P.c), M.ptr, C.byref(prm))
 
 
+def search_phase1(P, M):
+    return lib().orc_search_phase1(C.byref(P.c), M.ptr)
+
+
+def search_phase2(P, M, prm):
+    return lib().orc_search_phase2(C.byref(P.c), M.ptr, C.byref(prm))
+
+
 def active_nodes(M):
     n2m = np.zeros(M.nnodes, dtype=np.int32)
     na = lib().orc_active_nodes(_i(n2m), M.ptr)

@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/nlps_gpu.h declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from util import ROOT, make_case, nlps
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nlps_gpu.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nlps_(?:gpu|host)_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    n = nlps()
+    L = n.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert sorted(n.SYMBOLS) == syms, "python binding list out of sync with the header"
+
+
+def test_header_is_plain_c():
+    import subprocess
+    import tempfile
+    src = '#include "nlps_gpu.h"\nint main(void){ nlps_grid g; nlps_particles p; (void)g; (void)p; return 0; }\n'
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "t.c")
+        open(f, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                               "-c", f, "-o", os.path.join(d, "t.o")])
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "nl-partsol_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert not re.search(r"import\s+oracle|from\s+oracle|nlps_oracle|oracle/|orc_\w+\(", txt), \
+                    fn + " references the oracle"
+    import subprocess
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "csrc", "libnlps_gpu.so")]).decode()
+    assert "nlps_oracle" not in out
+
+
+def test_no_gpu_means_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    n = nlps()
+    case = make_case(2, [8, 8], [2, 2], [3, 3])
+    with pytest.raises(n.NlpsError):
+        n.Solver(2, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"])

@@ -1,0 +1,113 @@
+"""N > 1 path on CPU: world_size-2/3 gloo processes run the slab partition with the ghost-node
+exchange of nl-partsol_amd/halo.py (the same SlabHalo object bench.py installs behind the C-ABI halo
+callback), with the ORACLE doing each rank's particle work.  The partitioned result must equal the
+single-process oracle: ActiveNode after the OR exchange, neighbour lists, nodal mass after the sum
+exchange."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CELLS, MARGIN, NX = 7, 4, 11
+
+
+def _global_case(world):
+    import util
+    cells = [NX, CELLS * world + 2 * MARGIN]
+    case = util.make_case(2, cells, [3, MARGIN], [5, CELLS * world], velocity=[0.3, -1.0], seed=99)
+    return case
+
+
+def _worker(rank, world, port, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import torch
+    import torch.distributed as dist
+    import util
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    o = util.orc()
+    halo_mod = importlib.import_module("nl-partsol_amd.halo")
+    case = _global_case(world)
+    gn = case["grid_n"]
+    # reference run: one process, all particles
+    Mg, Pg, prm, mats = util.oracle_setup(case)
+    rng = np.random.default_rng(5)
+    dx = 0.3 * rng.uniform(-1, 1, size=Pg["x"].shape)
+    # shard: particles whose cell lies in this rank's slab (before the move)
+    ycell = np.floor(case["cloud"]["x"][:, 1]).astype(int)
+    mine = (ycell >= MARGIN + CELLS * rank) & (ycell < MARGIN + CELLS * (rank + 1))
+    shard = {k: (v[mine].copy() if isinstance(v, np.ndarray) and v.shape[:1] == (Pg.np,) else v)
+             for k, v in case["cloud"].items()}
+    shard["x"] = Pg["x"][mine] + dx[mine]
+    shard["dis"] = Pg["dis"][mine] + dx[mine]
+    shard["I0"] = Pg["I0"][mine].copy()
+    shard["lambda"] = Pg["lambda"][mine].copy()
+    shard["beta"] = Pg["beta"][mine].copy()
+    Pg["x"][:] += dx
+    Pg["dis"][:] += dx
+    assert o.local_search(Pg, Mg, prm) == 0
+    n2m_g, na_g = o.active_nodes(Mg)
+    mass_g = np.zeros(Mg.nnodes)
+    mass_g[n2m_g >= 0] = o.lumped_mass(Pg, Mg, n2m_g, na_g).reshape(-1, 2)[:, 0]
+
+    # partitioned run
+    M = o.OracleMesh(2, gn, case["origin"], case["h"])
+    P = o.OracleParticles(shard)
+    lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[1], reach=3)
+    halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0], gn[1], lo, hi, mode=mode)
+    assert o.search_phase1(P, M) == 0
+    act = torch.from_numpy(M.active())           # shares memory with the oracle mesh
+    halo.exchange(act, 1, 1)
+    assert o.search_phase2(P, M, prm) == 0
+    n2m, na = o.active_nodes(M)
+    mass = np.zeros(M.nnodes)
+    mass[n2m >= 0] = o.lumped_mass(P, M, n2m, na).reshape(-1, 2)[:, 0]
+    mt = torch.from_numpy(mass)
+    halo.exchange(mt, 1, 0)
+
+    sl = slice(lo[rank] * gn[0], (hi[rank] + 1) * gn[0])
+    own = slice((MARGIN + CELLS * rank) * gn[0], (MARGIN + CELLS * (rank + 1) + 1) * gn[0])
+    ok = True
+    msgs = []
+    if not np.array_equal(P["I0"], Pg["I0"][mine]):
+        ok = False
+        msgs.append("I0")
+    if not np.array_equal(P["nn"], Pg["nn"][mine]):
+        ok = False
+        msgs.append("nn")
+    for q, p in enumerate(np.nonzero(mine)[0]):
+        if not np.array_equal(P.lists(q), Pg.lists(p)):
+            ok = False
+            msgs.append("list %d" % p)
+            break
+    if mode == "p2p":
+        # active flags and masses are complete on the layers this rank's particles can reach
+        need = slice((MARGIN + CELLS * rank - 2) * gn[0], (MARGIN + CELLS * (rank + 1) + 3) * gn[0])
+        if not np.array_equal(M.active()[need], Mg.active()[need]):
+            ok = False
+            msgs.append("active")
+        if not np.allclose(mass[need], mass_g[need], rtol=1e-13, atol=0):
+            ok = False
+            msgs.append("mass")
+    else:
+        if not np.array_equal(M.active(), Mg.active()) or not np.allclose(mass, mass_g, rtol=1e-13, atol=0):
+            ok = False
+            msgs.append("allreduce")
+    del sl, own
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("OK" if ok else "FAIL " + " ".join(msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "p2p"), (3, "p2p"), (2, "allreduce")])
+def test_slab_partition_matches_single_process(world, mode, tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + world * 7 + (0 if mode == "p2p" else 3)
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / ("rank%d.txt" % r)).read() == "OK"
