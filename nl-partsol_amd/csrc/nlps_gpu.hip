@@ -1766,8 +1766,17 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // S5
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL(k5_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm);
-    else hipLaunchKernelGGL(k5_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm);
+#define NLPS_K5(NDv, LAWv) \
+  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
+    const int law = h->uniform_law;
+    if (ND == 2) {
+      if (law == 0 || law == 1) NLPS_K5(2, 0);
+      else NLPS_K5(2, 2);
+    } else {
+      if (law == 0 || law == 1) NLPS_K5(3, 0);
+      else NLPS_K5(3, 2);
+    }
+#undef NLPS_K5
   }
   HIPCHK(hipGetLastError());
   if (h->timing) {

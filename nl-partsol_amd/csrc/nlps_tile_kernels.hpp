@@ -307,7 +307,8 @@ template <int ND, int LAW>
 __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
-  __shared__ double du[ND * NW];
+  constexpr int DS = (ND == 3) ? 4 : 2;  // doubles per node of the AoS gather window (16-B aligned)
+  __shared__ __attribute__((aligned(16))) double du[DS * NW];
   __shared__ double fac[ND * NW];
   const int tile = blockIdx.x;
   const int cnt = td.count[tile];
@@ -319,11 +320,13 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
     int node = window_node<ND>(g, w0, idx, in);
 #pragma unroll
     for (int a = 0; a < ND; a++) {
-      du[a * NW + idx] = in ? N.dU[(size_t)node * ND + a] : 0.0;
+      du[idx * DS + a] = in ? N.dU[(size_t)node * ND + a] : 0.0;
       fac[a * NW + idx] = 0.0;
     }
+    if (DS > ND) du[idx * DS + ND] = 0.0;
   }
   __syncthreads();
+  const double2* du2 = reinterpret_cast<const double2*>(du);
   const int start = td.start[tile];
   for (int s = threadIdx.x; s < cnt; s += BLK) {
     const int p = td.order[start + s];
@@ -361,11 +364,13 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
           A0 += m0;
           A1 += m1;
           A2 = fma(m0, X.x2[i], A2);
+          const double2 u01 = du2[li * (DS / 2)];
+          const double u2 = (ND == 3) ? du[li * DS + 2] : 0.0;
+          const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
           for (int a = 0; a < ND; a++) {
-            const double u = du[a * NW + li];
-            R0[a] = fma(m0, u, R0[a]);
-            R1[a] = fma(m1, u, R1[a]);
+            R0[a] = fma(m0, uu[a], R0[a]);
+            R1[a] = fma(m1, uu[a], R1[a]);
           }
         }
         const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
@@ -515,12 +520,16 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
 
 // ------------------------------------------------------------------------------------------------
 // K5: G2P of nodal acceleration and dU, corrector, roll                   (S5)
+// The gather window is AoS: the 2d doubles {dU, a} of one node are contiguous and 16-B aligned, read
+// as double2 (ds_read_b128, full LDS rate, conflict-free for the tile's 64 I0 positions) instead of
+// 2d separate 8-byte reads that the compiler pairs into half-rate ds_read2_b64.
 // ------------------------------------------------------------------------------------------------
-template <int ND>
+template <int ND, int LAW>
 __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
-  __shared__ double du[ND * NW];
-  __shared__ double ac[ND * NW];
+  constexpr int NV = 2 * ND;           // values per node: dU[ND], accel[ND]
+  constexpr int NP = (NV + 1) / 2;     // double2 per node (2-D: 2, 3-D: 3)
+  __shared__ __attribute__((aligned(16))) double win[NW * 2 * NP];
   const int tile = blockIdx.x;
   const int cnt = td.count[tile];
   if (cnt == 0) return;
@@ -531,11 +540,12 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
     int node = window_node<ND>(g, w0, idx, in);
 #pragma unroll
     for (int a = 0; a < ND; a++) {
-      du[a * NW + idx] = in ? N.dU[(size_t)node * ND + a] : 0.0;
-      ac[a * NW + idx] = in ? N.accel[(size_t)node * ND + a] : 0.0;
+      win[idx * 2 * NP + a] = in ? N.dU[(size_t)node * ND + a] : 0.0;
+      win[idx * 2 * NP + ND + a] = in ? N.accel[(size_t)node * ND + a] : 0.0;
     }
   }
   __syncthreads();
+  const double2* win2 = reinterpret_cast<const double2*>(win);
   const int start = td.start[tile];
   for (int s = threadIdx.x; s < cnt; s += BLK) {
     const int p = td.order[start + s];
@@ -544,9 +554,9 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     const int base = window_base<ND>(c.ijk, w0);
     NLPS_YZ_LOCALS(c);
-    double Z = 0.0, sa[ND], su[ND];
+    double Z = 0.0, sv[2 * NP];
 #pragma unroll
-    for (int a = 0; a < ND; a++) sa[a] = su[a] = 0.0;
+    for (int a = 0; a < 2 * NP; a++) sv[a] = 0.0;
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
@@ -555,33 +565,31 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll 1
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
-        double A0 = 0.0, Ra_[ND], Ru_[ND];
+        double A0 = 0.0, R[2 * NP];
 #pragma unroll
-        for (int a = 0; a < ND; a++) Ra_[a] = Ru_[a] = 0.0;
+        for (int a = 0; a < 2 * NP; a++) R[a] = 0.0;
 #pragma unroll
         for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
           const int li = basek + (i - 2) + W * (j - 2);
           const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0;
           A0 += m0;
 #pragma unroll
-          for (int a = 0; a < ND; a++) {
-            Ra_[a] = fma(m0, ac[a * NW + li], Ra_[a]);
-            Ru_[a] = fma(m0, du[a * NW + li], Ru_[a]);
+          for (int q = 0; q < NP; q++) {
+            const double2 v = win2[li * NP + q];
+            R[2 * q] = fma(m0, v.x, R[2 * q]);
+            R[2 * q + 1] = fma(m0, v.y, R[2 * q + 1]);
           }
         }
         const double w = ey5[j] * z0;
         Z = fma(w, A0, Z);
 #pragma unroll
-        for (int a = 0; a < ND; a++) {
-          sa[a] = fma(w, Ra_[a], sa[a]);
-          su[a] = fma(w, Ru_[a], su[a]);
-        }
+        for (int a = 0; a < 2 * NP; a++) sv[a] = fma(w, R[a], sv[a]);
       }
     }
     const double Zinv = 1.0 / Z;
 #pragma unroll
     for (int a = 0; a < ND; a++) {
-      double av = sa[a] * Zinv, dd = su[a] * Zinv;
+      double dd = sv[a] * Zinv, av = sv[ND + a] * Zinv;
       PF(P, F_ACC + a, p) = av;
       PF(P, F_DDIS + a, p) = dd;
       PF(P, F_VEL + a, p) = PF(P, F_VEL + a, p) + gamma_nm * dt * av;
@@ -589,13 +597,15 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
       PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
     }
     PF(P, F_JN, p) = PF(P, F_JN1, p);
-    PF(P, F_KN, p) = PF(P, F_KN1, p);
-    PF(P, F_EN, p) = PF(P, F_EN1, p);
     constexpr int T = (ND == 2) ? 5 : 9;
 #pragma unroll
-    for (int s2 = 0; s2 < T; s2++) {
-      PF(P, F_BEN + s2, p) = PF(P, F_BEN1 + s2, p);
-      PF(P, F_FN + s2, p) = PF(P, F_FN1 + s2, p);
+    for (int s2 = 0; s2 < T; s2++) PF(P, F_FN + s2, p) = PF(P, F_FN1 + s2, p);
+    if (LAW != NLPS_MAT_NEO_HOOKEAN && LAW != NLPS_MAT_HENCKY) {
+      // kappa, eps-bar and b_e exist for the plastic law only (Constitutive.c:160-168)
+      PF(P, F_KN, p) = PF(P, F_KN1, p);
+      PF(P, F_EN, p) = PF(P, F_EN1, p);
+#pragma unroll
+      for (int s2 = 0; s2 < T; s2++) PF(P, F_BEN + s2, p) = PF(P, F_BEN1 + s2, p);
     }
   }
 }
