@@ -137,7 +137,7 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
+__global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
   constexpr int KN = Lme<ND>::KN;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
       const unsigned pb = plane_bits<ND>(c, k);
       const double wz = mz * ez5[k];
       const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
-#pragma unroll 1
+#pragma unroll NLPS_JUNROLL_SCATTER
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
         const double w = wz * ey5[j];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(BLK) void k2_tile(PView P, GridD g, NView N, TileD 
 // K3: G2P grad(dU) -> DF, F, J, density; stress; P2G of -f_int            (S3 + S4)
 // ------------------------------------------------------------------------------------------------
 template <int ND, int LAW>
-__global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+__global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int DS = (ND == 3) ? 4 : 2;  // doubles per node of the AoS gather window (16-B aligned)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
       double Gx[ND], Gy[ND], Gz[ND];  // plane partial sums of G[.][x], G[.][y], G[.][z]/lz
 #pragma unroll
       for (int a = 0; a < ND; a++) Gx[a] = Gy[a] = Gz[a] = 0.0;
-#pragma unroll 1
+#pragma unroll NLPS_JUNROLL_K3
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
         double A0 = 0.0, A1 = 0.0, A2 = 0.0, R0[ND], R1[ND];
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(BLK) void k3_tile(PView P, GridD g, NView N, TileD 
         const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
         const double wz = Zinv * ez5[k];
         const double lzk = lz5[k];
-#pragma unroll 1
+#pragma unroll NLPS_JUNROLL_SCATTER
         for (int j = 0; j < 5; j++) {
           const unsigned bits = (pb >> (5 * j)) & 31u;
           const double w = wz * ey5[j];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
       const unsigned pb = plane_bits<ND>(c, k);
       const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
       const double z0 = ez5[k];
-#pragma unroll 1
+#pragma unroll NLPS_JUNROLL_K5
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
         double A0 = 0.0, R[2 * NP];
