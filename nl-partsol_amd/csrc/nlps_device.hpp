@@ -646,8 +646,6 @@ struct LmeX {  // x-axis helpers: ex*lx (per evaluation) and lx^2 (geometry)
 // Z^-1, r = sum p l, J = sum p l(x)l - r(x)r  (LME.c:766-832) by rows and planes
 template <int ND>
 __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
-  LmeX<ND> X;
-  X.prep(c);
   NLPS_YZ_LOCALS(c);
   double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
   // real (not unrolled) plane and row loops: compact code, short live ranges
@@ -662,10 +660,10 @@ __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, do
       double A0 = 0.0, A1 = 0.0, A2 = 0.0;
 #pragma unroll
       for (int i = 0; i < 5; i++) {
-        const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+        const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0, m1 = m0 * c.lx[i];
         A0 += m0;
-        A1 = fma(m0, c.lx[i], A1);
-        A2 = fma(m0, X.x2[i], A2);
+        A1 += m1;
+        A2 = fma(m1, c.lx[i], A2);
       }
       const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
       P00 = fma(y0, A0, P00);

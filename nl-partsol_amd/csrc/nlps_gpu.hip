@@ -1495,8 +1495,8 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   if (tiled) {
     TileD td = tile_view(h);
-    if (h->nd == 2) hipLaunchKernelGGL(k2_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
-    else hipLaunchKernelGGL(k2_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    if (h->nd == 2) hipLaunchKernelGGL(k2_tile<2>, dim3(h->ntiles * K2_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    else hipLaunchKernelGGL(k2_tile<3>, dim3(h->ntiles * K2_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
   } else {
     LAUNCH_ND((k_lists_newton<2, false>), (k_lists_newton<3, false>), nblk(np), h->P, h->g, h->N, h->prm, dt,
               gamma_nm, h->gstatus_d);
@@ -1738,7 +1738,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   {
     TileD td = tile_view(h);
 #define NLPS_K3(NDv, LAWv)                                                                                      \
-  hipLaunchKernelGGL((k3_tile<NDv, LAWv>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d)
     const int law = h->uniform_law;
     if (ND == 2) {
@@ -1767,7 +1767,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   {
     TileD td = tile_view(h);
 #define NLPS_K5(NDv, LAWv) \
-  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
+  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntiles * K5_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
     const int law = h->uniform_law;
     if (ND == 2) {
       if (law == 0 || law == 1) NLPS_K5(2, 0);
