@@ -313,8 +313,11 @@ template <int ND, int LAW>
 __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
-  constexpr int DS = (ND == 3) ? 4 : 2;  // doubles per node of the AoS gather window (16-B aligned)
-  __shared__ __attribute__((aligned(16))) double du[DS * NW];
+  // gather window of dU: {x,y} as one 16-B double2 per node (ds_read_b128) + z as a separate 8-B array
+  // (ds_read_b64): with node strides of 16 B and 8 B the tile's 64 I0 positions hit distinct banks; a
+  // padded 32-B AoS row put every second node on the same banks (41 % conflict cycles measured).
+  __shared__ __attribute__((aligned(16))) double duxy[2 * NW];
+  __shared__ double duz[(ND == 3) ? NW : 1];
   __shared__ double fac[ND * NW];
   const int tile = blockIdx.x / K3_SPLIT, part = blockIdx.x % K3_SPLIT;
   const int cnt = td.count[tile];
@@ -324,15 +327,14 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
     bool in;
     int node = window_node<ND>(g, w0, idx, in);
+    duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
+    duxy[2 * idx + 1] = in ? N.dU[(size_t)node * ND + 1] : 0.0;
+    if (ND == 3) duz[idx % ((ND == 3) ? NW : 1)] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
 #pragma unroll
-    for (int a = 0; a < ND; a++) {
-      du[idx * DS + a] = in ? N.dU[(size_t)node * ND + a] : 0.0;
-      fac[a * NW + idx] = 0.0;
-    }
-    if (DS > ND) du[idx * DS + ND] = 0.0;
+    for (int a = 0; a < ND; a++) fac[a * NW + idx] = 0.0;
   }
   __syncthreads();
-  const double2* du2 = reinterpret_cast<const double2*>(du);
+  const double2* du2 = reinterpret_cast<const double2*>(duxy);
   const int start = td.start[tile];
   for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K3_SPLIT) {
     const int p = td.order[start + s];
@@ -368,8 +370,8 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
           A0 += m0;
           A1 += m1;
           A2 = fma(m1, c.lx[i], A2);
-          const double2 u01 = du2[li * (DS / 2)];
-          const double u2 = (ND == 3) ? du[li * DS + 2] : 0.0;
+          const double2 u01 = du2[li];
+          const double u2 = (ND == 3) ? duz[li % ((ND == 3) ? NW : 1)] : 0.0;
           const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
           for (int a = 0; a < ND; a++) {
