@@ -180,6 +180,13 @@ int nlps_gpu_num_active(nlps_gpu *h, int *nactive);
 int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force, double *accel,
                             double *reaction);
 
+/* Maintenance: physically re-sorts the device-resident particle arrays by (tile of the closest node,
+ * corner type, closest node) so that memory order keeps matching the tile binning as particles move.
+ * Results are unaffected (downloads always use the caller's particle order).  explicit_step calls it
+ * every `every_n_steps` steps (default 50, 0 = never). */
+int nlps_gpu_resort(nlps_gpu *h);
+int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
+
 /* ------------------------------------------------------------------ multi-GPU hooks */
 
 /* Halo exchange callback, invoked by explicit_step / the P2G stages after a nodal scatter, on the

@@ -11,6 +11,7 @@
 // One lane = one particle.  All LME quantities (15 separable exp factors, Z, r, J, J^-1, DF, tau)
 // live in that lane's registers; no MFMA (<=3x3 contractions), no LDS in the gather kernels.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -905,6 +906,39 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 #include "nlps_tile_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
+// physical re-sort of the particle SoA (maintenance, every few dozen steps): restores the
+// (tile of I0, corner type, I0 in tile) memory order that makes waves hit distinct window slots
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.np) return;
+  constexpr int TB = TileCfg<ND>::TB;
+  const int I0 = P.I0[p];
+  int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+  unsigned long long kt = 0, kn = 0, kc = 0, mt = 1, mn = 1, mc = 1;
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    const double xi = (PF(P, F_X + a, p) - g.o[a]) / g.h;
+    int c = (int)floor(xi);
+    c = c < 0 ? 0 : (c > g.n[a] - 2 ? g.n[a] - 2 : c);
+    kt += mt * (unsigned long long)(ijk[a] / TB);
+    mt *= (unsigned long long)tc.nt[a];
+    kn += mn * (unsigned long long)(ijk[a] % TB);
+    mn *= TB;
+    kc += mc * (unsigned long long)(ijk[a] > c ? 1 : 0);
+    mc *= 2;
+  }
+  keys[p] = (kt * mc + kc) * mn + kn;
+  vals[p] = p;
+}
+template <class T>
+__global__ void k_gather(T* __restrict__ out, const T* __restrict__ in, const int* __restrict__ idx, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[idx[i]];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct BcDev {
@@ -950,6 +984,16 @@ struct nlps_gpu {
   size_t maskedA_cap;
 
   std::vector<BcDev> bcs;
+
+  // periodic physical re-sort
+  int* perm_d;            // sorted slot -> caller's particle index (device copy of perm)
+  bool perm_dirty;        // device perm newer than the host copy
+  int resort_every, steps_since_sort;
+  unsigned long long *skey_d, *skey2_d;
+  int *sval_d, *sval2_d;
+  void* cub_tmp;
+  size_t cub_tmp_bytes;
+  double* gather_tmp;     // [npad] scratch for the field-by-field gather
 
   // per-step tile binning
   int nt[3], ntiles;
@@ -1141,6 +1185,15 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->masks_valid = false;
   h->maskedA = nullptr;
   h->maskedA_cap = 0;
+  h->perm_d = nullptr;
+  h->perm_dirty = false;
+  h->resort_every = 50;
+  h->steps_since_sort = 0;
+  h->skey_d = h->skey2_d = nullptr;
+  h->sval_d = h->sval2_d = nullptr;
+  h->cub_tmp = nullptr;
+  h->cub_tmp_bytes = 0;
+  h->gather_tmp = nullptr;
   memset(h->ms, 0, sizeof(h->ms));
   if (grid->ndim != 2 && grid->ndim != 3) {
     h->err = "ndim must be 2 or 3";
@@ -1322,7 +1375,68 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
       HIPCHK(hipMemcpy(h->P.I0, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
     }
   }
+  // re-sort buffers
+  if (dev_alloc(h, &h->perm_d, h->P.npad)) return 1;
+  HIPCHK(hipMemcpy(h->perm_d, h->perm.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice));
+  if (dev_alloc(h, &h->skey_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->skey2_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->sval_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->sval2_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->gather_tmp, h->P.npad)) return 1;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, h->cub_tmp_bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np,
+                                            0, 64, h->stream));
+  HIPCHK(hipMalloc(&h->cub_tmp, h->cub_tmp_bytes + 16));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// Physical re-sort of every particle array by (tile of I0, corner type, I0 in tile).
+static int resort(nlps_gpu* h) {
+  const int np = h->P.np;
+  if (np == 0) return 0;
+  TileCnt tc;
+  for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
+  tc.count = nullptr;
+  if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d);
+  else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d);
+  HIPCHK(hipGetLastError());
+  size_t bytes = h->cub_tmp_bytes;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
+                                            h->stream));
+  const int* idx = h->sval2_d;  // new slot -> old slot
+  const size_t npad = h->P.npad;
+  for (int f = 0; f < NFD; f++) {
+    double* fld = h->P.d + (size_t)f * npad;
+    hipLaunchKernelGGL(k_gather<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->gather_tmp, fld, idx, np);
+    HIPCHK(hipMemcpyAsync(fld, h->gather_tmp, (size_t)np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d};
+  for (int* a : iarr) {
+    hipLaunchKernelGGL(k_gather<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (int*)h->gather_tmp, a, idx, np);
+    HIPCHK(hipMemcpyAsync(a, h->gather_tmp, (size_t)np * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+  }
+  u64* uarr[] = {h->P.mlo, h->P.mhi};
+  for (u64* a : uarr) {
+    hipLaunchKernelGGL(k_gather<u64>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (u64*)h->gather_tmp, a, idx, np);
+    HIPCHK(hipMemcpyAsync(a, h->gather_tmp, (size_t)np * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+  }
+  HIPCHK(hipGetLastError());
+  h->perm_dirty = true;
+  h->steps_since_sort = 0;
+  return 0;
+}
+
+static int refresh_perm(nlps_gpu* h) {
+  if (!h->perm_dirty) return 0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->perm.data(), h->perm_d, (size_t)h->P.np * sizeof(int), hipMemcpyDeviceToHost));
+  h->perm_dirty = false;
+  return 0;
+}
+
+extern "C" int nlps_gpu_resort(nlps_gpu* h) { return resort(h); }
+extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
+  h->resort_every = every_n_steps;
   return 0;
 }
 
@@ -1332,7 +1446,8 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d};
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->gather_tmp, h->cub_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -1356,6 +1471,7 @@ static int download_field(nlps_gpu* h, int f, int ncomp, double* dst, int stride
 
 extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (refresh_perm(h)) return 1;
   int ND = h->nd, T = h->T, np = h->P.np;
   std::vector<double> tmp(h->P.npad);
   if (download_field(h, F_X, ND, o->x_GC, ND, tmp)) return 1;
@@ -1390,6 +1506,7 @@ extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
 
 extern "C" int nlps_gpu_download_lists(nlps_gpu* h, int* nn_out, int* list) {
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (refresh_perm(h)) return 1;
   int np = h->P.np, ND = h->nd;
   std::vector<int> I0(np);
   std::vector<u64> lo(np), hi(np);
@@ -1709,6 +1826,10 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
                                       const double* gravity) {
   int ND = h->nd, nn = h->g.nnodes;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
+  if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
+    if (resort(h)) return 1;
+  }
+  h->steps_since_sort++;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   HIPCHK(hipMemsetAsync(h->N.nm, 0, (size_t)nn * (1 + ND) * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)nn * ND * sizeof(double), h->stream));

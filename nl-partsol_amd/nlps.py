@@ -63,7 +63,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_touched_layers", "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
+           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
 
 
 def lib():
@@ -85,7 +85,8 @@ def lib():
         L.nlps_gpu_last_error.argtypes = [C.c_void_p]
         L.nlps_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Grid), C.POINTER(Params),
                                       C.POINTER(Material), C.c_int, C.POINTER(Particles), C.c_int, C.c_void_p]
-        for name in ["nlps_gpu_destroy", "nlps_gpu_synchronize", "nlps_gpu_initialize_lme",
+        L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
+        for name in ["nlps_gpu_destroy", "nlps_gpu_synchronize", "nlps_gpu_initialize_lme", "nlps_gpu_resort",
                      "nlps_gpu_local_search", "nlps_gpu_constitutive", "nlps_gpu_roll_state"]:
             getattr(L, name).argtypes = [C.c_void_p]
         L.nlps_gpu_download_state.argtypes = [C.c_void_p, C.POINTER(Particles)]
@@ -352,6 +353,12 @@ class Solver:
 
         self._halo_cb = HALO_FN(_cb)
         self._chk(self.L.nlps_gpu_set_halo_exchange(self.h, self._halo_cb, None))
+
+    def resort(self):
+        self._chk(self.L.nlps_gpu_resort(self.h))
+
+    def set_resort_interval(self, n):
+        self._chk(self.L.nlps_gpu_set_resort_interval(self.h, int(n)))
 
     def touched_layers(self):
         lo, hi = C.c_int(0), C.c_int(0)
