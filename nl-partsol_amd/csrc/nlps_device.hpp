@@ -48,10 +48,7 @@ struct ParamsD {
 
 #define NLPS_TOL_NR 10E-6  // Macros.h:40
 
-// The 5 stencil planes are unrolled (static register names, no indirect addressing) but fenced: the
-// scheduler may not interleave two planes, which keeps the live ranges (hoisted LDS reads, partial
-// sums) of one plane only and the VGPR count far below the 256 cap.
-#define NLPS_PLANE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// tunables of the row/plane loops (measured at 1 M particles)
 #ifndef NLPS_JUNROLL_MOMENTS
 #define NLPS_JUNROLL_MOMENTS 5  // rows per iteration of the moments row loop (1 = real loop, 5 = unrolled)
 #endif
@@ -70,9 +67,6 @@ struct ParamsD {
 #ifndef NLPS_K3_WAVES
 #define NLPS_K3_WAVES 1
 #endif
-// compiler-level memory fence between stencil rows: LDS reads of later rows may not be hoisted above
-// it, so at most one row of window reads is in flight per lane (bounded live ranges, no spills)
-#define NLPS_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }  // Macros.h:49-50
 
@@ -526,71 +520,11 @@ struct Lme {
   }
 };
 
-// Visit every member of the neighbourhood: f(bit, i, j, k, e) with e the UNNORMALISED weight
-// Ex(i)Ey(j)Ez(k).  Fully unrolled so ex/ey/ez/lx/... stay in named registers.
-template <int ND, class F>
-__device__ __forceinline__ void for_each_nb(const Lme<ND>& c, F&& f) {
-#pragma unroll
-  for (int k = 0; k < Lme<ND>::KN; k++) {
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      double eyz = (ND == 3) ? c.ey[j] * c.ez[k] : c.ey[j];
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        int b = i + 5 * j + 25 * k;
-        if (c.on(b)) f(b, i, j, k, c.ex[i] * eyz);
-      }
-    }
-  }
-}
-
-// Z, r = sum p l, J = sum p l(x)l - r(x)r at the current factors (LME.c:766-832).  Jm = full ND x ND.
-template <int ND>
-__device__ __forceinline__ void lme_moments(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
-  double Z = 0.0, s[ND], q[ND * ND];
-#pragma unroll
-  for (int a = 0; a < ND; a++) s[a] = 0.0;
-#pragma unroll
-  for (int a = 0; a < ND * ND; a++) q[a] = 0.0;
-  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-    double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
-    Z += e;
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      double el = e * l[a];
-      s[a] += el;
-#pragma unroll
-      for (int b2 = a; b2 < ND; b2++) q[a * ND + b2] += el * l[b2];
-    }
-  });
-  Zinv = 1.0 / Z;
-#pragma unroll
-  for (int a = 0; a < ND; a++) r[a] = s[a] * Zinv;
-#pragma unroll
-  for (int a = 0; a < ND; a++)
-#pragma unroll
-    for (int b2 = a; b2 < ND; b2++) {
-      double v = q[a * ND + b2] * Zinv - r[a] * r[b2];
-      Jm[a * ND + b2] = v;
-      Jm[b2 * ND + a] = v;
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Hierarchical (row -> plane -> total) evaluation.  The weights are separable, only the membership
 // mask is not: the innermost loop over i touches three masked adds per member, everything that does
 // not depend on i is applied once per (j,k) row, everything that only depends on k once per plane.
 // ------------------------------------------------------------------------------------------------
-
-// 5 membership bits of row (j,k): bits [5(j+5k), 5(j+5k)+5) of the 125-bit mask
-template <int ND>
-__device__ __forceinline__ unsigned row_bits(const Lme<ND>& c, int j, int k) {
-  const int s = 5 * (j + 5 * k);
-  if (s + 5 <= 64) return (unsigned)(c.mlo >> s) & 31u;
-  if (s >= 64) return (unsigned)(c.mhi >> (s - 64)) & 31u;
-  return (unsigned)((c.mlo >> s) | (c.mhi << (64 - s))) & 31u;
-}
 
 // 25 membership bits of plane k (k may be a run-time, wave-uniform loop counter)
 template <int ND>
@@ -601,22 +535,6 @@ __device__ __forceinline__ unsigned plane_bits(const Lme<ND>& c, int k) {
   else if (s < 64) v = (c.mlo >> s) | (c.mhi << (64 - s));
   else v = c.mhi >> (s - 64);
   return (unsigned)v & 0x1FFFFFFu;
-}
-
-// a[k] for a wave-uniform run-time k without indirect register addressing
-__device__ __forceinline__ double sel5(const double* a, int k) {
-  double v = a[0];
-  v = (k == 1) ? a[1] : v;
-  v = (k == 2) ? a[2] : v;
-  v = (k == 3) ? a[3] : v;
-  v = (k == 4) ? a[4] : v;
-  return v;
-}
-
-template <int ND>
-__device__ __forceinline__ double sel5z(const double* a, int k) {  // a has Lme<ND>::KN entries
-  if (ND == 3) return sel5(a, k);
-  return a[0];
 }
 
 // y/z factors and offsets as plain LOCAL arrays (not struct members: only those are promoted to
@@ -630,18 +548,6 @@ __device__ __forceinline__ double sel5z(const double* a, int k) {  // a has Lme<
     ez5[i_] = (ND == 3) ? (c).ez[i_ % Lme<ND>::KN] : 1.0;         \
     lz5[i_] = (ND == 3) ? (c).lz[i_ % Lme<ND>::KN] : 0.0;         \
   }
-
-template <int ND>
-struct LmeX {  // x-axis helpers: ex*lx (per evaluation) and lx^2 (geometry)
-  double x1[5], x2[5];
-  __device__ __forceinline__ void prep(const Lme<ND>& c) {
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      x1[i] = c.ex[i] * c.lx[i];
-      x2[i] = c.lx[i] * c.lx[i];
-    }
-  }
-};
 
 // Z^-1, r = sum p l, J = sum p l(x)l - r(x)r  (LME.c:766-832) by rows and planes
 template <int ND>

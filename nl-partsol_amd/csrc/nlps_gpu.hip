@@ -270,11 +270,6 @@ __global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N, Tile
   bin_particle<ND>(P, g, tc, p, bestnode, valid);
 }
 
-// ------------------------------------------------------------------------------------------------
-// S1b (+S2): neighbour mask (tributary__LME__, LME.c:1019-1099), beta (LME.c:995-996), Newton for
-// lambda (LME.c:272-353); optionally the explicit predictor (U-Verlet.c:229-253) and the P2G scatter
-// of mass and m*dD (U-Verlet.c:160-223, 301-367 == U-Newmark-beta.c:528-597)
-// ------------------------------------------------------------------------------------------------
 template <int ND>
 __device__ __forceinline__ bool load_lme(const PView& P, const GridD& g, int p, Lme<ND>& c, double* lam, double& beta) {
   double x[ND];
@@ -289,151 +284,6 @@ __device__ __forceinline__ bool load_lme(const PView& P, const GridD& g, int p, 
   c.mhi = P.mhi[p];
   c.factors(lam, beta, g.h);
   return (c.mlo | c.mhi) != 0ull;
-}
-
-template <int ND, bool P2G>
-__global__ __launch_bounds__(BLK) void k_lists_newton(PView P, GridD g, NView N, ParamsD prm, double dt,
-                                                      double gamma_nm, int* __restrict__ gstatus) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  Lme<ND> c;
-  double x[ND], lam[ND];
-#pragma unroll
-  for (int a = 0; a < ND; a++) {
-    x[a] = PF(P, F_X + a, p);
-    lam[a] = PF(P, F_LAM + a, p);
-  }
-  int I0 = P.I0[p];
-  c.geom(g, x, I0);
-  double beta_prev = PF(P, F_BETA, p);
-  double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052 (beta = 0 at init => +inf)
-  u64 mlo = 0ull, mhi = 0ull;
-#pragma unroll
-  for (int k = 0; k < Lme<ND>::KN; k++)
-#pragma unroll
-    for (int j = 0; j < 5; j++)
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        int gi = c.ijk[0] + i - 2, gj = c.ijk[1] + j - 2, gk = (ND == 3) ? c.ijk[2] + k - 2 : 0;
-        bool ok = gi >= 0 && gi < g.n[0] && gj >= 0 && gj < g.n[1] && (ND == 2 || (gk >= 0 && gk < g.n[2]));
-        if (ok) {
-          int node = gi + g.n[0] * (gj + g.n[1] * gk);
-          double sq = 0.0;
-          sq += c.lx[i] * c.lx[i];
-          sq += c.ly[j] * c.ly[j];
-          if (ND == 3) sq += c.lz[k % Lme<ND>::KN] * c.lz[k % Lme<ND>::KN];
-          ok = N.active[node] && (sqrt(sq) <= Ra);
-        }
-        int b = i + 5 * j + 25 * k;
-        if (ok) {
-          if (b < 64) mlo |= (1ull << b);
-          else mhi |= (1ull << (b - 64));
-        }
-      }
-  c.mlo = mlo;
-  c.mhi = mhi;
-  int nn = __popcll(mlo) + __popcll(mhi);
-  int st = 0;
-  if (nn < ND + 1) {  // LME.c:1087-1092
-    P.nn[p] = 0;
-    P.mlo[p] = 0ull;
-    P.mhi[p] = 0ull;
-    atomicOr(&P.status[p], ST_CONNECT);
-    atomicOr(gstatus, ST_CONNECT);
-    return;
-  }
-  double hv = N.h_avg[I0];
-  double beta = prm.gamma_lme / (hv * hv);  // beta__LME__, LME.c:177-185
-
-  int NumIter = 0;
-  double Zinv = 0.0;
-  while (NumIter <= prm.max_iter_lme) {
-    double r[ND], J[ND * ND], Jm1[ND * ND];
-    c.factors(lam, beta, g.h);
-    lme_moments<ND>(c, Zinv, r, J);
-    double aux = 0.0;
-#pragma unroll
-    for (int a = 0; a < ND; a++) aux += dsqr(r[a]);
-    if (sqrt(aux) > prm.tol_wrapper) {
-      if (rcond_ref<ND>(J) < 1E-8 || !inverse<ND>(Jm1, J)) {
-        st |= ST_NEWTON;
-        break;
-      }
-#pragma unroll
-      for (int a = 0; a < ND; a++) {
-        double dl = 0.0;
-#pragma unroll
-        for (int b2 = 0; b2 < ND; b2++) dl += Jm1[a * ND + b2] * r[b2];
-        lam[a] -= dl;
-      }
-      NumIter++;
-    } else {
-      break;
-    }
-  }
-  if (NumIter >= prm.max_iter_lme) st |= ST_NEWTON;
-
-  P.nn[p] = nn;
-  P.mlo[p] = mlo;
-  P.mhi[p] = mhi;
-  PF(P, F_BETA, p) = beta;
-#pragma unroll
-  for (int a = 0; a < ND; a++) PF(P, F_LAM + a, p) = lam[a];
-  if (st) {
-    atomicOr(&P.status[p], st);
-    atomicOr(gstatus, st);
-  }
-
-  if (P2G) {
-    double m = PF(P, F_MASS, p);
-    double dd[ND];
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      double v = PF(P, F_VEL + a, p), ac = PF(P, F_ACC + a, p);
-      dd[a] = dt * v + 0.5 * dsqr(dt) * ac;
-      PF(P, F_DDIS + a, p) = dd[a];
-      PF(P, F_VEL + a, p) = v + (1 - gamma_nm) * dt * ac;
-    }
-    double mz = m * Zinv;
-    for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-      int node = I0 + c.node_offset(g, i, j, k);
-      double w = mz * e;
-      double* dst = N.nm + (size_t)node * (1 + ND);
-      atomic_add_f64(dst, w);
-#pragma unroll
-      for (int a = 0; a < ND; a++) atomic_add_f64(dst + 1 + a, w * dd[a]);
-    });
-  }
-}
-
-// generic P2G of m*N*{1 | vel,acc}: __compute_nodal_lumped_mass (U-Newmark-beta.c:528-597) and the
-// accumulation loop of __get_nodal_field_n (:615-696).  out = [nnodes][NF]
-template <int ND, int MODE>  // MODE 0: mass (NF=1)   1: vel & acc (NF = 2*ND)
-__global__ __launch_bounds__(BLK) void k_p2g(PView P, GridD g, double* __restrict__ out) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  Lme<ND> c;
-  double lam[ND], beta;
-  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
-  constexpr int NF = MODE == 0 ? 1 : 2 * ND;
-  double vals[NF];
-  if (MODE == 0) vals[0] = 1.0;
-  else {
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      vals[a] = PF(P, F_VEL + a, p);
-      vals[ND + a] = PF(P, F_ACC + a, p);
-    }
-  }
-  double Z = 0.0;
-  for_each_nb<ND>(c, [&](int, int, int, int, double e) { Z += e; });
-  double mz = PF(P, F_MASS, p) * (1.0 / Z);
-  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-    int node = c.I0 + c.node_offset(g, i, j, k);
-    double w = mz * e;
-#pragma unroll
-    for (int f = 0; f < NF; f++) atomic_add_f64(out + (size_t)node * NF + f, w * vals[f]);
-  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -514,113 +364,6 @@ __device__ __forceinline__ bool force_operator(double* B, const double* tau, con
   return true;
 }
 
-template <int ND>
-__device__ __forceinline__ void scatter_force(const Lme<ND>& c, const GridD& g, double Zinv, const double* B,
-                                              double* __restrict__ force) {
-  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-    int node = c.I0 + c.node_offset(g, i, j, k);
-    double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
-    double pa = e * Zinv;
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      double s = 0.0;
-#pragma unroll
-      for (int m = 0; m < ND; m++) s += B[a * ND + m] * l[m];
-      atomic_add_f64(force + (size_t)node * ND + a, pa * s);
-    }
-  });
-}
-
-// MODE 0: compatibility only (level B)   1: explicit fused (compat + density + stress + force scatter)
-template <int ND, int MODE>
-__global__ __launch_bounds__(BLK) void k_g2p_grad(PView P, GridD g, const double* __restrict__ dU,
-                                                  double* __restrict__ force, const MatD* __restrict__ mats,
-                                                  ParamsD prm, int* __restrict__ gstatus) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  Lme<ND> c;
-  double lam[ND], beta;
-  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
-  double Z = 0.0, s[ND], q[ND * ND], G[ND * ND];
-#pragma unroll
-  for (int a = 0; a < ND; a++) s[a] = 0.0;
-#pragma unroll
-  for (int a = 0; a < ND * ND; a++) {
-    q[a] = 0.0;
-    G[a] = 0.0;
-  }
-  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-    int node = c.I0 + c.node_offset(g, i, j, k);
-    double l[3] = {c.lx[i], c.ly[j], ND == 3 ? c.lz[k % Lme<ND>::KN] : 0.0};
-    double u[ND];
-#pragma unroll
-    for (int a = 0; a < ND; a++) u[a] = dU[(size_t)node * ND + a];
-    Z += e;
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      double el = e * l[a];
-      s[a] += el;
-#pragma unroll
-      for (int b2 = a; b2 < ND; b2++) q[a * ND + b2] += el * l[b2];
-#pragma unroll
-      for (int b2 = 0; b2 < ND; b2++) G[b2 * ND + a] += el * u[b2];  // G[i][m] = sum p dU_i l_m
-    }
-  });
-  double Zinv = 1.0 / Z, r[ND], J[ND * ND], Jm1[ND * ND];
-#pragma unroll
-  for (int a = 0; a < ND; a++) r[a] = s[a] * Zinv;
-#pragma unroll
-  for (int a = 0; a < ND; a++)
-#pragma unroll
-    for (int b2 = a; b2 < ND; b2++) {
-      double v = q[a * ND + b2] * Zinv - r[a] * r[b2];
-      J[a * ND + b2] = v;
-      J[b2 * ND + a] = v;
-    }
-  int st = 0;
-  if (!inverse<ND>(Jm1, J)) st |= ST_NEWTON;
-  // DF = I + sum_A dU_A (x) grad N_A = I - (G/Z) J^-T           (compute-Strains.c:20-44)
-  double DF[ND * ND], Fn[ND * ND], Fn1[ND * ND], fzz;
-#pragma unroll
-  for (int i = 0; i < ND; i++)
-#pragma unroll
-    for (int j = 0; j < ND; j++) {
-      double v = 0.0;
-#pragma unroll
-      for (int m = 0; m < ND; m++) v += (G[i * ND + m] * Zinv) * Jm1[j * ND + m];
-      DF[i * ND + j] = ((i == j) ? 1.0 : 0.0) - v;
-    }
-  load_block<ND>(P, F_FN, p, Fn, fzz);
-#pragma unroll
-  for (int i = 0; i < ND; i++)  // update_Deformation_Gradient_n1__Particles__, compute-Strains.c:76-105
-#pragma unroll
-    for (int j = 0; j < ND; j++) {
-      double a2 = 0.0;
-#pragma unroll
-      for (int k2 = 0; k2 < ND; k2++) a2 += DF[i * ND + k2] * Fn[k2 * ND + j];
-      Fn1[i * ND + j] = a2;
-    }
-  double Jn1 = det<ND>(Fn1);
-  if (Jn1 <= 0.0) {
-    st |= ST_JACOBIAN;
-    if (MODE == 0) Jn1 = 0.0;  // implicit path clamps (U-Newmark-beta.c:1137-1142); explicit path fails (U-Verlet.c:608-613)
-  }
-  store_block<ND>(P, F_DF, p, DF, 0.0, false);
-  store_block<ND>(P, F_FN1, p, Fn1, 0.0, false);
-  PF(P, F_JN1, p) = Jn1;
-  if (MODE == 1) {
-    PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
-    double tau[ND * ND], B[ND * ND];
-    st |= stress_update<ND>(P, p, mats, prm, Fn1, DF, Jn1, tau);
-    if (force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0)) scatter_force<ND>(c, g, Zinv, B, force);
-    else st |= ST_JACOBIAN;
-  }
-  if (st) {
-    atomicOr(&P.status[p], st);
-    atomicOr(gstatus, st);
-  }
-}
-
 // __constitutive_update (U-Newmark-beta.c:1208-1242)
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict__ mats, ParamsD prm,
@@ -634,106 +377,6 @@ __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict_
   if (st) {
     atomicOr(&P.status[p], st);
     atomicOr(gstatus, st);
-  }
-}
-
-// __nodal_internal_forces (U-Newmark-beta.c:1257-1374): +V0 tau (DF^-T grad N) into force[nnodes][ND]
-template <int ND>
-__global__ __launch_bounds__(BLK) void k_fint(PView P, GridD g, double* __restrict__ force, int* __restrict__ gstatus) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  Lme<ND> c;
-  double lam[ND], beta;
-  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
-  double Zinv, r[ND], J[ND * ND], Jm1[ND * ND], tau[ND * ND], DF[ND * ND], B[ND * ND], z;
-  lme_moments<ND>(c, Zinv, r, J);
-  load_block<ND>(P, F_TAU, p, tau, z);
-  load_block<ND>(P, F_DF, p, DF, z);
-  if (inverse<ND>(Jm1, J) && force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), 1.0)) {
-    scatter_force<ND>(c, g, Zinv, B, force);
-  } else {
-    atomicOr(&P.status[p], ST_JACOBIAN);
-    atomicOr(gstatus, ST_JACOBIAN);
-  }
-}
-
-// S5 explicit: G2P of nodal acceleration and dU (U-Verlet.c:962-1010), corrector + roll (:1024-1084)
-template <int ND>
-__global__ __launch_bounds__(BLK) void k_g2p_update(PView P, GridD g, const double* __restrict__ accel,
-                                                    const double* __restrict__ dU, double dt, double gamma_nm) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  Lme<ND> c;
-  double lam[ND], beta;
-  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
-  double Z = 0.0, sa[ND], su[ND];
-#pragma unroll
-  for (int a = 0; a < ND; a++) {
-    sa[a] = 0.0;
-    su[a] = 0.0;
-  }
-  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-    int node = c.I0 + c.node_offset(g, i, j, k);
-    Z += e;
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      sa[a] += e * accel[(size_t)node * ND + a];
-      su[a] += e * dU[(size_t)node * ND + a];
-    }
-  });
-  double Zinv = 1.0 / Z;
-#pragma unroll
-  for (int a = 0; a < ND; a++) {
-    double ac = sa[a] * Zinv, dd = su[a] * Zinv;
-    PF(P, F_ACC + a, p) = ac;
-    PF(P, F_DDIS + a, p) = dd;
-    PF(P, F_VEL + a, p) = PF(P, F_VEL + a, p) + gamma_nm * dt * ac;
-    PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
-    PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
-  }
-  PF(P, F_JN, p) = PF(P, F_JN1, p);
-  PF(P, F_KN, p) = PF(P, F_KN1, p);
-  PF(P, F_EN, p) = PF(P, F_EN1, p);
-  constexpr int T = (ND == 2) ? 5 : 9;
-#pragma unroll
-  for (int s2 = 0; s2 < T; s2++) {
-    PF(P, F_BEN + s2, p) = PF(P, F_BEN1 + s2, p);
-    PF(P, F_FN + s2, p) = PF(P, F_FN1 + s2, p);
-  }
-}
-
-// __update_particles_kinetics_FLIP_PIC (U-Newmark-beta.c:1993-2072): 4 nodal arrays [nnodes][ND]
-template <int ND>
-__global__ __launch_bounds__(BLK) void k_kinetics(PView P, GridD g, double alpha_blend, const double* __restrict__ dU,
-                                                  const double* __restrict__ Un_dt, const double* __restrict__ dU_dt,
-                                                  const double* __restrict__ dU_dt2) {
-  int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= P.np) return;
-  Lme<ND> c;
-  double lam[ND], beta;
-  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
-  double Z = 0.0, s0[ND], s1[ND], s2[ND], s3[ND];
-#pragma unroll
-  for (int a = 0; a < ND; a++) s0[a] = s1[a] = s2[a] = s3[a] = 0.0;
-  for_each_nb<ND>(c, [&](int, int i, int j, int k, double e) {
-    size_t o = (size_t)(c.I0 + c.node_offset(g, i, j, k)) * ND;
-    Z += e;
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      s0[a] += e * dU[o + a];
-      s1[a] += e * Un_dt[o + a];
-      s2[a] += e * dU_dt[o + a];
-      s3[a] += e * dU_dt2[o + a];
-    }
-  });
-  double Zinv = 1.0 / Z, beta_blend = 1 - alpha_blend;
-#pragma unroll
-  for (int a = 0; a < ND; a++) {
-    double du = s0[a] * Zinv;
-    PF(P, F_ACC + a, p) = PF(P, F_ACC + a, p) + s3[a] * Zinv;
-    PF(P, F_VEL + a, p) = alpha_blend * PF(P, F_VEL + a, p) + (s2[a] * Zinv + beta_blend * (s1[a] * Zinv));
-    PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + du;
-    PF(P, F_X + a, p) = PF(P, F_X + a, p) + du;
   }
 }
 
@@ -976,6 +619,7 @@ struct nlps_gpu {
   int* gstatus_d;
   int nactive, nfree;
   bool masks_valid;
+  bool binned;  // order[] / tile tables describe the current I0s
 
   // scratch nodal arrays
   double* gridA;  // [nnodes][2*ND] general purpose
@@ -1183,6 +827,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->halo_ctx = nullptr;
   h->timing = false;
   h->masks_valid = false;
+  h->binned = false;
   h->maskedA = nullptr;
   h->maskedA_cap = 0;
   h->perm_d = nullptr;
@@ -1422,6 +1067,7 @@ static int resort(nlps_gpu* h) {
   }
   HIPCHK(hipGetLastError());
   h->perm_dirty = true;
+  h->binned = false;
   h->steps_since_sort = 0;
   return 0;
 }
@@ -1595,31 +1241,30 @@ static TileD tile_view(nlps_gpu* h) {
 // beta and the Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`, tiled form only)
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm) {
   int np = h->P.np;
-  bool tiled = p2g;
   HIPCHK(hipMemsetAsync(h->N.active, 0, (size_t)h->g.nnodes, h->stream));  // Shape-Functions.c:38-46
-  if (tiled) HIPCHK(hipMemsetAsync(h->tile_count_d, 0, ((size_t)h->ntiles + 1) * sizeof(int), h->stream));
-  TileCnt tc = tile_cnt(h, tiled);
+  HIPCHK(hipMemsetAsync(h->tile_count_d, 0, ((size_t)h->ntiles + 1) * sizeof(int), h->stream));
+  TileCnt tc = tile_cnt(h, true);
   if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
   else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
   HIPCHK(hipGetLastError());
-  if (tiled) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d, h->tile_start_d, h->ntiles);
-    hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank,
-                       h->tile_start_d, h->order_d);
-    HIPCHK(hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d, h->tile_start_d, h->ntiles);
+  hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
+                     h->order_d);
+  HIPCHK(hipGetLastError());
   if (halo(h, h->N.active, 1, 1, 1)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  if (tiled) {
-    TileD td = tile_view(h);
-    if (h->nd == 2) hipLaunchKernelGGL(k2_tile<2>, dim3(h->ntiles * K2_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
-    else hipLaunchKernelGGL(k2_tile<3>, dim3(h->ntiles * K2_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+  TileD td = tile_view(h);
+  const dim3 grid(h->ntiles * K2_SPLIT), blk(BLK);
+  if (h->nd == 2) {
+    if (p2g) hipLaunchKernelGGL((k2_tile<2, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    else hipLaunchKernelGGL((k2_tile<2, false>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
   } else {
-    LAUNCH_ND((k_lists_newton<2, false>), (k_lists_newton<3, false>), nblk(np), h->P, h->g, h->N, h->prm, dt,
-              gamma_nm, h->gstatus_d);
+    if (p2g) hipLaunchKernelGGL((k2_tile<3, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    else hipLaunchKernelGGL((k2_tile<3, false>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
   }
   HIPCHK(hipGetLastError());
   h->masks_valid = false;
+  h->binned = true;
   return 0;
 }
 
@@ -1748,7 +1393,14 @@ static int from_grid(nlps_gpu* h, double* masked, const double* grid, int nf, in
   return 0;
 }
 
+static int need_binning(nlps_gpu* h, const char* who) {
+  if (h->binned) return 0;
+  h->err = std::string(who) + ": call nlps_gpu_local_search() first (particles are not binned to tiles)";
+  return 1;
+}
+
 static int need_masks(nlps_gpu* h, const char* who) {
+  if (need_binning(h, who)) return 1;
   if (h->masks_valid) return 0;
   h->err = std::string(who) + ": call nlps_gpu_active_masks() after the local search first";
   return 1;
@@ -1758,7 +1410,11 @@ extern "C" int nlps_gpu_lumped_mass(nlps_gpu* h, double* M) {
   if (need_masks(h, "nlps_gpu_lumped_mass")) return 1;
   int ND = h->nd;
   HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * sizeof(double), h->stream));
-  LAUNCH_ND((k_p2g<2, 0>), (k_p2g<3, 0>), nblk(h->P.np), h->P, h->g, h->gridA);
+  {
+    TileD td = tile_view(h);
+    if (ND == 2) hipLaunchKernelGGL((kb_p2g_tile<2, 0>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+    else hipLaunchKernelGGL((kb_p2g_tile<3, 0>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+  }
   HIPCHK(hipGetLastError());
   if (halo(h, h->gridA, 1, 8, 0)) return 1;
   return from_grid(h, M, h->gridA, ND, 1, 0, 1, 0, nullptr);
@@ -1768,7 +1424,11 @@ extern "C" int nlps_gpu_nodal_field_n(nlps_gpu* h, double* V, double* A, const d
   if (need_masks(h, "nlps_gpu_nodal_field_n")) return 1;
   int ND = h->nd;
   HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * 2 * ND * sizeof(double), h->stream));
-  LAUNCH_ND((k_p2g<2, 1>), (k_p2g<3, 1>), nblk(h->P.np), h->P, h->g, h->gridA);
+  {
+    TileD td = tile_view(h);
+    if (ND == 2) hipLaunchKernelGGL((kb_p2g_tile<2, 1>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+    else hipLaunchKernelGGL((kb_p2g_tile<3, 1>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+  }
   HIPCHK(hipGetLastError());
   if (halo(h, h->gridA, 2 * ND, 8, 0)) return 1;
   if (from_grid(h, V, h->gridA, ND, 2 * ND, 0, 0, 2, M)) return 1;
@@ -1779,8 +1439,11 @@ extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const doubl
   (void)dU_dt;  // rate tensors: consumed only by the out-of-scope Newtonian-fluid law (Constitutive.c:84-108)
   if (need_masks(h, "nlps_gpu_compatibility")) return 1;
   if (to_grid(h, h->N.dU, dU, h->nd)) return 1;
-  LAUNCH_ND((k_g2p_grad<2, 0>), (k_g2p_grad<3, 0>), nblk(h->P.np), h->P, h->g, h->N.dU, (double*)nullptr, h->mats_d,
-            h->prm, h->gstatus_d);
+  {
+    TileD td = tile_view(h);
+    if (h->nd == 2) hipLaunchKernelGGL((k3_tile<2, 0, 0>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
+    else hipLaunchKernelGGL((k3_tile<3, 0, 0>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1795,7 +1458,11 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
   if (need_masks(h, "nlps_gpu_internal_forces")) return 1;
   int ND = h->nd;
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
-  LAUNCH_ND((k_fint<2>), (k_fint<3>), nblk(h->P.np), h->P, h->g, h->N.force, h->gstatus_d);
+  {
+    TileD td = tile_view(h);
+    if (ND == 2) hipLaunchKernelGGL(kb_fint_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->N.force, h->gstatus_d);
+    else hipLaunchKernelGGL(kb_fint_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->N.force, h->gstatus_d);
+  }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.force, ND, 8, 0)) return 1;
   return from_grid(h, R, h->N.force, ND, ND, 0, 0, 1, nullptr);
@@ -1816,8 +1483,11 @@ extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const d
   if (to_grid(h, h->gridB + st, Un_dt, ND)) return 1;
   if (to_grid(h, h->gridB + 2 * st, dU_dt, ND)) return 1;
   if (to_grid(h, h->gridB + 3 * st, dU_dt2, ND)) return 1;
-  LAUNCH_ND((k_kinetics<2>), (k_kinetics<3>), nblk(h->P.np), h->P, h->g, alpha_blend, h->gridB, h->gridB + st,
-            h->gridB + 2 * st, h->gridB + 3 * st);
+  {
+    TileD td = tile_view(h);
+    if (ND == 2) hipLaunchKernelGGL(kb_kinetics_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
+    else hipLaunchKernelGGL(kb_kinetics_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1859,7 +1529,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   {
     TileD td = tile_view(h);
 #define NLPS_K3(NDv, LAWv)                                                                                      \
-  hipLaunchKernelGGL((k3_tile<NDv, LAWv>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d)
     const int law = h->uniform_law;
     if (ND == 2) {

@@ -142,7 +142,7 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 // ------------------------------------------------------------------------------------------------
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
-template <int ND>
+template <int ND, bool P2G>
 __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
@@ -155,10 +155,11 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int r = threadIdx.x; r < NROWS; r += BLK) actrow[r] = 0u;
-  for (int idx = threadIdx.x; idx < NW; idx += BLK) {
+  if (P2G)
+    for (int idx = threadIdx.x; idx < NW; idx += BLK) {
 #pragma unroll
-    for (int f = 0; f < NF; f++) acc[f * NW + idx] = 0.0;
-  }
+      for (int f = 0; f < NF; f++) acc[f * NW + idx] = 0.0;
+    }
   __syncthreads();
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
     bool in;
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
       atomicOr(&P.status[p], st);
       atomicOr(gstatus, st);
     }
+    if (!P2G) continue;  // local_search__LME__ alone stops here (LME.c:895-1015)
     double dd[ND];
 #pragma unroll
     for (int a = 0; a < ND; a++) {
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
       }
     }
   }
+  if (!P2G) return;
   __syncthreads();
   for (int q = threadIdx.x; q < NW * NF; q += BLK) {
     int f = q % NF, idx = q / NF;
@@ -309,7 +312,9 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
 // ------------------------------------------------------------------------------------------------
 // K3: G2P grad(dU) -> DF, F, J, density; stress; P2G of -f_int            (S3 + S4)
 // ------------------------------------------------------------------------------------------------
-template <int ND, int LAW>
+// MODE 1: fused explicit stage (S3+S4).  MODE 0: __local_compatibility_conditions only (level B):
+// DF, F_n1, J_n1 with the implicit driver's clamp of J <= 0 (U-Newmark-beta.c:1137-1142).
+template <int ND, int LAW, int MODE>
 __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
@@ -465,11 +470,21 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
         for (int k2 = 0; k2 < ND; k2++) a2 += DF[i * ND + k2] * Fn[k2 * ND + j];
         Fn1[i * ND + j] = a2;
       }
-    const double Jn1 = det<ND>(Fn1);
-    if (Jn1 <= 0.0) st |= ST_JACOBIAN;  // fatal in the explicit scheme, U-Verlet.c:608-613
+    double Jn1 = det<ND>(Fn1);
+    if (Jn1 <= 0.0) {
+      st |= ST_JACOBIAN;  // fatal in the explicit scheme (U-Verlet.c:608-613), clamped in the implicit one
+      if (MODE == 0) Jn1 = 0.0;
+    }
     store_block<ND>(P, F_DF, p, DF, 0.0, false);
     store_block<ND>(P, F_FN1, p, Fn1, 0.0, false);
     PF(P, F_JN1, p) = Jn1;
+    if (MODE == 0) {
+      if (st) {
+        atomicOr(&P.status[p], st);
+        atomicOr(gstatus, st);
+      }
+      continue;
+    }
     PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
     double tau[ND * ND], B[ND * ND];
     st |= stress_update<ND, LAW>(P, p, mats, prm, Fn1, DF, Jn1, tau);
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
       atomicOr(gstatus, st);
     }
   }
+  if (MODE == 0) return;
   __syncthreads();
   for (int qq = threadIdx.x; qq < NW * ND; qq += BLK) {
     int f = qq % ND, idx = qq / ND;
@@ -607,6 +623,250 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
       PF(P, F_EN, p) = PF(P, F_EN1, p);
 #pragma unroll
       for (int s2 = 0; s2 < T; s2++) PF(P, F_BEN + s2, p) = PF(P, F_BEN1 + s2, p);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level-B stage kernels in tile form (the implicit driver's stage functions)
+// ------------------------------------------------------------------------------------------------
+
+// Z^-1 alone (rows of masked ex, then ey, ez)
+template <int ND>
+__device__ __forceinline__ double lme_zinv(const Lme<ND>& c) {
+  NLPS_YZ_LOCALS(c);
+  (void)ly5;
+  (void)lz5;
+  double Z = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < Lme<ND>::KN; k++) {
+    const unsigned pb = plane_bits<ND>(c, k);
+    double P0 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const unsigned bits = (pb >> (5 * j)) & 31u;
+      double A0 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; i++) A0 += ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+      P0 = fma(ey5[j], A0, P0);
+    }
+    Z = fma(ez5[k], P0, Z);
+  }
+  return 1.0 / Z;
+}
+
+// __compute_nodal_lumped_mass (MODE 0, NF = 1) and the accumulation of __get_nodal_field_n
+// (MODE 1, NF = 2d: m N v, m N a) into out[nnodes][NF]        (U-Newmark-beta.c:528-597, 615-696)
+template <int ND, int MODE>
+__global__ __launch_bounds__(BLK) void kb_p2g_tile(PView P, GridD g, TileD td, double* __restrict__ out) {
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
+  constexpr int NF = MODE == 0 ? 1 : 2 * ND;
+  __shared__ double acc[NF * NW];
+  const int tile = blockIdx.x;
+  const int cnt = td.count[tile];
+  if (cnt == 0) return;
+  int w0[3];
+  tile_origin<ND>(td, tile, w0);
+  for (int idx = threadIdx.x; idx < NW * NF; idx += BLK) acc[idx] = 0.0;
+  __syncthreads();
+  const int start = td.start[tile];
+  for (int s = threadIdx.x; s < cnt; s += BLK) {
+    const int p = td.order[start + s];
+    Lme<ND> c;
+    double lam[ND], beta;
+    if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
+    const int base = window_base<ND>(c.ijk, w0);
+    double vals[NF];
+    if (MODE == 0) vals[0] = 1.0;
+    else {
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        vals[a % NF] = PF(P, F_VEL + a, p);
+        vals[(ND + a) % NF] = PF(P, F_ACC + a, p);
+      }
+    }
+    const double mz = PF(P, F_MASS, p) * lme_zinv<ND>(c);
+    NLPS_YZ_LOCALS(c);
+    (void)ly5;
+    (void)lz5;
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const unsigned pb = plane_bits<ND>(c, k);
+      const double wz = mz * ez5[k];
+      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const unsigned bits = (pb >> (5 * j)) & 31u;
+        const double w = wz * ey5[j];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+          if ((bits >> i) & 1u) {
+            const int li = basek + (i - 2) + W * (j - 2);
+            const double v0 = w * c.ex[i];
+#pragma unroll
+            for (int f = 0; f < NF; f++) atomicAdd(&acc[f * NW + li], v0 * vals[f]);
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < NW * NF; q += BLK) {
+    int f = q % NF, idx = q / NF;
+    double v = acc[f * NW + idx];
+    if (v != 0.0) {
+      bool in;
+      int node = window_node<ND>(g, w0, idx, in);
+      if (in) atomic_add_f64(out + (size_t)node * NF + f, v);
+    }
+  }
+}
+
+// __nodal_internal_forces (U-Newmark-beta.c:1257-1374): +V0 tau (DF^-T grad N) from the stored tau, DF
+template <int ND>
+__global__ __launch_bounds__(BLK) void kb_fint_tile(PView P, GridD g, TileD td, double* __restrict__ force,
+                                                    int* __restrict__ gstatus) {
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
+  __shared__ double fac[ND * NW];
+  const int tile = blockIdx.x;
+  const int cnt = td.count[tile];
+  if (cnt == 0) return;
+  int w0[3];
+  tile_origin<ND>(td, tile, w0);
+  for (int idx = threadIdx.x; idx < NW * ND; idx += BLK) fac[idx] = 0.0;
+  __syncthreads();
+  const int start = td.start[tile];
+  for (int s = threadIdx.x; s < cnt; s += BLK) {
+    const int p = td.order[start + s];
+    Lme<ND> c;
+    double lam[ND], beta;
+    if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
+    const int base = window_base<ND>(c.ijk, w0);
+    double Zinv, r[ND], J[ND * ND], Jm1[ND * ND], tau[ND * ND], DF[ND * ND], B[ND * ND], z;
+    lme_moments_h<ND>(c, Zinv, r, J);
+    load_block<ND>(P, F_TAU, p, tau, z);
+    load_block<ND>(P, F_DF, p, DF, z);
+    if (!(inverse<ND>(Jm1, J) && force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), 1.0))) {
+      atomicOr(&P.status[p], ST_JACOBIAN);
+      atomicOr(gstatus, ST_JACOBIAN);
+      continue;
+    }
+    NLPS_YZ_LOCALS(c);
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const unsigned pb = plane_bits<ND>(c, k);
+      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
+      const double wz = Zinv * ez5[k];
+      const double lzk = lz5[k];
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const unsigned bits = (pb >> (5 * j)) & 31u;
+        const double w = wz * ey5[j];
+        double cr[ND];
+#pragma unroll
+        for (int a = 0; a < ND; a++)
+          cr[a] = (ND == 3) ? fma(B[a * ND + 1], ly5[j], B[a * ND + (2 % ND)] * lzk) : B[a * ND + 1] * ly5[j];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+          if ((bits >> i) & 1u) {
+            const int li = basek + (i - 2) + W * (j - 2);
+            const double we = w * c.ex[i];
+#pragma unroll
+            for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * fma(B[a * ND + 0], c.lx[i], cr[a]));
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for (int qq = threadIdx.x; qq < NW * ND; qq += BLK) {
+    int f = qq % ND, idx = qq / ND;
+    double v = fac[f * NW + idx];
+    if (v != 0.0) {
+      bool in;
+      int node = window_node<ND>(g, w0, idx, in);
+      if (in) atomic_add_f64(force + (size_t)node * ND + f, v);
+    }
+  }
+}
+
+// __update_particles_kinetics_FLIP_PIC (U-Newmark-beta.c:1993-2072): gathers 4 nodal vectors
+// [nnodes][ND] (dU, Un_dt, dU_dt, dU_dt2) through one AoS window of 4d doubles per node
+template <int ND>
+__global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD td, double alpha_blend,
+                                                        const double* __restrict__ dU, const double* __restrict__ Un_dt,
+                                                        const double* __restrict__ dU_dt,
+                                                        const double* __restrict__ dU_dt2) {
+  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
+  constexpr int NV = 4 * ND, NP = NV / 2;
+  __shared__ __attribute__((aligned(16))) double win[NW * NV];
+  const int tile = blockIdx.x;
+  const int cnt = td.count[tile];
+  if (cnt == 0) return;
+  int w0[3];
+  tile_origin<ND>(td, tile, w0);
+  for (int idx = threadIdx.x; idx < NW; idx += BLK) {
+    bool in;
+    int node = window_node<ND>(g, w0, idx, in);
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      const size_t o = (size_t)node * ND + a;
+      win[idx * NV + a] = in ? dU[o] : 0.0;
+      win[idx * NV + ND + a] = in ? Un_dt[o] : 0.0;
+      win[idx * NV + 2 * ND + a] = in ? dU_dt[o] : 0.0;
+      win[idx * NV + 3 * ND + a] = in ? dU_dt2[o] : 0.0;
+    }
+  }
+  __syncthreads();
+  const double2* win2 = reinterpret_cast<const double2*>(win);
+  const int start = td.start[tile];
+  for (int s = threadIdx.x; s < cnt; s += BLK) {
+    const int p = td.order[start + s];
+    Lme<ND> c;
+    double lam[ND], beta;
+    if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
+    const int base = window_base<ND>(c.ijk, w0);
+    NLPS_YZ_LOCALS(c);
+    (void)ly5;
+    (void)lz5;
+    double Z = 0.0, sv[NV];
+#pragma unroll
+    for (int a = 0; a < NV; a++) sv[a] = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < KN; k++) {
+      const unsigned pb = plane_bits<ND>(c, k);
+      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
+      const double z0 = ez5[k];
+#pragma unroll 1
+      for (int j = 0; j < 5; j++) {
+        const unsigned bits = (pb >> (5 * j)) & 31u;
+        double A0 = 0.0, R[NV];
+#pragma unroll
+        for (int a = 0; a < NV; a++) R[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+          const int li = basek + (i - 2) + W * (j - 2);
+          const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+          A0 += m0;
+#pragma unroll
+          for (int q = 0; q < NP; q++) {
+            const double2 v = win2[li * NP + q];
+            R[2 * q] = fma(m0, v.x, R[2 * q]);
+            R[2 * q + 1] = fma(m0, v.y, R[2 * q + 1]);
+          }
+        }
+        const double w = ey5[j] * z0;
+        Z = fma(w, A0, Z);
+#pragma unroll
+        for (int a = 0; a < NV; a++) sv[a] = fma(w, R[a], sv[a]);
+      }
+    }
+    const double Zinv = 1.0 / Z, beta_blend = 1 - alpha_blend;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      const double du = sv[a] * Zinv, vn = sv[ND + a] * Zinv, dv = sv[2 * ND + a] * Zinv, da = sv[3 * ND + a] * Zinv;
+      PF(P, F_ACC + a, p) = PF(P, F_ACC + a, p) + da;
+      PF(P, F_VEL + a, p) = alpha_blend * PF(P, F_VEL + a, p) + (dv + beta_blend * vn);
+      PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + du;
+      PF(P, F_X + a, p) = PF(P, F_X + a, p) + du;
     }
   }
 }
