@@ -1358,3 +1358,57 @@ int orc_explicit_step(orc_particles *P, orc_mesh *M, const orc_material *mats, c
   }
   return STATUS;
 }
+
+/* ======================================================================================
+ * uGIMP (BASELINE config 1, plumbing only — uGIMP is not on the GPU path and is unusable in the
+ * reference: local_search exits, Shape-Functions.c:70-71, and dN__GIMP__ mixes node and dimension
+ * indices, GIMP.c:314-320).  Sip / dSip / N follow Nodes/GIMP.c:235-295; the gradient is the
+ * correct tensor product dS(x_j) * prod_{k != j} S(x_k).
+ * ====================================================================================== */
+double orc_sip_gimp(double L, double lp, double Delta_xp) { /* GIMP.c:235-253 */
+  if ((-lp < Delta_xp) && (Delta_xp <= lp)) {
+    return 1 - 0.5 * (dsqr(Delta_xp) + lp * lp) * (double)1 / (L * lp);
+  } else if (((-L - lp) < Delta_xp) && (Delta_xp <= (-L + lp))) {
+    return (double)(0.25 / (L * lp)) * dsqr(L + lp + Delta_xp);
+  } else if (((L - lp) < Delta_xp) && (Delta_xp <= (L + lp))) {
+    return (double)(0.25 / (L * lp)) * dsqr(L + lp - Delta_xp);
+  } else if (((-L + lp) < Delta_xp) && (Delta_xp <= -lp)) {
+    return 1 + (double)Delta_xp / L;
+  } else if ((lp < Delta_xp) && (Delta_xp <= (L - lp))) {
+    return 1 - (double)Delta_xp / L;
+  }
+  return (double)0.0;
+}
+
+double orc_dsip_gimp(double L, double lp, double Delta_xp) { /* GIMP.c:257-273 */
+  if (((-L - lp) < Delta_xp) && (Delta_xp <= (-L + lp))) {
+    return (double)(0.5 / (L * lp)) * (L + lp + Delta_xp);
+  } else if (((-L + lp) < Delta_xp) && (Delta_xp <= -lp)) {
+    return (double)1 / L;
+  } else if ((-lp < Delta_xp) && (Delta_xp <= lp)) {
+    return -(double)Delta_xp / (L * lp);
+  } else if ((lp < Delta_xp) && (Delta_xp <= (L - lp))) {
+    return -(double)1 / L;
+  } else if (((L - lp) < Delta_xp) && (Delta_xp <= (L + lp))) {
+    return -(double)(0.5 / (L * lp)) * (L + lp - Delta_xp);
+  }
+  return (double)0.0;
+}
+
+/* N__GIMP__, GIMP.c:277-295; Delta_Xp[nn][ndim] = x_p - x_I, lp[ndim] half particle size */
+void orc_N_gimp(double *S, const double *Delta_Xp, int nn, int ndim, const double *lp, double L) {
+  for (int i = 0; i < nn; i++) {
+    S[i] = 1.0;
+    for (int j = 0; j < ndim; j++) S[i] *= orc_sip_gimp(L, lp[j], Delta_Xp[i * ndim + j]);
+  }
+}
+
+void orc_dN_gimp(double *dS, const double *Delta_Xp, int nn, int ndim, const double *lp, double L) {
+  for (int i = 0; i < nn; i++)
+    for (int j = 0; j < ndim; j++) {
+      double v = orc_dsip_gimp(L, lp[j], Delta_Xp[i * ndim + j]);
+      for (int k = 0; k < ndim; k++)
+        if (k != j) v *= orc_sip_gimp(L, lp[k], Delta_Xp[i * ndim + k]);
+      dS[i * ndim + j] = v;
+    }
+}

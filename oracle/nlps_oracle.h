@@ -145,6 +145,12 @@ int orc_explicit_step(orc_particles *P, orc_mesh *M, const orc_material *mats, c
                       const orc_bcc *bcc, int nbcc, int step, int nsteps, double dt, double gamma,
                       const double *gravity, orc_step_out *out);
 
+/* ---- uGIMP (config-1 plumbing, CPU only; Nodes/GIMP.c:235-295) ---- */
+double orc_sip_gimp(double L, double lp, double Delta_xp);
+double orc_dsip_gimp(double L, double lp, double Delta_xp);
+void orc_N_gimp(double *S, const double *Delta_Xp, int nn, int ndim, const double *lp, double L);
+void orc_dN_gimp(double *dS, const double *Delta_Xp, int nn, int ndim, const double *lp, double L);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -355,3 +355,21 @@ def num_threads():
 
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+def N_gimp(Delta_Xp, lp, L):
+    D = np.ascontiguousarray(Delta_Xp, dtype=np.float64)
+    lp = np.ascontiguousarray(lp, dtype=np.float64)
+    S = np.zeros(D.shape[0])
+    lib().orc_N_gimp.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, C.c_double]
+    lib().orc_N_gimp(_d(S), _d(D), D.shape[0], D.shape[1], _d(lp), float(L))
+    return S
+
+
+def dN_gimp(Delta_Xp, lp, L):
+    D = np.ascontiguousarray(Delta_Xp, dtype=np.float64)
+    lp = np.ascontiguousarray(lp, dtype=np.float64)
+    dS = np.zeros(D.shape)
+    lib().orc_dN_gimp.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, C.c_double]
+    lib().orc_dN_gimp(_d(dS), _d(D), D.shape[0], D.shape[1], _d(lp), float(L))
+    return dS

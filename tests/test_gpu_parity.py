@@ -329,3 +329,67 @@ def test_shuffled_upload_and_periodic_resort(ndim):
     assert np.array_equal(st["I0"], P["I0"]) and np.array_equal(nn, P["nn"]) and lists_equal(nn, lst, P["list"])
     for k, ok in (("x", "x"), ("vel", "vel"), ("Stress", "stress"), ("F_n", "F_n"), ("lambda", "lambda")):
         assert_close(st[k], P[ok], 1e-9, f"{k} after resorted steps")
+
+
+def test_config1_2d_10k_parity():
+    """BASELINE configs[0] shape (2-D, 10 000 particles, explicit) on the HIP path against the oracle;
+    LME + Hencky stand in for uGIMP / linear-elastic (no runnable reference equivalent)."""
+    o = orc()
+    n = nlps()
+    from util import synth
+    case = make_case(2, [60, 60], [5, 5], [50, 50], material=HENCKY, velocity=[1.0, 0.0])
+    nsteps = 3
+    nodes = synth.plane_nodes(case["grid_n"], 0, 5)
+    bc = [{"nodes": nodes, "dim": 2, "dir": np.ones((2, nsteps), dtype=np.int32), "value": np.zeros((2, nsteps))}]
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    st = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bc), nsteps)
+    gb = n.BccSet(bc)
+    for t in range(nsteps):
+        assert st.step(t, 1e-3) == 0
+        S.explicit_step(gb, t, 1e-3)
+    d = S.download_state()
+    assert np.array_equal(d["I0"], P["I0"])
+    for k, ok in (("x", "x"), ("vel", "vel"), ("Stress", "stress"), ("F_n", "F_n"), ("W", "W")):
+        assert_close(d[k], P[ok], 1e-9, "config1 " + k)
+
+
+def test_config3_4m_neo_hookean_column_properties():
+    """BASELINE configs[2]: 3-D Neo-Hookean column, 4 M particles (50x50x200 cells x 8), gravity, soft
+    material (large-deformation F-update path).  Size-independent properties only."""
+    n = nlps()
+    case = make_case(3, [60, 60, 210], [5, 5, 5], [50, 50, 200], material={"type": 0, "E": 1.0e5, "nu": 0.3})
+    S = gpu_setup(case, nsteps=3)
+    assert S.np == 4_000_000
+    gb = n.BccSet([dirichlet_plane(case, 2, 5, 3)])
+    m0 = case["cloud"]["mass"].sum()
+    dt = 0.1 / 10.0
+    for t in range(2):
+        S.explicit_step(gb, t, dt, 0.5, [0.0, 0.0, -9.81])
+    nod = S.explicit_nodal()
+    assert abs(nod["mass"].reshape(-1, 3)[:, 0].sum() / m0 - 1.0) < 1e-12
+    # free nodes accelerate with g + f/M; with f summing to zero the mass-weighted mean is g on free dofs
+    a = nod["accel"].reshape(-1, 3)
+    assert np.isfinite(a).all() and a[:, 2].min() < 0
+    d = S.download_state()
+    assert np.all(d["J_n"] > 0) and np.isfinite(d["Stress"]).all()
+    assert d["vel"][:, 2].mean() < 0
+    assert S.status_flags() == 0
+
+
+def test_config5_drucker_prager_1m_properties():
+    """BASELINE configs[4] physics at one GPU's share (1 M particles): Drucker-Prager column under gravity
+    (plastic return mapping inside the stress kernel)."""
+    n = nlps()
+    case = make_case(3, [60, 60, 60], [5, 5, 5], [50, 50, 50], material=DP)
+    S = gpu_setup(case, nsteps=6)
+    gb = n.BccSet([dirichlet_plane(case, 2, 5, 6)])
+    dt = 0.1 / np.sqrt(DP["E"] / 1000.0)
+    for t in range(5):
+        S.explicit_step(gb, t, dt, 0.5, [0.0, 0.0, -9.81])
+    d = S.download_state()
+    assert S.status_flags() == 0
+    assert np.all(d["J_n"] > 0) and np.isfinite(d["Stress"]).all()
+    assert np.all(d["Kappa_n"] >= DP["kappa_0"] - 1e-9) and np.all(d["EPS_n"] >= 0)
+    be = d["b_e_n"]
+    assert np.allclose(be[:, [1, 2, 5]], be[:, [3, 6, 7]], atol=1e-9)

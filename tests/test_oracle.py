@@ -274,3 +274,52 @@ def test_drucker_prager_oedometric_path(ndim):
         eps_hist.append(eps)
     assert eps_hist[0] == 0.0 and plastic_steps > 10
     assert np.all(np.isfinite(tau)) and kappa > DP["kappa_0"]
+
+
+def test_ugimp_shape_functions_config1_plumbing():
+    """BASELINE configs[0] names uGIMP; it is unusable upstream, so only S/dS/N are
+    restated (Nodes/GIMP.c:235-295) and checked analytically: partition of unity, gradient sum zero,
+    gradient = finite difference, linear completeness."""
+    o = orc()
+    L, lp = 1.0, np.array([0.25, 0.25])
+    rng = np.random.default_rng(8)
+    gx, gy = np.meshgrid(np.arange(-3, 4), np.arange(-3, 4), indexing="ij")
+    nodes = np.stack([gx.ravel(), gy.ravel()], axis=1).astype(float)
+    for _ in range(50):
+        xp = rng.uniform(-0.5, 0.5, size=2)
+        D = xp[None, :] - nodes
+        S = o.N_gimp(D, lp, L)
+        dS = o.dN_gimp(D, lp, L)
+        assert abs(S.sum() - 1) < 1e-14 and np.all(S >= 0)
+        assert np.abs(dS.sum(0)).max() < 1e-13
+        assert np.abs(S @ nodes - xp).max() < 1e-13                      # linear completeness
+        assert np.abs(nodes.T @ dS - np.eye(2)).max() < 1e-12
+        e = 1e-6
+        for j in range(2):
+            dp = np.zeros(2)
+            dp[j] = e
+            fd = (o.N_gimp(D + dp, lp, L) - o.N_gimp(D - dp, lp, L)) / (2 * e)
+            assert np.abs(fd - dS[:, j]).max() < 1e-8
+
+
+def test_config1_2d_10k_particles_cpu_path():
+    """BASELINE configs[0] shape: 2-D bar, 10 000 particles (50x50 cells x 4), explicit step, CPU path.
+    uGIMP/linear-elastic have no runnable reference equivalent: LME + Hencky stand in.
+    Left edge fixed, right-moving initial velocity; checks the plumbing end to end on the oracle."""
+    o = orc()
+    case = make_case(2, [60, 60], [5, 5], [50, 50], material={"type": 1, "E": 1.0e7, "nu": 0.3},
+                     velocity=[1.0, 0.0])
+    assert case["cloud"]["x"].shape[0] == 10000
+    M, P, prm, mats = oracle_setup(case)
+    nsteps = 3
+    nodes = synth.plane_nodes(case["grid_n"], 0, 5)
+    bcs = o.BccSet([{"nodes": nodes, "dim": 2, "dir": np.ones((2, nsteps), dtype=np.int32),
+                     "value": np.zeros((2, nsteps))}])
+    st = o.ExplicitStepper(P, M, mats, prm, bcs, nsteps)
+    dt = 0.1 * 1.0 / 100.0
+    m0 = P["mass"].sum()
+    for t in range(nsteps):
+        assert st.step(t, dt) == 0
+        assert abs(st.nodal("mass").reshape(-1, 2)[:, 0].sum() / m0 - 1) < 1e-12
+    assert np.all(P["J_n"] > 0) and np.isfinite(P["stress"]).all()
+    assert P["x"][:, 0].mean() > case["cloud"]["x"][:, 0].mean()
