@@ -664,7 +664,7 @@ struct nlps_gpu {
     }                                                                                        \
   } while (0)
 
-static inline int nblk(int n, int b = BLK) { return (n + b - 1) / b; }
+static inline int nblk(int n, int b = BLK) { return n > 0 ? (n + b - 1) / b : 1; }
 
 static bool is_device_ptr(const void* p) {
   hipPointerAttribute_t a;

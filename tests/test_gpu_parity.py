@@ -393,3 +393,77 @@ def test_config5_drucker_prager_1m_properties():
     assert np.all(d["Kappa_n"] >= DP["kappa_0"] - 1e-9) and np.all(d["EPS_n"] >= 0)
     be = d["b_e_n"]
     assert np.allclose(be[:, [1, 2, 5]], be[:, [3, 6, 7]], atol=1e-9)
+
+
+def _random_cloud_case(ndim, n, seed, cells, lo, hi):
+    """Ragged input: n particles at uniformly random positions (0..many per cell), random masses."""
+    from util import synth
+    rng = np.random.default_rng(seed)
+    case = make_case(ndim, cells, [int(v) for v in lo], [1] * ndim)
+    x = rng.uniform(lo, hi, size=(n, ndim))
+    vol = rng.uniform(0.05, 0.2, size=n)
+    case["cloud"] = {
+        "ndim": ndim, "x": x, "dis": np.zeros((n, ndim)), "vel": rng.normal(size=(n, ndim)),
+        "acc": np.zeros((n, ndim)), "F_n": synth.identity_rows(n, ndim), "b_e_n": synth.identity_rows(n, ndim),
+        "J_n": np.ones(n), "rho": np.full(n, 1000.0), "mass": 1000.0 * vol, "vol0": vol,
+        "kappa_n": np.zeros(n), "eps_n": np.zeros(n), "matidx": np.zeros(n, dtype=np.int32)}
+    return case
+
+
+@pytest.mark.parametrize("ndim,n", [(2, 1), (2, 37), (3, 1), (3, 5), (3, 333)])
+def test_ragged_and_tiny_clouds(ndim, n):
+    """Edge cases: a single particle, counts that are no multiple of the wave size, many particles in one
+    cell and empty cells in between (uniformly random positions)."""
+    o = orc()
+    nl = nlps()
+    cells = [12, 11] if ndim == 2 else [9, 8, 8]
+    lo = np.array([3.2] * ndim)
+    hi = np.array([7.7, 6.9] if ndim == 2 else [5.8, 4.9, 4.6])
+    case = _random_cloud_case(ndim, n, 100 + n, cells, lo, hi)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=3)
+    compare_search(S, P, M, "ragged init")
+    st = o.ExplicitStepper(P, M, mats, prm, o.BccSet([]), 3)
+    gb = nl.BccSet([])
+    for t in range(3):
+        assert st.step(t, 2e-3) == 0
+        S.explicit_step(gb, t, 2e-3)
+    d = S.download_state()
+    assert np.array_equal(d["I0"], P["I0"])
+    for k, ok, scale in (("x", "x", None), ("vel", "vel", None), ("Stress", "stress", NH["E"]), ("F_n", "F_n", None)):
+        assert_close(d[k], P[ok], 1e-9, "ragged " + k, scale)
+
+
+def test_empty_particle_set():
+    nl = nlps()
+    case = _random_cloud_case(2, 0, 1, [8, 8], np.array([3.0, 3.0]), np.array([4.0, 4.0]))
+    S = gpu_setup(case, nsteps=2)
+    S.explicit_step(nl.BccSet([]), 0, 1e-3)
+    assert S.status_flags() == 0 and S.download_state()["x"].shape == (0, 2)
+    nod = S.explicit_nodal()
+    assert S.nactive == 0 and nod["mass"].size == 0
+
+
+def test_particle_outside_grid_is_an_error_not_a_crash():
+    nl = nlps()
+    case = _random_cloud_case(2, 10, 3, [8, 8], np.array([3.0, 3.0]), np.array([4.0, 4.0]))
+    case["cloud"]["x"][3] = [-5.0, 2.0]
+    S = gpu_setup(case, init=False)
+    with pytest.raises(nl.NlpsError):
+        S.initialise_shapefun()
+    assert S.status_flags() & 2
+
+
+def test_maximum_size_8m_particles():
+    """BASELINE configs[3] total size on ONE GPU (8 M particles, 100^3 cells x 8): capacity and
+    size-independent properties (664 B + index data per particle = 5.6 GB of 288 GB)."""
+    nl = nlps()
+    case = make_case(3, [110, 110, 110], [5, 5, 5], [100, 100, 100], velocity=[0.0, 0.0, -10.0])
+    S = gpu_setup(case, nsteps=2)
+    assert S.np == 8_000_000
+    S.explicit_step(nl.BccSet([dirichlet_plane(case, 2, 0, 2)]), 0, 1e-3)
+    nod = S.explicit_nodal()
+    assert abs(nod["mass"].reshape(-1, 3)[:, 0].sum() / case["cloud"]["mass"].sum() - 1.0) < 1e-12
+    assert S.status_flags() == 0
+    nn, _ = S.download_lists()
+    assert nn.min() >= 4 and nn.max() <= 125
