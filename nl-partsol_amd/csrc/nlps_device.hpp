@@ -55,6 +55,15 @@ struct ParamsD {
 #ifndef NLPS_K2_WAVES
 #define NLPS_K2_WAVES 3  // 168 VGPRs (small spill) beat 235 VGPRs at 2 waves/SIMD: 0.52 -> 0.41 ms with the row unroll
 #endif
+// The reference warm-starts the lambda Newton iteration from the previous step's lambda (LME.c:998) and
+// stops at |r| <= TOL_wrapper_LME = 1e-10, so its lambda carries a solver error of ~1e-10/|J| that
+// depends on the iteration path.  Starting from the extrapolation 2 lambda_n - lambda_(n-1) saves about
+// one of four evaluations (K2 0.39 -> 0.33 ms) and converges to the same root, but to a DIFFERENT point
+// of that tolerance ball (measured: lambda differs by 1.5e-8 relative from the reference path).  Parity
+// with the reference path is kept: OFF by default.
+#ifndef NLPS_LAMBDA_EXTRAPOLATE
+#define NLPS_LAMBDA_EXTRAPOLATE 0
+#endif
 #ifndef NLPS_JUNROLL_K3
 #define NLPS_JUNROLL_K3 1
 #endif

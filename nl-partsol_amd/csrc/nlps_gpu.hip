@@ -35,7 +35,9 @@ enum {
   F_X = 0, F_DIS = 3, F_VEL = 6, F_ACC = 9, F_DDIS = 12,
   F_FN = 15, F_FN1 = 24, F_DF = 33, F_TAU = 42, F_BEN = 51, F_BEN1 = 60,
   F_JN = 69, F_JN1 = 70, F_RHO = 71, F_MASS = 72, F_VOL0 = 73, F_W = 74,
-  F_KN = 75, F_KN1 = 76, F_EN = 77, F_EN1 = 78, F_LAM = 79, F_BETA = 82, NFD = 83
+  F_KN = 75, F_KN1 = 76, F_EN = 77, F_EN1 = 78, F_LAM = 79, F_BETA = 82,
+  F_LAMP = 83,  // lambda of the previous step (Newton start extrapolation)
+  NFD = 86
 };
 
 struct PView {
@@ -1012,6 +1014,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     if (upload_field(h, F_EN1, 1, host->EPS_n1 ? host->EPS_n1 : host->EPS_n, 1, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_LAM, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_BETA, 1, host->Beta, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_LAMP, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
     std::vector<int> it(h->P.npad, 0);
     for (int s = 0; s < np; s++) it[s] = host->MatIdx ? host->MatIdx[h->perm[s]] : 0;
     HIPCHK(hipMemcpy(h->P.mat, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
@@ -1286,7 +1289,7 @@ static int check_status(nlps_gpu* h, int fatal_mask, const char* where) {
 extern "C" int nlps_gpu_initialize_lme(nlps_gpu* h) {
   // beta and lambda start at zero (Generate-One-Phase-Analysis.c:190-192) => first list is the
   // whole active 2-ring (LME.c:150-154)
-  HIPCHK(hipMemsetAsync(h->P.d + (size_t)F_LAM * h->P.npad, 0, 4 * h->P.npad * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->P.d + (size_t)F_LAM * h->P.npad, 0, 7 * h->P.npad * sizeof(double), h->stream));
   if (search_and_lists(h, true, false, 0.0, 0.0)) return 1;
   if (compute_node_mask(h)) return 1;
   return check_status(h, ST_NEWTON | ST_CONNECT, "initialize__LME__()");

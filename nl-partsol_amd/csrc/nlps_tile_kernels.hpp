@@ -177,6 +177,13 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
     for (int a = 0; a < ND; a++) {
       x[a] = PF(P, F_X + a, p);
       lam[a] = PF(P, F_LAM + a, p);
+#if NLPS_LAMBDA_EXTRAPOLATE
+      if (P2G) {  // start Newton from 2 lambda_n - lambda_{n-1}: same root, usually one iteration fewer
+        const double lp = PF(P, F_LAMP + a, p);
+        PF(P, F_LAMP + a, p) = lam[a];
+        lam[a] = 2.0 * lam[a] - lp;
+      }
+#endif
     }
     const int I0 = P.I0[p];
     c.geom(g, x, I0);
