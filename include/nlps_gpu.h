@@ -96,6 +96,10 @@ typedef struct {
   int *I0;              /* [np]      NULL on upload => nlps_gpu_initialize_lme() must be called */
   double *lambda;       /* [np][ndim] (MPM_Mesh.lambda.nV) optional */
   double *Beta;         /* [np]       (MPM_Mesh.Beta.nV)   optional */
+  double *dt_F_n;       /* [np][T]  optional (0): rate of F, consumed only by the fluid law upstream */
+  double *dt_F_n1;      /* [np][T]  optional */
+  double *dt_DF;        /* [np][T]  optional */
+  double *C_ep;         /* [np][ndim*ndim] download only: elastoplastic tangent moduli (Drucker-Prager) */
 } nlps_particles;
 
 /* Dirichlet boundary = Load of FEM_Mesh.Bounds (Types.h:296-351), flattened:
@@ -150,8 +154,9 @@ int nlps_gpu_lumped_mass(nlps_gpu *h, double *M);
 /* __get_nodal_field_n, U-Newmark-beta.c:615-696.  V, A overwritten; needs M from the call above. */
 int nlps_gpu_nodal_field_n(nlps_gpu *h, double *V, double *A, const double *M);
 
-/* __local_compatibility_conditions, U-Newmark-beta.c:1064-1160: DF, F_n1, J_n1 (dU_dt may be NULL:
- * the rate tensors feed only the Newtonian-fluid law, Constitutive.c:84-108). */
+/* __local_compatibility_conditions, U-Newmark-beta.c:1064-1160: DF, F_n1, J_n1 and, when dU_dt is given,
+ * the rate tensors dt_DF, dt_F_n1 (compute-Strains.c:48-72,176-207; they feed only the Newtonian-fluid law,
+ * Constitutive.c:84-108, so dU_dt may be NULL). */
 int nlps_gpu_compatibility(nlps_gpu *h, const double *dU, const double *dU_dt);
 
 /* __constitutive_update -> Stress_integration__Constitutive__, U-Newmark-beta.c:1208-1242,

@@ -216,6 +216,23 @@ __device__ __forceinline__ void sym_eigen(double* w, double* v, const double* Ai
   }
 #pragma unroll
   for (int i = 0; i < N; i++) w[i] = a[i * N + i];
+  // ascending eigenvalues like LAPACK's dsyev (Matlib/LAPACK.c): the stress is order-invariant, but the
+  // Drucker-Prager tangent moduli C_ep are stored per principal direction
+#pragma unroll
+  for (int i = 0; i < N - 1; i++)
+#pragma unroll
+    for (int j = 0; j < N - 1 - i; j++)
+      if (w[j] > w[j + 1]) {
+        double t = w[j];
+        w[j] = w[j + 1];
+        w[j + 1] = t;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+          t = v[k * N + j];
+          v[k * N + j] = v[k * N + j + 1];
+          v[k * N + j + 1] = t;
+        }
+      }
 }
 
 template <int N>
@@ -256,6 +273,7 @@ struct StressIO {
   double be[N * N];
   double be_zz;
   double kappa, eps;
+  double cep[N * N];  // elastoplastic tangent moduli in principal space (Drucker-Prager.c:1088-1198)
   int fail;
 };
 
@@ -354,6 +372,11 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
   if (PHI_0 <= NLPS_TOL_NR) {
 #pragma unroll
     for (int a = 0; a < 3; a++) Tp[a] = -Tvol[a] + Tdev[a];
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        o.cep[i * N + j] = (1.0 / 3.0) * K * 1.0 * 1.0 + 2.0 * G * ((i == j ? 1.0 : 0.0) - (1.0 / 3.0) * 1.0 * 1.0);
   } else {
     if (J2 > NLPS_TOL_NR) {
       n[0] = Tdev[0] / J2;
@@ -393,6 +416,20 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
       }
       o.eps = eps_k;
       o.kappa = kappa_k;
+      {
+        const double c0 = 9 * alpha_F * alpha_Q * K + 2 * G + beta * d_kappa_k * sqrt(2. / 3. * (1 + 3 * alpha_Q * alpha_Q));
+        const double c1 = 1.0 - 9.0 * alpha_F * alpha_Q * K / c0;
+        double c2 = 0.0;
+        if (J2 > NLPS_TOL_NR) c2 = d_gamma_k / J2;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+          for (int j = 0; j < N; j++)
+            o.cep[i * N + j] = c1 * K * 1.0 * 1.0 +
+                               2 * G * ((i == j ? 1.0 : 0.0) - (1. / 3.) * (1.0 - 2.0 * G * c2) * 1.0 * 1.0) -
+                               (6.0 * alpha_Q * K * G / c0) * 1.0 * n[j] - (6.0 * alpha_Q * K * G / c0) * n[i] * 1.0 -
+                               4 * G * G * (1.0 / c0 - c2) * n[i] * n[j];
+      }
     } else {
       double d_gamma_1 = J2 / (2.0 * G);
       double d_gamma_2_k = 0.0;
@@ -425,6 +462,19 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
       }
       o.eps = eps_k;
       o.kappa = kappa_k;
+      {
+        double c0 = 0.0, c1 = 0.0;
+        if (d_gamma_k > 0.0) {
+          c0 = (alpha_Q * beta * sqrt(2. / 3.) * d_kappa_k * d_gamma_k) /
+               (3.0 * alpha_F * K * sqrt(d_gamma_1 * d_gamma_1 + 3.0 * alpha_Q * alpha_Q * d_gamma_k * d_gamma_k) +
+                alpha_Q * beta * sqrt(2. / 3.) * d_kappa_k * d_gamma_k);
+          c1 = c0 * K / (2.0 * alpha_Q * G * d_gamma_k);
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+          for (int j = 0; j < N; j++) o.cep[i * N + j] = c0 * K * 1.0 * 1.0 + c1 * 1.0 * n[j];
+      }
     }
   }
 #undef NLPS_YIELD

@@ -37,7 +37,9 @@ enum {
   F_JN = 69, F_JN1 = 70, F_RHO = 71, F_MASS = 72, F_VOL0 = 73, F_W = 74,
   F_KN = 75, F_KN1 = 76, F_EN = 77, F_EN1 = 78, F_LAM = 79, F_BETA = 82,
   F_LAMP = 83,  // lambda of the previous step (Newton start extrapolation)
-  NFD = 86
+  F_CEP = 86,   // C_ep[ndim*ndim] (Drucker-Prager tangent moduli, implicit driver only)
+  F_DTFN = 95, F_DTFN1 = 104, F_DTDF = 113,  // rate tensors (level-B compatibility with dU_dt)
+  NFD = 122
 };
 
 struct PView {
@@ -307,7 +309,8 @@ __device__ __forceinline__ void store_block(const PView& P, int f0, int p, const
 
 // LAW = -1: dispatch on the particle's material at run time (mixed clouds); LAW = 0/1/2: the whole
 // cloud uses that one law, so only its code (and register footprint) is compiled into the kernel.
-template <int ND, int LAW = -1>
+// CEP: also keep the Drucker-Prager tangent moduli (only the implicit driver's Jacobian reads them).
+template <int ND, int LAW = -1, bool CEP = false>
 __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* __restrict__ mats, const ParamsD& prm,
                                              const double* Fn1, const double* DF, double J, double* tau) {
   MatD m = mats[P.mat[p]];
@@ -327,6 +330,10 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
     store_block<ND>(P, F_BEN1, p, o.be, o.be_zz, true);
     PF(P, F_KN1, p) = o.kappa;
     PF(P, F_EN1, p) = o.eps;
+    if (CEP) {
+#pragma unroll
+      for (int q = 0; q < ND * ND; q++) PF(P, F_CEP + q, p) = o.cep[q];
+    }
   }
 #pragma unroll
   for (int s = 0; s < ND * ND; s++) tau[s] = o.tau[s];
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict_
   double Fn1[ND * ND], DF[ND * ND], tau[ND * ND], z;
   load_block<ND>(P, F_FN1, p, Fn1, z);
   load_block<ND>(P, F_DF, p, DF, z);
-  int st = stress_update<ND>(P, p, mats, prm, Fn1, DF, PF(P, F_JN1, p), tau);
+  int st = stress_update<ND, -1, true>(P, p, mats, prm, Fn1, DF, PF(P, F_JN1, p), tau);
   if (st) {
     atomicOr(&P.status[p], st);
     atomicOr(gstatus, st);
@@ -397,6 +404,7 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
   for (int s = 0; s < T; s++) {
     PF(P, F_BEN + s, p) = PF(P, F_BEN1 + s, p);
     PF(P, F_FN + s, p) = PF(P, F_FN1 + s, p);
+    PF(P, F_DTFN + s, p) = PF(P, F_DTFN1 + s, p);
   }
 }
 
@@ -622,6 +630,7 @@ struct nlps_gpu {
   int nactive, nfree;
   bool masks_valid;
   bool binned;  // order[] / tile tables describe the current I0s
+  bool level_b_fields = false;  // C_ep / rate tensors hold data (a level-B constitutive or rate call was made)
 
   // scratch nodal arrays
   double* gridA;  // [nnodes][2*ND] general purpose
@@ -1015,6 +1024,10 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     if (upload_field(h, F_LAM, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_BETA, 1, host->Beta, 1, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_LAMP, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
+    if (host->dt_F_n || host->dt_F_n1 || host->dt_DF) h->level_b_fields = true;
+    if (host->dt_F_n && upload_field(h, F_DTFN, T, host->dt_F_n, T, tmp, nullptr, 0.0)) return 1;
+    if (host->dt_F_n1 && upload_field(h, F_DTFN1, T, host->dt_F_n1, T, tmp, nullptr, 0.0)) return 1;
+    if (host->dt_DF && upload_field(h, F_DTDF, T, host->dt_DF, T, tmp, nullptr, 0.0)) return 1;
     std::vector<int> it(h->P.npad, 0);
     for (int s = 0; s < np; s++) it[s] = host->MatIdx ? host->MatIdx[h->perm[s]] : 0;
     HIPCHK(hipMemcpy(h->P.mat, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
@@ -1053,7 +1066,8 @@ static int resort(nlps_gpu* h) {
                                             h->stream));
   const int* idx = h->sval2_d;  // new slot -> old slot
   const size_t npad = h->P.npad;
-  for (int f = 0; f < NFD; f++) {
+  const int nf = h->level_b_fields ? (int)NFD : (int)F_CEP;  // C_ep and the rate tensors only exist for level B
+  for (int f = 0; f < nf; f++) {
     double* fld = h->P.d + (size_t)f * npad;
     hipLaunchKernelGGL(k_gather<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->gather_tmp, fld, idx, np);
     HIPCHK(hipMemcpyAsync(fld, h->gather_tmp, (size_t)np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1145,6 +1159,10 @@ extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
   if (download_field(h, F_EN1, 1, o->EPS_n1, 1, tmp)) return 1;
   if (download_field(h, F_LAM, ND, o->lambda, ND, tmp)) return 1;
   if (download_field(h, F_BETA, 1, o->Beta, 1, tmp)) return 1;
+  if (download_field(h, F_DTFN, T, o->dt_F_n, T, tmp)) return 1;
+  if (download_field(h, F_DTFN1, T, o->dt_F_n1, T, tmp)) return 1;
+  if (download_field(h, F_DTDF, T, o->dt_DF, T, tmp)) return 1;
+  if (download_field(h, F_CEP, ND * ND, o->C_ep, ND * ND, tmp)) return 1;
   if (o->I0) {
     std::vector<int> it(np);
     HIPCHK(hipMemcpy(it.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
@@ -1439,19 +1457,26 @@ extern "C" int nlps_gpu_nodal_field_n(nlps_gpu* h, double* V, double* A, const d
 }
 
 extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const double* dU_dt) {
-  (void)dU_dt;  // rate tensors: consumed only by the out-of-scope Newtonian-fluid law (Constitutive.c:84-108)
   if (need_masks(h, "nlps_gpu_compatibility")) return 1;
   if (to_grid(h, h->N.dU, dU, h->nd)) return 1;
-  {
-    TileD td = tile_view(h);
-    if (h->nd == 2) hipLaunchKernelGGL((k3_tile<2, 0, 0>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
-    else hipLaunchKernelGGL((k3_tile<3, 0, 0>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d);
+  if (dU_dt && to_grid(h, h->gridB, dU_dt, h->nd)) return 1;
+  if (dU_dt) h->level_b_fields = true;
+  TileD td = tile_view(h);
+  const dim3 grid(h->ntiles * K3_SPLIT), blk(BLK);
+  const double* dV = dU_dt ? h->gridB : nullptr;
+  if (h->nd == 2) {
+    if (dV) hipLaunchKernelGGL((k3_tile<2, 0, 2>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, dV);
+    else hipLaunchKernelGGL((k3_tile<2, 0, 0>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, dV);
+  } else {
+    if (dV) hipLaunchKernelGGL((k3_tile<3, 0, 2>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, dV);
+    else hipLaunchKernelGGL((k3_tile<3, 0, 0>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, dV);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 extern "C" int nlps_gpu_constitutive(nlps_gpu* h) {
+  h->level_b_fields = true;
   LAUNCH_ND((k_stress<2>), (k_stress<3>), nblk(h->P.np), h->P, h->mats_d, h->prm, h->gstatus_d);
   HIPCHK(hipGetLastError());
   return check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()");
@@ -1533,7 +1558,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     TileD td = tile_view(h);
 #define NLPS_K3(NDv, LAWv)                                                                                      \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
-                     h->prm, h->gstatus_d)
+                     h->prm, h->gstatus_d, (const double*)nullptr)
     const int law = h->uniform_law;
     if (ND == 2) {
       if (law == 0) NLPS_K3(2, 0);

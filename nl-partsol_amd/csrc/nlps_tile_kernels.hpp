@@ -321,10 +321,16 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
 // ------------------------------------------------------------------------------------------------
 // MODE 1: fused explicit stage (S3+S4).  MODE 0: __local_compatibility_conditions only (level B):
 // DF, F_n1, J_n1 with the implicit driver's clamp of J <= 0 (U-Newmark-beta.c:1137-1142).
+// MODE 2: MODE 0 plus the rate tensors dt_DF = sum dV_A (x) grad N_A and dt_F_n1 = dt_DF F_n + DF dt_F_n
+// (compute-Strains.c:48-72, 176-207) from a second gather window dV.
 template <int ND, int LAW, int MODE>
 __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
-                                               ParamsD prm, int* __restrict__ gstatus) {
+                                               ParamsD prm, int* __restrict__ gstatus,
+                                               const double* __restrict__ dVgrid) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
+  constexpr bool RATES = (MODE == 2);
+  __shared__ __attribute__((aligned(16))) double dvxy[RATES ? 2 * NW : 2];
+  __shared__ double dvz[(RATES && ND == 3) ? NW : 1];
   // gather window of dU: {x,y} as one 16-B double2 per node (ds_read_b128) + z as a separate 8-B array
   // (ds_read_b64): with node strides of 16 B and 8 B the tile's 64 I0 positions hit distinct banks; a
   // padded 32-B AoS row put every second node on the same banks (41 % conflict cycles measured).
@@ -342,11 +348,17 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
     duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
     duxy[2 * idx + 1] = in ? N.dU[(size_t)node * ND + 1] : 0.0;
     if (ND == 3) duz[idx % ((ND == 3) ? NW : 1)] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
+    if (RATES) {
+      dvxy[(2 * idx) % (RATES ? 2 * NW : 2)] = in ? dVgrid[(size_t)node * ND + 0] : 0.0;
+      dvxy[(2 * idx + 1) % (RATES ? 2 * NW : 2)] = in ? dVgrid[(size_t)node * ND + 1] : 0.0;
+      if (ND == 3) dvz[idx % ((RATES && ND == 3) ? NW : 1)] = in ? dVgrid[(size_t)node * ND + (2 % ND)] : 0.0;
+    }
 #pragma unroll
     for (int a = 0; a < ND; a++) fac[a * NW + idx] = 0.0;
   }
   __syncthreads();
   const double2* du2 = reinterpret_cast<const double2*>(duxy);
+  const double2* dv2 = reinterpret_cast<const double2*>(dvxy);
   const int start = td.start[tile];
   for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K3_SPLIT) {
     const int p = td.order[start + s];
@@ -357,23 +369,26 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
     NLPS_YZ_LOCALS(c);
     // pass 1: moments (rows -> planes) and G[a][m] = sum e dU_a l_m (rows)
     double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
-    double G[ND * ND];
+    double G[ND * ND], Gv[RATES ? ND * ND : 1];
 #pragma unroll
     for (int a = 0; a < ND * ND; a++) G[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < (RATES ? ND * ND : 1); a++) Gv[a] = 0.0;
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
       double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;
       double Gx[ND], Gy[ND], Gz[ND];  // plane partial sums of G[.][x], G[.][y], G[.][z]/lz
+      double Hx[ND], Hy[ND], Hz[ND];  // the same for the velocity increments (RATES)
 #pragma unroll
-      for (int a = 0; a < ND; a++) Gx[a] = Gy[a] = Gz[a] = 0.0;
+      for (int a = 0; a < ND; a++) Gx[a] = Gy[a] = Gz[a] = Hx[a] = Hy[a] = Hz[a] = 0.0;
 #pragma unroll NLPS_JUNROLL_K3
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
-        double A0 = 0.0, A1 = 0.0, A2 = 0.0, R0[ND], R1[ND];
+        double A0 = 0.0, A1 = 0.0, A2 = 0.0, R0[ND], R1[ND], V0r[ND], V1r[ND];
 #pragma unroll
-        for (int a = 0; a < ND; a++) R0[a] = R1[a] = 0.0;
+        for (int a = 0; a < ND; a++) R0[a] = R1[a] = V0r[a] = V1r[a] = 0.0;
 #pragma unroll
         for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
           const bool on = (bits >> i) & 1u;
@@ -390,6 +405,16 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
             R0[a] = fma(m0, uu[a], R0[a]);
             R1[a] = fma(m1, uu[a], R1[a]);
           }
+          if (RATES) {
+            const double2 v01 = dv2[li % (RATES ? NW : 1)];
+            const double v2 = (ND == 3) ? dvz[li % ((RATES && ND == 3) ? NW : 1)] : 0.0;
+            const double vv[3] = {v01.x, v01.y, v2};
+#pragma unroll
+            for (int a = 0; a < ND; a++) {
+              V0r[a] = fma(m0, vv[a], V0r[a]);
+              V1r[a] = fma(m1, vv[a], V1r[a]);
+            }
+          }
         }
         const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
         P00 = fma(y0, A0, P00);
@@ -403,6 +428,11 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
           Gx[a] = fma(y0, R1[a], Gx[a]);
           Gy[a] = fma(y1, R0[a], Gy[a]);
           Gz[a] = fma(y0, R0[a], Gz[a]);
+          if (RATES) {
+            Hx[a] = fma(y0, V1r[a], Hx[a]);
+            Hy[a] = fma(y1, V0r[a], Hy[a]);
+            Hz[a] = fma(y0, V0r[a], Hz[a]);
+          }
         }
       }
       if (ND == 3) {
@@ -422,6 +452,11 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
           G[a * ND + 0] = fma(z0, Gx[a], G[a * ND + 0]);
           G[a * ND + 1] = fma(z0, Gy[a], G[a * ND + 1]);
           G[a * ND + (2 % ND)] = fma(z1, Gz[a], G[a * ND + (2 % ND)]);
+          if (RATES) {
+            Gv[(a * ND + 0) % (RATES ? ND * ND : 1)] = fma(z0, Hx[a], Gv[(a * ND + 0) % (RATES ? ND * ND : 1)]);
+            Gv[(a * ND + 1) % (RATES ? ND * ND : 1)] = fma(z0, Hy[a], Gv[(a * ND + 1) % (RATES ? ND * ND : 1)]);
+            Gv[(a * ND + (2 % ND)) % (RATES ? ND * ND : 1)] = fma(z1, Hz[a], Gv[(a * ND + (2 % ND)) % (RATES ? ND * ND : 1)]);
+          }
         }
       } else {
         Z = P00;
@@ -434,6 +469,10 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
         for (int a = 0; a < ND; a++) {
           G[a * ND + 0] = Gx[a];
           G[a * ND + 1] = Gy[a];
+          if (RATES) {
+            Gv[(a * ND + 0) % (RATES ? ND * ND : 1)] = Hx[a];
+            Gv[(a * ND + 1) % (RATES ? ND * ND : 1)] = Hy[a];
+          }
         }
       }
     }
@@ -480,12 +519,36 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
     double Jn1 = det<ND>(Fn1);
     if (Jn1 <= 0.0) {
       st |= ST_JACOBIAN;  // fatal in the explicit scheme (U-Verlet.c:608-613), clamped in the implicit one
-      if (MODE == 0) Jn1 = 0.0;
+      if (MODE != 1) Jn1 = 0.0;
     }
     store_block<ND>(P, F_DF, p, DF, 0.0, false);
     store_block<ND>(P, F_FN1, p, Fn1, 0.0, false);
     PF(P, F_JN1, p) = Jn1;
-    if (MODE == 0) {
+    if (RATES) {
+      double dDF[ND * ND], dFn[ND * ND], dFn1[ND * ND], zz;
+#pragma unroll
+      for (int i = 0; i < ND; i++)
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+          double v = 0.0;
+#pragma unroll
+          for (int m = 0; m < ND; m++) v = fma(Gv[(i * ND + m) % (RATES ? ND * ND : 1)] * Zinv, Jm1[j * ND + m], v);
+          dDF[i * ND + j] = -v;
+        }
+      load_block<ND>(P, F_DTFN, p, dFn, zz);
+#pragma unroll
+      for (int i = 0; i < ND; i++)
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+          double a2 = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < ND; k2++) a2 += dDF[i * ND + k2] * Fn[k2 * ND + j] + DF[i * ND + k2] * dFn[k2 * ND + j];
+          dFn1[i * ND + j] = a2;
+        }
+      store_block<ND>(P, F_DTDF, p, dDF, 0.0, false);
+      store_block<ND>(P, F_DTFN1, p, dFn1, 0.0, false);
+    }
+    if (MODE != 1) {
       if (st) {
         atomicOr(&P.status[p], st);
         atomicOr(gstatus, st);
@@ -529,7 +592,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
       atomicOr(gstatus, st);
     }
   }
-  if (MODE == 0) return;
+  if (MODE != 1) return;
   __syncthreads();
   for (int qq = threadIdx.x; qq < NW * ND; qq += BLK) {
     int f = qq % ND, idx = qq / ND;

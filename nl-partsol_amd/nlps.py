@@ -45,7 +45,8 @@ _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e
 
 class Particles(C.Structure):
     _fields_ = ([("np", C.c_int)] + [(k, _dp) for k in _PD] +
-                [("MatIdx", _ip), ("I0", _ip), ("lambda_", _dp), ("Beta", _dp)])
+                [("MatIdx", _ip), ("I0", _ip), ("lambda_", _dp), ("Beta", _dp), ("dt_F_n", _dp), ("dt_F_n1", _dp),
+                 ("dt_DF", _dp), ("C_ep", _dp)])
 
 
 class Bcc(C.Structure):
@@ -196,7 +197,7 @@ class Solver:
         hp.np = self.np
         keymap = {"x_GC": "x", "dis": "dis", "vel": "vel", "acc": "acc", "F_n": "F_n", "b_e_n": "b_e_n",
                   "J_n": "J_n", "rho": "rho", "mass": "mass", "Vol_0": "vol0", "Kappa_n": "kappa_n",
-                  "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta"}
+                  "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta", "dt_F_n": "dt_F_n"}
         for ck, k in keymap.items():
             if k in cloud and cloud[k] is not None:
                 a = np.ascontiguousarray(cloud[k], dtype=np.float64)
@@ -306,7 +307,8 @@ class Solver:
              "b_e_n": np.zeros((n, T)), "b_e_n1": np.zeros((n, T)), "J_n": np.zeros(n), "J_n1": np.zeros(n),
              "rho": np.zeros(n), "mass": np.zeros(n), "Vol_0": np.zeros(n), "W": np.zeros(n),
              "Kappa_n": np.zeros(n), "Kappa_n1": np.zeros(n), "EPS_n": np.zeros(n), "EPS_n1": np.zeros(n),
-             "lambda_": np.zeros((n, d)), "Beta": np.zeros(n)}
+             "lambda_": np.zeros((n, d)), "Beta": np.zeros(n), "dt_F_n": np.zeros((n, T)),
+             "dt_F_n1": np.zeros((n, T)), "dt_DF": np.zeros((n, T)), "C_ep": np.zeros((n, d * d))}
         i0 = np.zeros(n, dtype=np.int32)
         hp = Particles()
         hp.np = n

@@ -947,7 +947,7 @@ static int stress_hencky(int ndim, const orc_material *mat, const double *F_n1, 
 static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_params *prm,
                                  const double *d_phi, const double *b_e_n, double kappa_n,
                                  double eps_n_in, double *T, double *W, double *b_e, double *kappa_out,
-                                 double *eps_out) {
+                                 double *eps_out, double *C_ep) {
   double eigval[3] = {0, 0, 0}, eigvec[9] = {0}, btr[9] = {0};
   /* __compute_trial_b_e :617-660 */
   for (int i = 0; i < ndim; i++)
@@ -1010,6 +1010,10 @@ static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_pa
   if (PHI_0 <= TOL_NR) { /* elastic :410-432 */
     for (int a = 0; a < 3; a++) Tp[a] = -Tvol[a] + Tdev[a];
     ppal_to_xyz(T, Tp, eigvec, ndim);
+    if (C_ep) /* __tangent_moduli_elastic :1088-1113 */
+      for (int i = 0; i < ndim; i++)
+        for (int j = 0; j < ndim; j++)
+          C_ep[i * ndim + j] = (1.0 / 3.0) * K * 1.0 * 1.0 + 2.0 * G * ((i == j ? 1.0 : 0.0) - (1.0 / 3.0) * 1.0 * 1.0);
   } else {
     if (J2 > TOL_NR) { /* __compute_plastic_flow_direction :798-812 */
       n[0] = Tdev[0] / J2;
@@ -1053,6 +1057,18 @@ static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_pa
       *kappa_out = kappa_k;
       for (int a = 0; a < 3; a++) dEp[a] = d_gamma_k * (alpha_Q + n[a]);
       ppal_to_xyz(T, Tp, eigvec, ndim);
+      if (C_ep) { /* __tangent_moduli_classical :1117-1159 */
+        double c0 = 9 * alpha_F * alpha_Q * K + 2 * G + beta * d_kappa_k * sqrt(2. / 3. * (1 + 3 * alpha_Q * alpha_Q));
+        double c1 = 1.0 - 9.0 * alpha_F * alpha_Q * K / c0;
+        double c2 = 0.0;
+        if (J2 > TOL_NR) c2 = d_gamma_k / J2;
+        for (int i = 0; i < ndim; i++)
+          for (int j = 0; j < ndim; j++)
+            C_ep[i * ndim + j] = c1 * K * 1.0 * 1.0 +
+                                 2 * G * ((i == j ? 1.0 : 0.0) - (1. / 3.) * (1.0 - 2.0 * G * c2) * 1.0 * 1.0) -
+                                 (6.0 * alpha_Q * K * G / c0) * 1.0 * n[j] - (6.0 * alpha_Q * K * G / c0) * n[i] * 1.0 -
+                                 4 * G * G * (1.0 / c0 - c2) * n[i] * n[j];
+      }
     } else { /* apex return :532-590 */
       double d_gamma_1 = J2 / (2.0 * G);
       double d_gamma_2_k = 0.0;
@@ -1085,6 +1101,17 @@ static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_pa
       *kappa_out = kappa_k;
       for (int a = 0; a < 3; a++) dEp[a] = d_gamma_k * alpha_Q + d_gamma_1 * n[a];
       ppal_to_xyz(T, Tp, eigvec, ndim);
+      if (C_ep) { /* __tangent_moduli_apex :1163-1198 */
+        double c0 = 0.0, c1 = 0.0;
+        if (d_gamma_k > 0.0) {
+          c0 = (alpha_Q * beta * sqrt(2. / 3.) * d_kappa_k * d_gamma_k) /
+               (3.0 * alpha_F * K * sqrt(d_gamma_1 * d_gamma_1 + 3.0 * alpha_Q * alpha_Q * d_gamma_k * d_gamma_k) +
+                alpha_Q * beta * sqrt(2. / 3.) * d_kappa_k * d_gamma_k);
+          c1 = c0 * K / (2.0 * alpha_Q * G * d_gamma_k);
+        }
+        for (int i = 0; i < ndim; i++)
+          for (int j = 0; j < ndim; j++) C_ep[i * ndim + j] = c0 * K * 1.0 * 1.0 + c1 * 1.0 * n[j];
+      }
     }
   }
 #undef YIELD_CLASSICAL
@@ -1103,7 +1130,7 @@ static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_pa
 /* Stress_integration__Constitutive__, Constitutive/Constitutive.c:18-258 (the three laws on the path) */
 int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, const double *F_n1,
                    const double *DF, double J, const double *b_e_n, double kappa_n, double eps_n,
-                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1) {
+                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep) {
   switch (mat->type) {
   case ORC_MAT_NEO_HOOKEAN:
     return stress_neo_hookean(ndim, mat, F_n1, J, stress, W);
@@ -1111,7 +1138,7 @@ int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, con
     return stress_hencky(ndim, mat, F_n1, stress, W);
   case ORC_MAT_DRUCKER_PRAGER:
     return stress_drucker_prager(ndim, mat, prm, DF, b_e_n, kappa_n, eps_n, stress, W, b_e_n1,
-                                 kappa_n1, eps_n1);
+                                 kappa_n1, eps_n1, C_ep);
   default:
     return 1; /* Constitutive.c:251-256 exit()s */
   }
@@ -1129,7 +1156,7 @@ int orc_constitutive(orc_particles *P, const orc_material *mats, const orc_param
                             P->b_e_n ? &P->b_e_n[p * T] : dummyb, P->kappa_n ? P->kappa_n[p] : 0.0,
                             P->eps_n ? P->eps_n[p] : 0.0, &P->stress[p * T], &P->W[p],
                             P->b_e_n1 ? &P->b_e_n1[p * T] : dummyb, P->kappa_n1 ? &P->kappa_n1[p] : &dk,
-                            P->eps_n1 ? &P->eps_n1[p] : &de);
+                            P->eps_n1 ? &P->eps_n1[p] : &de, P->C_ep ? &P->C_ep[p * P->ndim * P->ndim] : NULL);
     if (st) {
       if (P->status) P->status[p] |= 8;
       STATUS |= 1;

@@ -57,6 +57,7 @@ typedef struct {
   int *nn;                                              /* NumberNodes[np] */
   int *list;                                            /* ListNodes as array [np][ORC_MAXNB], chain order */
   int *status;                                          /* per-particle failure flags (build's addition) */
+  double *C_ep;                                         /* [np][ndim*ndim] elastoplastic tangent moduli */
 } orc_particles;
 
 /* Material: Types.h:359-458 (members the three laws read). */
@@ -121,7 +122,7 @@ int orc_compatibility(const double *dU, const double *dU_dt, orc_particles *P, c
 int orc_constitutive(orc_particles *P, const orc_material *mats, const orc_params *prm);
 int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, const double *F_n1,
                    const double *DF, double J, const double *b_e_n, double kappa_n, double eps_n,
-                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1);
+                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep);
 int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
                         const int *dofs2mask);
 void orc_roll_state(orc_particles *P);

@@ -34,7 +34,7 @@ _PFIELDS_D = ["x", "dis", "vel", "acc", "d_dis", "F_n", "F_n1", "DF", "stress", 
 class CParticles(C.Structure):
     _fields_ = ([("np", C.c_int), ("ndim", C.c_int), ("T", C.c_int)] + [(k, _dp) for k in _PFIELDS_D] +
                 [("matidx", _ip), ("I0", _ip), ("lambda_", _dp), ("beta", _dp), ("nn", _ip), ("list", _ip),
-                 ("status", _ip)])
+                 ("status", _ip), ("C_ep", _dp)])
 
 
 class Material(C.Structure):
@@ -148,6 +148,8 @@ class OracleParticles:
         a["stress"] = np.zeros((n, T))
         for k in ["dt_F_n", "dt_F_n1", "dt_DF"]:
             a[k] = np.zeros((n, T))
+        if cloud.get("dt_F_n") is not None:
+            a["dt_F_n"][:] = cloud["dt_F_n"]
         for k in ["J_n", "rho", "mass", "vol0", "kappa_n", "eps_n"]:
             a[k] = np.ascontiguousarray(cloud[k], dtype=np.float64).copy()
         a["J_n1"] = a["J_n"].copy()
@@ -161,6 +163,7 @@ class OracleParticles:
         a["nn"] = np.zeros(n, dtype=np.int32)
         a["list"] = np.full((n, MAXNB), -1, dtype=np.int32)
         a["status"] = np.zeros(n, dtype=np.int32)
+        a["C_ep"] = np.zeros((n, d * d))
         for k in ("I0", "lambda_", "beta"):
             src = "lambda" if k == "lambda_" else k
             if src in cloud and cloud[src] is not None:
@@ -168,7 +171,7 @@ class OracleParticles:
         self.a = a
         c = CParticles()
         c.np, c.ndim, c.T = n, d, T
-        for k in _PFIELDS_D + ["lambda_", "beta"]:
+        for k in _PFIELDS_D + ["lambda_", "beta", "C_ep"]:
             setattr(c, k, _d(a[k]))
         for k in ["matidx", "I0", "nn", "list", "status"]:
             setattr(c, k, _i(a[k]))
@@ -318,12 +321,12 @@ def stress_one(ndim, mat, prm, F_n1, DF, J, b_e_n, kappa_n, eps_n):
     e1 = C.c_double(0)
     f = lib().orc_stress_one
     f.argtypes = [C.c_int, C.POINTER(Material), C.POINTER(Params), _dp, _dp, C.c_double, _dp, C.c_double,
-                  C.c_double, _dp, _dp, _dp, _dp, _dp]
+                  C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]
     F_n1 = np.ascontiguousarray(F_n1, dtype=np.float64)
     DF = np.ascontiguousarray(DF, dtype=np.float64)
     b_e_n = np.ascontiguousarray(b_e_n, dtype=np.float64)
     st = f(ndim, C.byref(mat), C.byref(prm), _d(F_n1), _d(DF), float(J), _d(b_e_n), float(kappa_n),
-           float(eps_n), _d(stress), C.byref(W), _d(b1), C.byref(k1), C.byref(e1))
+           float(eps_n), _d(stress), C.byref(W), _d(b1), C.byref(k1), C.byref(e1), None)
     return st, stress, W.value, b1, k1.value, e1.value
 
 

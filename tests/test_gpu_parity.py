@@ -89,6 +89,10 @@ def test_stage_functions(ndim, material):
     case = small_case(ndim, material=material, velocity=vel)
     rng = np.random.default_rng(7)
     case["cloud"]["acc"][:] = rng.normal(size=case["cloud"]["acc"].shape)
+    T = 5 if ndim == 2 else 9
+    case["cloud"]["dt_F_n"] = 0.1 * rng.normal(size=(case["cloud"]["x"].shape[0], T))
+    if ndim == 2:
+        case["cloud"]["dt_F_n"][:, 4] = 0.0
     nsteps = 3
     bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
     M, P, prm, mats = oracle_setup(case)
@@ -121,17 +125,28 @@ def test_stage_functions(ndim, material):
     assert_close(V_g, V_o, TOL, "nodal velocity")
     assert_close(A_g, A_o, TOL, "nodal acceleration")
 
-    dU = 1e-3 * rng.normal(size=na * ndim)
-    assert o.compatibility(dU, None, P, M, n2m) == 0
-    S.local_compatibility_conditions(dU)
+    # a dU large enough that the Drucker-Prager particles leave the elastic range (all three tangent branches)
+    dU = (2e-2 if material["type"] == 2 else 1e-3) * rng.normal(size=na * ndim)
+    dUdt = 1e-1 * rng.normal(size=na * ndim)
+    assert o.compatibility(dU, dUdt, P, M, n2m) == 0
+    S.local_compatibility_conditions(dU, dUdt)
     assert o.constitutive(P, mats, prm) == 0
     S.constitutive_update()
     st = S.download_state()
-    for k, ok in (("DF", "DF"), ("F_n1", "F_n1"), ("J_n1", "J_n1"), ("Stress", "stress"), ("W", "W"),
-                  ("b_e_n1", "b_e_n1"), ("Kappa_n1", "kappa_n1"), ("EPS_n1", "eps_n1")):
-        if material["type"] != 2 and k in ("b_e_n1", "Kappa_n1", "EPS_n1"):
+    for k, ok in (("DF", "DF"), ("F_n1", "F_n1"), ("J_n1", "J_n1"), ("dt_DF", "dt_DF"), ("dt_F_n1", "dt_F_n1"),
+                  ("Stress", "stress"), ("W", "W"), ("b_e_n1", "b_e_n1"), ("Kappa_n1", "kappa_n1"),
+                  ("EPS_n1", "eps_n1"), ("C_ep", "C_ep")):
+        if material["type"] != 2 and k in ("b_e_n1", "Kappa_n1", "EPS_n1", "C_ep"):
             continue
         assert_close(st[k], P[ok], TOL, f"{k} after compatibility+constitutive")
+    assert np.abs(P["dt_F_n1"]).max() > 0
+    if material["type"] == 2:
+        plastic = np.count_nonzero(P["eps_n1"] > P["eps_n"])
+        assert 0 < plastic, "the case must exercise the plastic tangent"
+    # without dU_dt the rate tensors stay as they are (U-Static.c passes no rates)
+    S.local_compatibility_conditions(dU)
+    st2 = S.download_state()
+    assert np.array_equal(st2["dt_DF"], st["dt_DF"]) and np.array_equal(st2["F_n1"], st["F_n1"])
 
     R_o, s = o.internal_forces(P, M, n2m, d2m, na)
     assert s == 0
@@ -148,8 +163,37 @@ def test_stage_functions(ndim, material):
     S.update_particles_kinetics_FLIP_PIC(1.0, dU, V_g, dV, dA)
     st = S.download_state()
     for k, ok in (("x", "x"), ("dis", "dis"), ("vel", "vel"), ("acc", "acc"), ("F_n", "F_n"), ("J_n", "J_n"),
-                  ("rho", "rho")):
+                  ("rho", "rho"), ("dt_F_n", "dt_F_n")):
         assert_close(st[k], P[ok], TOL, f"{k} after roll+kinetics")
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("stretch", [0.05, 0.01, -0.02])
+def test_drucker_prager_return_branches(ndim, stretch):
+    """Uniform volumetric stretch fields (LME reproduces them exactly) drive every particle down one branch of
+    the return mapping: +5 % ends in the apex return (Drucker-Prager.c:532-590, whose tangent is all zeros
+    when the apex iteration backs off), the others in the classical return or the elastic range."""
+    o = orc()
+    case = small_case(ndim, material=DP)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=1)
+    n2m, d2m, na = masks(S, M, [], 0, 1)
+    X = M.coords().reshape(-1, ndim)
+    act = np.where(n2m >= 0)[0]
+    dU = np.zeros((na, ndim))
+    dU[n2m[act]] = stretch * (X[act] - X.mean(0))
+    dU = dU.ravel()
+    assert o.compatibility(dU, None, P, M, n2m) == 0
+    assert o.constitutive(P, mats, prm) == 0
+    S.local_compatibility_conditions(dU)
+    S.constitutive_update()
+    st = S.download_state()
+    for k, ok in (("DF", "DF"), ("Stress", "stress"), ("W", "W"), ("b_e_n1", "b_e_n1"), ("Kappa_n1", "kappa_n1"),
+                  ("EPS_n1", "eps_n1")):
+        assert_close(st[k], P[ok], TOL, f"{k} (stretch {stretch})")
+    assert_close(st["C_ep"], P["C_ep"], TOL, "C_ep", scale=DP["E"])
+    if stretch == 0.05:
+        assert np.all(P["C_ep"] == 0.0) and np.all(st["C_ep"] == 0.0), "apex branch expected"
 
 
 @pytest.mark.parametrize("ndim,material", [(2, NH), (3, NH), (2, HENCKY), (3, DP), (2, DP)])
