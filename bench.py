@@ -130,9 +130,11 @@ def main():
         nnodes = gn[0] * gn[1] * gn[2]
 
         def exchange(dptr, nfield, elem, kind):
-            return halo.exchange(halo_mod.device_tensor(torch, dptr, nnodes * nfield, elem), nfield, kind)
+            return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind)
 
         S.set_halo_exchange(exchange)
+        # per-step nodal work only on the layers this rank can touch (the grid grows with the rank count)
+        S.set_node_window(lo[rank], hi[rank])
     S.initialise_shapefun()
     dt = 0.1 * case["h"] / 100.0  # CFL 0.1, celerity sqrt(E/rho) = 100
 

@@ -201,6 +201,11 @@ int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
  * ranks (RCCL send/recv or all-reduce).  NULL = single GPU. */
 typedef int (*nlps_halo_fn)(void *ctx, void *dptr, int nfield, int elem_bytes, int kind);
 int nlps_gpu_set_halo_exchange(nlps_gpu *h, nlps_halo_fn fn, void *ctx);
+/* Promise that the 5^d stencils of this rank's particles stay inside node layers [layer_lo, layer_hi] of the
+ * slab (slowest) axis: the per-step nodal work of explicit_step / local_search (resets, nodal kernels, tile
+ * launches) is limited to that window instead of the whole grid, so a rank's cost does not grow with the number
+ * of ranks.  A particle that leaves the window raises status flag 16.  Default: the whole grid. */
+int nlps_gpu_set_node_window(nlps_gpu *h, int layer_lo, int layer_hi);
 /* Range of node layers along the slab axis this rank's particles may touch (5^d stencil reach). */
 int nlps_gpu_touched_layers(nlps_gpu *h, int *lo, int *hi);
 

@@ -78,7 +78,10 @@ static constexpr int BLK = 256;
 
 struct TileCnt {
   int nt[3];
-  int* count;  // [ntiles] particles per tile, nullptr = no binning
+  int* count;       // [ntiles] particles per tile, nullptr = no binning
+  int tile0, ntw;   // tiles of the node window (nlps_gpu_set_node_window); default: all
+  int win_lo, win_hi, plane;  // node layers (slowest axis) of the window, nodes per layer
+  int* gstatus;
 };
 template <int ND>
 struct TileCfg;
@@ -95,7 +98,19 @@ template <int ND>
 __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, const TileCnt& tc, int p, int I0,
                                              bool valid) {
   if (!tc.count) return;
-  const int t = valid ? tile_of_node<ND>(g, tc.nt, I0) : -1;
+  int t = valid ? tile_of_node<ND>(g, tc.nt, I0) : -1;
+  if (valid) {  // the 5^d stencil of I0 must stay inside this rank's node window
+    const int layer = I0 / tc.plane, nl = g.n[ND - 1];
+    const int s_lo = layer - 2 < 0 ? 0 : layer - 2, s_hi = layer + 2 > nl - 1 ? nl - 1 : layer + 2;
+    if (s_lo < tc.win_lo || s_hi > tc.win_hi) {
+      atomicOr(&P.status[p], ST_HALO);
+      atomicOr(tc.gstatus, ST_HALO);
+    }
+    if (t < tc.tile0 || t >= tc.tile0 + tc.ntw) {  // not binned: its tile is never launched
+      t = -1;
+      valid = false;
+    }
+  }
   const int lane = threadIdx.x & 63;
   int rank = valid ? -1 : 0;
   while (true) {
@@ -110,8 +125,8 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
     base = __shfl(base, leader);
     if (mine) rank = base + (int)__popcll(same & ((1ull << lane) - 1ull));
   }
-  if (valid) {
-    P.tile[p] = t;
+  if (p < P.np) {
+    P.tile[p] = t;  // -1: not binned (failed element search or outside the node window)
     P.rank[p] = rank;
   }
 }
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N, Tile
     }
     if (!found) {
       atomicOr(&P.status[p], ST_CONNECT);
+      atomicOr(tc.gstatus, ST_CONNECT);  // the particle is not binned, so no later kernel would report it
       valid = false;
     } else {
       // connectivity chain = reverse GiD file order (Read-GID-Mesh.c:411-413): rank of corner (a,b,t)
@@ -412,9 +428,10 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
 // nodal kernels (grid numbering)
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ void k_nodal_dU(int nnodes, NView N) {  // U-Verlet.c:357-362
+__global__ void k_nodal_dU(int n0, int nnodes, NView N) {  // U-Verlet.c:357-362
   int A = blockIdx.x * blockDim.x + threadIdx.x;
   if (A >= nnodes) return;
+  A += n0;
   bool act = N.active[A];
   double M = N.nm[(size_t)A * (1 + ND)];
 #pragma unroll
@@ -438,9 +455,10 @@ __global__ void k_bc(const int* __restrict__ nodes, int n, int dim, int dirbits,
 }
 
 template <int ND>
-__global__ void k_nodal_accel(int nnodes, NView N, double g0, double g1, double g2) {  // U-Verlet.c:947-957
+__global__ void k_nodal_accel(int n0, int nnodes, NView N, double g0, double g1, double g2) {  // U-Verlet.c:947-957
   int A = blockIdx.x * blockDim.x + threadIdx.x;
   if (A >= nnodes) return;
+  A += n0;
   bool act = N.active[A];
   double M = N.nm[(size_t)A * (1 + ND)];
   double gv[3] = {g0, g1, g2};
@@ -663,6 +681,9 @@ struct nlps_gpu {
   hipEvent_t ev[8];
   float ms[8];
   int slab_lo, slab_hi;
+  int win_lo, win_hi;  // node window (layers of the slowest axis) the per-step nodal work is limited to
+  int n0, nwn;         // first node / node count of the window
+  int tile0, ntw;      // first tile / tile count of the window
 };
 
 #define HIPCHK(call)                                                                         \
@@ -795,6 +816,41 @@ extern "C" int nlps_gpu_set_halo_exchange(nlps_gpu* h, nlps_halo_fn fn, void* ct
   return 0;
 }
 
+static void apply_window(nlps_gpu* h, int lo, int hi) {
+  const int nd = h->nd, nl = h->g.n[nd - 1], plane = h->g.nnodes / nl;
+  const int TB = nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
+  const int tiles_per_layer = h->ntiles / h->nt[nd - 1];
+  h->win_lo = lo;
+  h->win_hi = hi;
+  h->n0 = lo * plane;
+  h->nwn = (hi - lo + 1) * plane;
+  h->tile0 = (lo / TB) * tiles_per_layer;
+  h->ntw = (hi / TB - lo / TB + 1) * tiles_per_layer;
+}
+
+extern "C" int nlps_gpu_set_node_window(nlps_gpu* h, int layer_lo, int layer_hi) {
+  const int nl = h->g.n[h->nd - 1];
+  if (layer_lo < 0 || layer_hi >= nl || layer_lo > layer_hi) {
+    h->err = "nlps_gpu_set_node_window: layers outside the grid";
+    return 1;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  apply_window(h, layer_lo, layer_hi);
+  // clean slate outside the new window (nothing resets those nodes any more)
+  const size_t nn = (size_t)h->g.nnodes, ND = (size_t)h->nd;
+  HIPCHK(hipMemsetAsync(h->N.active, 0, nn, h->stream));
+  HIPCHK(hipMemsetAsync(h->N.nm, 0, nn * (1 + ND) * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.dU, 0, nn * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.force, 0, nn * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.accel, 0, nn * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.reaction, 0, nn * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.fixed, 0, nn * ND, h->stream));
+  HIPCHK(hipMemsetAsync(h->tile_count_d, 0, ((size_t)h->ntiles + 1) * sizeof(int), h->stream));
+  h->masks_valid = false;
+  h->binned = false;
+  return 0;
+}
+
 extern "C" int nlps_gpu_touched_layers(nlps_gpu* h, int* lo, int* hi) {
   *lo = h->slab_lo;
   *hi = h->slab_hi;
@@ -888,6 +944,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     for (int a = 0; a < 3; a++) h->nt[a] = a < g.nd ? (g.n[a] + TB - 1) / TB : 1;
     h->ntiles = h->nt[0] * h->nt[1] * h->nt[2];
   }
+  apply_window(h, 0, g.n[g.nd - 1] - 1);
   h->hprm = *prm;
   h->prm.gamma_lme = prm->gamma_lme;
   h->prm.neg_log_tol_zero = -log(prm->tol_zero_lme);
@@ -1246,12 +1303,19 @@ static TileCnt tile_cnt(nlps_gpu* h, bool on) {
   TileCnt tc;
   for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
   tc.count = on ? h->tile_count_d : nullptr;
+  tc.tile0 = h->tile0;
+  tc.ntw = h->ntw;
+  tc.win_lo = h->win_lo;
+  tc.win_hi = h->win_hi;
+  tc.plane = h->g.nnodes / h->g.n[h->nd - 1];
+  tc.gstatus = h->gstatus_d;
   return tc;
 }
 static TileD tile_view(nlps_gpu* h) {
   TileD td;
   for (int a = 0; a < 3; a++) td.nt[a] = h->nt[a];
   td.ntiles = h->ntiles;
+  td.tile0 = h->tile0;
   td.start = h->tile_start_d;
   td.count = h->tile_count_d;
   td.order = h->order_d;
@@ -1262,20 +1326,21 @@ static TileD tile_view(nlps_gpu* h) {
 // beta and the Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`, tiled form only)
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm) {
   int np = h->P.np;
-  HIPCHK(hipMemsetAsync(h->N.active, 0, (size_t)h->g.nnodes, h->stream));  // Shape-Functions.c:38-46
-  HIPCHK(hipMemsetAsync(h->tile_count_d, 0, ((size_t)h->ntiles + 1) * sizeof(int), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.active + h->n0, 0, (size_t)h->nwn, h->stream));  // Shape-Functions.c:38-46
+  HIPCHK(hipMemsetAsync(h->tile_count_d + h->tile0, 0, (size_t)h->ntw * sizeof(int), h->stream));
   TileCnt tc = tile_cnt(h, true);
   if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
   else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d, h->tile_start_d, h->ntiles);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d + h->tile0,
+                     h->tile_start_d + h->tile0, h->ntw);
   hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                      h->order_d);
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.active, 1, 1, 1)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   TileD td = tile_view(h);
-  const dim3 grid(h->ntiles * K2_SPLIT), blk(BLK);
+  const dim3 grid(h->ntw * K2_SPLIT), blk(BLK);
   if (h->nd == 2) {
     if (p2g) hipLaunchKernelGGL((k2_tile<2, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
     else hipLaunchKernelGGL((k2_tile<2, false>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
@@ -1295,7 +1360,7 @@ static int check_status(nlps_gpu* h, int fatal_mask, const char* where) {
   HIPCHK(hipMemcpy(&st, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost));
   if (st & fatal_mask) {
     char buf[160];
-    snprintf(buf, sizeof buf, "Error in %s: particle failure flags 0x%x (1 Newton, 2 connectivity, 4 J<=0, 8 law)",
+    snprintf(buf, sizeof buf, "Error in %s: particle failure flags 0x%x (1 Newton, 2 connectivity, 4 J<=0, 8 law, 16 outside node window)",
              where, st);
     h->err = buf;
     fprintf(stderr, "\033[1;31m%s\033[0m\n", buf);
@@ -1310,13 +1375,13 @@ extern "C" int nlps_gpu_initialize_lme(nlps_gpu* h) {
   HIPCHK(hipMemsetAsync(h->P.d + (size_t)F_LAM * h->P.npad, 0, 7 * h->P.npad * sizeof(double), h->stream));
   if (search_and_lists(h, true, false, 0.0, 0.0)) return 1;
   if (compute_node_mask(h)) return 1;
-  return check_status(h, ST_NEWTON | ST_CONNECT, "initialize__LME__()");
+  return check_status(h, ST_NEWTON | ST_CONNECT | ST_HALO, "initialize__LME__()");
 }
 
 extern "C" int nlps_gpu_local_search(nlps_gpu* h) {
   if (search_and_lists(h, false, false, 0.0, 0.0)) return 1;
   if (compute_node_mask(h)) return 1;
-  return check_status(h, ST_NEWTON | ST_CONNECT, "local_search__LME__()");
+  return check_status(h, ST_NEWTON | ST_CONNECT | ST_HALO, "local_search__LME__()");
 }
 
 static int ensure_bcs(nlps_gpu* h, const nlps_bcc* bcc, int nbcc) {
@@ -1433,8 +1498,8 @@ extern "C" int nlps_gpu_lumped_mass(nlps_gpu* h, double* M) {
   HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * sizeof(double), h->stream));
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL((kb_p2g_tile<2, 0>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
-    else hipLaunchKernelGGL((kb_p2g_tile<3, 0>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+    if (ND == 2) hipLaunchKernelGGL((kb_p2g_tile<2, 0>), dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+    else hipLaunchKernelGGL((kb_p2g_tile<3, 0>), dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->gridA, 1, 8, 0)) return 1;
@@ -1447,8 +1512,8 @@ extern "C" int nlps_gpu_nodal_field_n(nlps_gpu* h, double* V, double* A, const d
   HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * 2 * ND * sizeof(double), h->stream));
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL((kb_p2g_tile<2, 1>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
-    else hipLaunchKernelGGL((kb_p2g_tile<3, 1>), dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+    if (ND == 2) hipLaunchKernelGGL((kb_p2g_tile<2, 1>), dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
+    else hipLaunchKernelGGL((kb_p2g_tile<3, 1>), dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, h->gridA);
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->gridA, 2 * ND, 8, 0)) return 1;
@@ -1462,7 +1527,7 @@ extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const doubl
   if (dU_dt && to_grid(h, h->gridB, dU_dt, h->nd)) return 1;
   if (dU_dt) h->level_b_fields = true;
   TileD td = tile_view(h);
-  const dim3 grid(h->ntiles * K3_SPLIT), blk(BLK);
+  const dim3 grid(h->ntw * K3_SPLIT), blk(BLK);
   const double* dV = dU_dt ? h->gridB : nullptr;
   if (h->nd == 2) {
     if (dV) hipLaunchKernelGGL((k3_tile<2, 0, 2>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, dV);
@@ -1488,8 +1553,8 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL(kb_fint_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->N.force, h->gstatus_d);
-    else hipLaunchKernelGGL(kb_fint_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, h->N.force, h->gstatus_d);
+    if (ND == 2) hipLaunchKernelGGL(kb_fint_tile<2>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, h->N.force, h->gstatus_d);
+    else hipLaunchKernelGGL(kb_fint_tile<3>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, h->N.force, h->gstatus_d);
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.force, ND, 8, 0)) return 1;
@@ -1513,8 +1578,8 @@ extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const d
   if (to_grid(h, h->gridB + 3 * st, dU_dt2, ND)) return 1;
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL(kb_kinetics_tile<2>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
-    else hipLaunchKernelGGL(kb_kinetics_tile<3>, dim3(h->ntiles), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
+    if (ND == 2) hipLaunchKernelGGL(kb_kinetics_tile<2>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
+    else hipLaunchKernelGGL(kb_kinetics_tile<3>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -1522,23 +1587,24 @@ extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const d
 
 extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, double dt, double gamma_nm,
                                       const double* gravity) {
-  int ND = h->nd, nn = h->g.nnodes;
+  int ND = h->nd;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
   if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
     if (resort(h)) return 1;
   }
   h->steps_since_sort++;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  HIPCHK(hipMemsetAsync(h->N.nm, 0, (size_t)nn * (1 + ND) * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)nn * ND * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->N.fixed, 0, (size_t)nn * ND, h->stream));
+  const size_t n0 = (size_t)h->n0, nw = (size_t)h->nwn;  // node window: all nodes on a single GPU
+  HIPCHK(hipMemsetAsync(h->N.nm + n0 * (1 + ND), 0, nw * (1 + ND) * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.force + n0 * ND, 0, nw * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->N.fixed + n0 * ND, 0, nw * ND, h->stream));
   // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel)
   if (search_and_lists(h, false, true, dt, gamma_nm)) return 1;
   if (halo(h, h->N.nm, 1 + ND, 8, 0)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
   // nodal: dU = (sum m N dD) / M, Dirichlet values
-  if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N);
-  else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N);
+  if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N);
+  else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N);
   for (int i = 0; i < nbcc; i++) {
     if (h->bcs[i].n == 0) continue;
     double v[3] = {0, 0, 0};
@@ -1557,7 +1623,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   {
     TileD td = tile_view(h);
 #define NLPS_K3(NDv, LAWv)                                                                                      \
-  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntiles * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d, (const double*)nullptr)
     const int law = h->uniform_law;
     if (ND == 2) {
@@ -1579,14 +1645,14 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   double gv[3] = {0, 0, 0};
   if (gravity)
     for (int a = 0; a < ND; a++) gv[a] = gravity[a];
-  if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N, gv[0], gv[1], gv[2]);
-  else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, nn, h->N, gv[0], gv[1], gv[2]);
+  if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N, gv[0], gv[1], gv[2]);
+  else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N, gv[0], gv[1], gv[2]);
   if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
   // S5
   {
     TileD td = tile_view(h);
 #define NLPS_K5(NDv, LAWv) \
-  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntiles * K5_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
+  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
     const int law = h->uniform_law;
     if (ND == 2) {
       if (law == 0 || law == 1) NLPS_K5(2, 0);
@@ -1636,5 +1702,5 @@ extern "C" int nlps_gpu_explicit_nodal(nlps_gpu* h, double* mass, double* dU, do
   if (force && from_grid(h, force, h->N.force, ND, ND, 0, 0, 0, nullptr)) return 1;
   if (accel && from_grid(h, accel, h->N.accel, ND, ND, 0, 0, 0, nullptr)) return 1;
   if (reaction && from_grid(h, reaction, h->N.reaction, ND, ND, 0, 0, 0, nullptr)) return 1;
-  return check_status(h, ST_NEWTON | ST_CONNECT | ST_JACOBIAN | ST_CONSTITUTIVE, "nlps_gpu_explicit_step()");
+  return check_status(h, ST_NEWTON | ST_CONNECT | ST_JACOBIAN | ST_CONSTITUTIVE | ST_HALO, "nlps_gpu_explicit_step()");
 }

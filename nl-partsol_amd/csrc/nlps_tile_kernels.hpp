@@ -34,6 +34,7 @@ static constexpr int K2_SPLIT = 2, K3_SPLIT = 1, K5_SPLIT = 1;
 struct TileD {
   int nt[3];
   int ntiles;
+  int tile0;  // first tile of the launched range (node window)
   const int* start;
   const int* count;
   const int* order;
@@ -108,7 +109,7 @@ __global__ void k_tile_scan(const int* __restrict__ count, int* __restrict__ sta
 __global__ void k_fill_order(int np, const int* __restrict__ tile, const int* __restrict__ rank,
                              const int* __restrict__ start, int* __restrict__ order) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= np) return;
+  if (p >= np || tile[p] < 0) return;
   order[start[tile[p]] + rank[p]] = p;
 }
 
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
   constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NW];
   __shared__ unsigned actrow[NROWS];
-  const int tile = blockIdx.x / K2_SPLIT, part = blockIdx.x % K2_SPLIT;
+  const int tile = td.tile0 + blockIdx.x / K2_SPLIT, part = blockIdx.x % K2_SPLIT;
   const int cnt = td.count[tile];
   if (cnt <= part * BLK) return;
   int w0[3];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
   __shared__ __attribute__((aligned(16))) double duxy[2 * NW];
   __shared__ double duz[(ND == 3) ? NW : 1];
   __shared__ double fac[ND * NW];
-  const int tile = blockIdx.x / K3_SPLIT, part = blockIdx.x % K3_SPLIT;
+  const int tile = td.tile0 + blockIdx.x / K3_SPLIT, part = blockIdx.x % K3_SPLIT;
   const int cnt = td.count[tile];
   if (cnt <= part * BLK) return;
   int w0[3];
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
   constexpr int NV = 2 * ND;           // values per node: dU[ND], accel[ND]
   constexpr int NP = (NV + 1) / 2;     // double2 per node (2-D: 2, 3-D: 3)
   __shared__ __attribute__((aligned(16))) double win[NW * 2 * NP];
-  const int tile = blockIdx.x / K5_SPLIT, part = blockIdx.x % K5_SPLIT;
+  const int tile = td.tile0 + blockIdx.x / K5_SPLIT, part = blockIdx.x % K5_SPLIT;
   const int cnt = td.count[tile];
   if (cnt <= part * BLK) return;
   int w0[3];
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(BLK) void kb_p2g_tile(PView P, GridD g, TileD td, d
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NF = MODE == 0 ? 1 : 2 * ND;
   __shared__ double acc[NF * NW];
-  const int tile = blockIdx.x;
+  const int tile = td.tile0 + blockIdx.x;
   const int cnt = td.count[tile];
   if (cnt == 0) return;
   int w0[3];
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(BLK) void kb_fint_tile(PView P, GridD g, TileD td, 
                                                     int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double fac[ND * NW];
-  const int tile = blockIdx.x;
+  const int tile = td.tile0 + blockIdx.x;
   const int cnt = td.count[tile];
   if (cnt == 0) return;
   int w0[3];
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD 
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NV = 4 * ND, NP = NV / 2;
   __shared__ __attribute__((aligned(16))) double win[NW * NV];
-  const int tile = blockIdx.x;
+  const int tile = td.tile0 + blockIdx.x;
   const int cnt = td.count[tile];
   if (cnt == 0) return;
   int w0[3];

@@ -15,7 +15,7 @@ class SlabHalo:
         self.torch, self.dist, self.rank, self.world, self.mode = torch, dist, rank, world, mode
         self.plane, self.nz = int(plane_nodes), int(nlayers)
         self.lo, self.hi = list(lo), list(hi)
-        self.bufs = {}
+        self.plans, self.tensors = {}, {}
         for r in range(world - 2):
             if self.hi[r] >= self.lo[r + 2]:
                 raise ValueError("slabs too thin: rank %d overlaps rank %d" % (r, r + 2))
@@ -40,6 +40,39 @@ class SlabHalo:
         if self.mode == "allreduce":
             dist.all_reduce(arr, op=dist.ReduceOp.SUM if kind == 0 else dist.ReduceOp.MAX)
             return 0
+        if arr.is_cuda and dist.get_backend() == "gloo":
+            return self._exchange_staged(arr, nfield, kind)
+        plan = self.plans.get((arr.data_ptr(), nfield, kind))
+        if plan is None:  # slices, receive buffers and P2P descriptors are built once per nodal array
+            ops, recv = [], []
+            for nb in (self.rank - 1, self.rank + 1):
+                if nb < 0 or nb >= self.world:
+                    continue
+                ov = self.overlap(self.rank, nb)
+                if ov is None:
+                    continue
+                sl = arr[ov[0] * self.plane * nfield:(ov[1] + 1) * self.plane * nfield]
+                rbuf = torch.empty_like(sl)
+                ops.append(dist.P2POp(dist.isend, sl, nb))  # the slice is contiguous: sent in place
+                ops.append(dist.P2POp(dist.irecv, rbuf, nb))
+                recv.append((sl, rbuf))
+            plan = (ops, recv, arr)
+            self.plans[(arr.data_ptr(), nfield, kind)] = plan
+        ops, recv, _ = plan
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for sl, rbuf in recv:  # after the sends completed (stream order), so the neighbour got the unsummed slice
+            if kind == 0:
+                sl.add_(rbuf)
+            else:
+                torch.maximum(sl, rbuf, out=sl)
+        return 0
+
+    def _exchange_staged(self, arr, nfield, kind):
+        """Device arrays over a CPU-only backend (gloo): the halo slices go through host memory.  Only for
+        rehearsing the N > 1 path on a box without one GPU per rank; RCCL never takes this branch."""
+        torch, dist = self.torch, self.dist
         ops, recv = [], []
         for nb in (self.rank - 1, self.rank + 1):
             if nb < 0 or nb >= self.world:
@@ -48,23 +81,29 @@ class SlabHalo:
             if ov is None:
                 continue
             sl = arr[ov[0] * self.plane * nfield:(ov[1] + 1) * self.plane * nfield]
-            key = (nb, nfield, arr.dtype)
-            if key not in self.bufs:
-                self.bufs[key] = (torch.empty_like(sl), torch.empty_like(sl))
-            sbuf, rbuf = self.bufs[key]
-            sbuf.copy_(sl)
-            ops.append(dist.P2POp(dist.isend, sbuf, nb))
-            ops.append(dist.P2POp(dist.irecv, rbuf, nb))
-            recv.append((sl, rbuf))
+            s_host = sl.cpu()
+            r_host = torch.empty_like(s_host)
+            ops.append(dist.P2POp(dist.isend, s_host, nb))
+            ops.append(dist.P2POp(dist.irecv, r_host, nb))
+            recv.append((sl, r_host))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        for sl, rbuf in recv:
+        for sl, r_host in recv:
+            r = r_host.to(sl.device)
             if kind == 0:
-                sl.add_(rbuf)
+                sl.add_(r)
             else:
-                torch.maximum(sl, rbuf, out=sl)
+                torch.maximum(sl, r, out=sl)
         return 0
+
+    def exchange_ptr(self, dptr, nelem, nfield, elem_bytes, kind):
+        """Entry point for the C callback: wraps the raw device pointer once and reuses the tensor."""
+        t = self.tensors.get((dptr, nelem, elem_bytes))
+        if t is None:
+            t = device_tensor(self.torch, dptr, nelem, elem_bytes)
+            self.tensors[(dptr, nelem, elem_bytes)] = t
+        return self.exchange(t, nfield, kind)
 
 
 def device_tensor(torch, dptr, n, elem_bytes):

@@ -64,7 +64,8 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
+           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window",
+           "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
 
 
 def lib():
@@ -87,6 +88,7 @@ def lib():
         L.nlps_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Grid), C.POINTER(Params),
                                       C.POINTER(Material), C.c_int, C.POINTER(Particles), C.c_int, C.c_void_p]
         L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
+        L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
         for name in ["nlps_gpu_destroy", "nlps_gpu_synchronize", "nlps_gpu_initialize_lme", "nlps_gpu_resort",
                      "nlps_gpu_local_search", "nlps_gpu_constitutive", "nlps_gpu_roll_state"]:
             getattr(L, name).argtypes = [C.c_void_p]
@@ -366,6 +368,9 @@ class Solver:
         lo, hi = C.c_int(0), C.c_int(0)
         self._chk(self.L.nlps_gpu_touched_layers(self.h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def set_node_window(self, layer_lo, layer_hi):
+        self._chk(self.L.nlps_gpu_set_node_window(self.h, int(layer_lo), int(layer_hi)))
 
     def set_timing(self, on=True):
         self._chk(self.L.nlps_gpu_set_timing(self.h, 1 if on else 0))

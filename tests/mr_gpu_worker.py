@@ -1,0 +1,96 @@
+"""Worker of tests/test_gpu_parity.py::test_multirank_on_one_gpu (launched by torch.distributed.run).
+
+Every rank drives the HIP library on the SAME card for its slab of a z-stacked cloud, with the ghost-node
+exchange of nl-partsol_amd/halo.py behind the C-ABI halo callback (gloo + host staging, because RCCL needs
+one GPU per rank) and the node window bench.py sets for N > 1.  Rank 0 also runs the whole cloud in one
+solver; the partitioned result has to match it: index maps bit for bit, fields to 1e-11."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CELLS, MARGIN, NSTEPS = 8, 5, 4
+
+
+def rank_cloud(synth, rank, world):
+    gc = [CELLS + 2 * MARGIN, CELLS + 2 * MARGIN, CELLS * world + 2 * MARGIN]
+    lo = [MARGIN, MARGIN, MARGIN + CELLS * rank]
+    return gc, synth.make_cloud(3, gc, lo, [CELLS] * 3, h=1.0, jitter=0.05, seed=777 + rank,
+                                velocity=[1.0, 0.5, -10.0])
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch
+    import torch.distributed as dist
+    import util
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nlps = util.nlps()
+    synth = util.synth
+    halo_mod = importlib.import_module("nl-partsol_amd.halo")
+    gc, cloud = rank_cloud(synth, rank, world)
+    gn = synth.grid_nodes(gc)
+    mats = [util.NH]
+    bc = {"nodes": synth.plane_nodes(gn, 2, MARGIN + 1), "dim": 3, "dir": np.ones((3, NSTEPS), dtype=np.int32),
+          "value": np.zeros((3, NSTEPS))}
+    dt = 0.4 / 100.0
+    stream = torch.cuda.current_stream().cuda_stream
+    S = nlps.Solver(3, gn, [0.0] * 3, 1.0, cloud, mats, nsteps=NSTEPS, stream=stream)
+    lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[2], reach=3)
+    halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi)
+    nnodes = gn[0] * gn[1] * gn[2]
+    S.set_halo_exchange(lambda dptr, nfield, elem, kind: halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind))
+    S.set_node_window(lo[rank], hi[rank])
+    S.set_resort_interval(2)
+    S.initialise_shapefun()
+    gb = nlps.BccSet([bc])
+    for t in range(NSTEPS):
+        S.explicit_step(gb, t, dt)
+    assert S.status_flags() == 0
+    st = S.download_state()
+    nn, lst = S.download_lists()
+    mine = {k: st[k] for k in ("x", "vel", "acc", "Stress", "F_n", "I0", "lambda")}
+    mine["nn"] = nn
+    mine["active"] = S.download_active()
+    parts = [None] * world
+    dist.gather_object(mine, parts if rank == 0 else None, dst=0)
+    ok = True
+    if rank == 0:
+        clouds = [rank_cloud(synth, r, world)[1] for r in range(world)]
+        whole = {}
+        for k, v in clouds[0].items():
+            whole[k] = np.concatenate([c[k] for c in clouds]) if isinstance(v, np.ndarray) else v
+        G = nlps.Solver(3, gn, [0.0] * 3, 1.0, whole, mats, nsteps=NSTEPS)
+        G.set_resort_interval(2)
+        G.initialise_shapefun()
+        for t in range(NSTEPS):
+            G.explicit_step(gb, t, dt)
+        assert G.status_flags() == 0
+        ref = G.download_state()
+        rnn, _ = G.download_lists()
+        for k in ("I0",):
+            got = np.concatenate([p[k] for p in parts])
+            assert np.array_equal(got, ref[k]), k
+        assert np.array_equal(np.concatenate([p["nn"] for p in parts]), rnn), "NumberNodes"
+        act = np.zeros_like(parts[0]["active"])
+        for p in parts:
+            act |= p["active"]
+        assert np.array_equal(act, G.download_active()), "ActiveNode (union over ranks)"
+        for k in ("x", "vel", "acc", "Stress", "F_n", "lambda"):
+            got = np.concatenate([p[k] for p in parts])
+            util.assert_close(got, ref[k], 1e-11 if k != "lambda" else 1e-9, "%s partitioned vs whole" % k)
+        assert np.abs(ref["Stress"]).max() > 1.0, "the case must deform"
+        print("MULTIRANK_GPU_OK world=%d particles=%d" % (world, ref["x"].shape[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -342,6 +342,76 @@ def test_halo_callback_and_rccl_on_library_memory():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_multirank_on_one_gpu(world):
+    """N > 1 rehearsal on the one card of the test box: `world` processes, each with its slab, the halo
+    callback, the node window and periodic re-sorts, against one solver holding the whole cloud
+    (tests/mr_gpu_worker.py; gloo with host staging stands in for RCCL, which needs one GPU per rank)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() + world) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mr_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_node_window(ndim):
+    """nlps_gpu_set_node_window limits the per-step nodal work to the layers a rank can touch: the same
+    steps with a tight window and with the whole grid agree with the oracle and with each other, indices
+    bit for bit; a window the particles do not fit in raises status flag 16 instead of corrupting memory."""
+    o = orc()
+    n = nlps()
+    vel = [2.0, -10.0] if ndim == 2 else [2.0, 1.0, -10.0]
+    if ndim == 2:
+        case = make_case(2, [14, 40], [3, 20], [7, 8], velocity=vel)
+    else:
+        case = make_case(3, [11, 10, 30], [3, 3, 14], [5, 4, 6], velocity=vel)
+    nsteps = 4
+    # one Dirichlet plane through the cloud (real deformation) and one outside the window (must be ignored)
+    bcs_list = [dirichlet_plane(case, ndim - 1, 21 if ndim == 2 else 15, nsteps),
+                dirichlet_plane(case, ndim - 1, 0, nsteps)]
+    dt = 0.4 * case["h"] / 100.0
+    M, P, prm, mats = oracle_setup(case)
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps)
+    gb = n.BccSet(bcs_list)
+    S = gpu_setup(case, init=False, nsteps=nsteps)
+    lo, hi = S.touched_layers()
+    assert lo > 0 and hi < case["grid_n"][ndim - 1] - 1
+    S.set_node_window(lo, hi)
+    S.initialise_shapefun()
+    Sf = gpu_setup(case, nsteps=nsteps)
+    for t in range(nsteps):
+        assert stepper.step(t, dt) == 0
+        S.explicit_step(gb, t, dt)
+        Sf.explicit_step(gb, t, dt)
+    assert S.status_flags() == 0
+    a, b = S.download_state(), Sf.download_state()
+    assert np.array_equal(a["I0"], P["I0"]) and np.array_equal(a["I0"], b["I0"])
+    nn, lst = S.download_lists()
+    assert np.array_equal(nn, P["nn"]) and lists_equal(nn, lst, P["list"])
+    assert np.array_equal(S.download_active(), M.active())
+    for k, ok in (("x", "x"), ("vel", "vel"), ("Stress", "stress"), ("F_n", "F_n")):
+        assert_close(a[k], P[ok], 1e-9, f"{k} with node window")
+        assert_close(a[k], b[k], 1e-12, f"{k} window vs whole grid")
+    na = S.explicit_nodal()
+    nb = Sf.explicit_nodal()
+    assert S.nactive == Sf.nactive
+    assert_close(na["mass"], nb["mass"], 1e-12, "nodal mass window vs whole grid")
+    # a window that cuts into the cloud: flagged, and the step still terminates
+    S3 = gpu_setup(case, init=False, nsteps=nsteps)
+    S3.set_node_window(lo + 4, hi)
+    try:
+        S3.initialise_shapefun()
+        S3.explicit_step(gb, 0, dt)
+    except n.NlpsError:
+        pass
+    assert S3.status_flags() & 16
+
+
 @pytest.mark.parametrize("ndim", [2, 3])
 def test_shuffled_upload_and_periodic_resort(ndim):
     """Caller's particle order is arbitrary (shuffled here); the device keeps its own tile-major order,
