@@ -672,6 +672,8 @@ struct nlps_gpu {
   int nt[3], ntiles;
   int* tile_count_d;
   int* tile_start_d;
+  int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
+  int* nwork_d = nullptr;
   int* order_d;
 
   nlps_halo_fn halo;
@@ -1051,6 +1053,9 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->order_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->tile_count_d, (size_t)h->ntiles + 1)) return 1;
   if (dev_alloc(h, &h->tile_start_d, (size_t)h->ntiles + 1)) return 1;
+  if (dev_alloc(h, &h->work1_d, (size_t)h->ntiles)) return 1;
+  if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
+  if (dev_alloc(h, &h->nwork_d, 2)) return 1;
   {
     std::vector<double> tmp(h->P.npad);
     int T = h->T;
@@ -1166,7 +1171,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1316,6 +1321,9 @@ static TileD tile_view(nlps_gpu* h) {
   for (int a = 0; a < 3; a++) td.nt[a] = h->nt[a];
   td.ntiles = h->ntiles;
   td.tile0 = h->tile0;
+  td.work[0] = h->work1_d;
+  td.work[1] = h->work2_d;
+  td.nwork = h->nwork_d;
   td.start = h->tile_start_d;
   td.count = h->tile_count_d;
   td.order = h->order_d;
@@ -1333,7 +1341,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d + h->tile0,
-                     h->tile_start_d + h->tile0, h->ntw);
+                     h->tile_start_d + h->tile0, h->ntw, h->tile0, h->work1_d, h->work2_d, h->nwork_d);
   hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                      h->order_d);
   HIPCHK(hipGetLastError());

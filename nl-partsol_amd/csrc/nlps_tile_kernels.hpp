@@ -38,6 +38,12 @@ struct TileD {
   const int* start;
   const int* count;
   const int* order;
+  // compacted work lists (k_tile_scan): work[S-1][b] = (tile, part) for the b-th workgroup of a kernel that
+  // splits a tile's particles over S workgroups, only for non-empty (tile, part) pairs; nwork[S-1] entries.
+  // Consecutive workgroups go to different XCDs, so a compacted list spreads the populated tiles evenly over
+  // the 8 XCDs whatever the shape of the cloud (tile-index order left XCDs 23 % apart for the cube).
+  const int2* work[2];
+  const int* nwork;
 };
 
 template <int ND>
@@ -85,24 +91,49 @@ __device__ __forceinline__ int window_base(const int* ijk, const int* w0) {
   return (ijk[0] - w0[0]) + W * (ijk[1] - w0[1]) + (ND == 3 ? PS * (ijk[2] - w0[2]) : 0);
 }
 
-// exclusive scan of the per-tile particle counts (one 1024-thread block)
-__global__ void k_tile_scan(const int* __restrict__ count, int* __restrict__ start, int n) {
-  __shared__ int sh[1024];
-  int chunk = (n + 1023) / 1024;
-  int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0;
-  for (int q = lo; q < hi; q++) c += count[q];
-  sh[threadIdx.x] = c;
+// block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive prefix, *total = sum
+__device__ __forceinline__ int block_scan_1024(int v, int* sh, int* total) {
+  __syncthreads();
+  sh[threadIdx.x] = v;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    int v = ((int)threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+    int t = ((int)threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
     __syncthreads();
-    sh[threadIdx.x] += v;
+    sh[threadIdx.x] += t;
     __syncthreads();
   }
-  int run = sh[threadIdx.x] - c;
+  *total = sh[1023];
+  return sh[threadIdx.x] - v;
+}
+
+// exclusive scan of the per-tile particle counts + the compacted work lists (one 1024-thread block).
+// count/start are already offset to the first tile of the node window; tile0 = that tile's index.
+__global__ void k_tile_scan(const int* __restrict__ count, int* __restrict__ start, int n, int tile0,
+                            int2* __restrict__ work1, int2* __restrict__ work2, int* __restrict__ nwork) {
+  __shared__ int sh[1024];
+  int chunk = (n + 1023) / 1024;
+  int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0, n1 = 0, n2 = 0;
   for (int q = lo; q < hi; q++) {
+    const int cq = count[q];
+    c += cq;
+    n1 += cq > 0;
+    n2 += (cq > 0) + (cq > BLK);
+  }
+  int tot;
+  int run = block_scan_1024(c, sh, &tot);
+  int r1 = block_scan_1024(n1, sh, &tot);
+  if (threadIdx.x == 0) nwork[0] = tot;
+  int r2 = block_scan_1024(n2, sh, &tot);
+  if (threadIdx.x == 0) nwork[1] = tot;
+  for (int q = lo; q < hi; q++) {
+    const int cq = count[q];
     start[q] = run;
-    run += count[q];
+    run += cq;
+    if (cq > 0) {
+      work1[r1++] = make_int2(tile0 + q, 0);
+      work2[r2++] = make_int2(tile0 + q, 0);
+      if (cq > BLK) work2[r2++] = make_int2(tile0 + q, 1);
+    }
   }
 }
 
@@ -150,9 +181,10 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
   constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NW];
   __shared__ unsigned actrow[NROWS];
-  const int tile = td.tile0 + blockIdx.x / K2_SPLIT, part = blockIdx.x % K2_SPLIT;
+  if ((int)blockIdx.x >= td.nwork[K2_SPLIT - 1]) return;
+  const int2 wk = td.work[K2_SPLIT - 1][blockIdx.x];
+  const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
-  if (cnt <= part * BLK) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int r = threadIdx.x; r < NROWS; r += BLK) actrow[r] = 0u;
@@ -338,9 +370,10 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
   __shared__ __attribute__((aligned(16))) double duxy[2 * NW];
   __shared__ double duz[(ND == 3) ? NW : 1];
   __shared__ double fac[ND * NW];
-  const int tile = td.tile0 + blockIdx.x / K3_SPLIT, part = blockIdx.x % K3_SPLIT;
+  if ((int)blockIdx.x >= td.nwork[K3_SPLIT - 1]) return;
+  const int2 wk = td.work[K3_SPLIT - 1][blockIdx.x];
+  const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
-  if (cnt <= part * BLK) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
@@ -618,9 +651,10 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
   constexpr int NV = 2 * ND;           // values per node: dU[ND], accel[ND]
   constexpr int NP = (NV + 1) / 2;     // double2 per node (2-D: 2, 3-D: 3)
   __shared__ __attribute__((aligned(16))) double win[NW * 2 * NP];
-  const int tile = td.tile0 + blockIdx.x / K5_SPLIT, part = blockIdx.x % K5_SPLIT;
+  if ((int)blockIdx.x >= td.nwork[K5_SPLIT - 1]) return;
+  const int2 wk = td.work[K5_SPLIT - 1][blockIdx.x];
+  const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
-  if (cnt <= part * BLK) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
@@ -733,9 +767,9 @@ __global__ __launch_bounds__(BLK) void kb_p2g_tile(PView P, GridD g, TileD td, d
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NF = MODE == 0 ? 1 : 2 * ND;
   __shared__ double acc[NF * NW];
-  const int tile = td.tile0 + blockIdx.x;
+  if ((int)blockIdx.x >= td.nwork[0]) return;
+  const int tile = td.work[0][blockIdx.x].x;
   const int cnt = td.count[tile];
-  if (cnt == 0) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW * NF; idx += BLK) acc[idx] = 0.0;
@@ -798,9 +832,9 @@ __global__ __launch_bounds__(BLK) void kb_fint_tile(PView P, GridD g, TileD td, 
                                                     int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double fac[ND * NW];
-  const int tile = td.tile0 + blockIdx.x;
+  if ((int)blockIdx.x >= td.nwork[0]) return;
+  const int tile = td.work[0][blockIdx.x].x;
   const int cnt = td.count[tile];
-  if (cnt == 0) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW * ND; idx += BLK) fac[idx] = 0.0;
@@ -869,9 +903,9 @@ __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD 
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NV = 4 * ND, NP = NV / 2;
   __shared__ __attribute__((aligned(16))) double win[NW * NV];
-  const int tile = td.tile0 + blockIdx.x;
+  if ((int)blockIdx.x >= td.nwork[0]) return;
+  const int tile = td.work[0][blockIdx.x].x;
   const int cnt = td.count[tile];
-  if (cnt == 0) return;
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
