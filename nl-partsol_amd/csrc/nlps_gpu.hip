@@ -59,6 +59,7 @@ struct PView {
 
 struct NView {
   unsigned char* active;  // [nnodes]
+  unsigned char* seed;    // [nnodes] 1 where some particle has this node as I0 (k_dilate turns it into `active`)
   const double* h_avg;    // [nnodes]
   double* nm;             // [nnodes][1+ND]
   double* dU;             // [nnodes][ND]
@@ -146,20 +147,46 @@ __device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
 // ------------------------------------------------------------------------------------------------
 // S1a: closest-node update (LME.c:913-945, Nodes-Tools.c:476-538) + 1-ring activation (LME.c:949-960)
 // ------------------------------------------------------------------------------------------------
+// One launch instead of five hipMemsetAsync (each of which costs one or two 5-us fill kernels): resets the
+// search seeds and tile counters and, for the fused explicit step, the nodal accumulators of the node window.
 template <int ND>
-__device__ __forceinline__ void activate_ring(const GridD& g, unsigned char* active, int I0) {
-  int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+__global__ void k_step_clear(int n0, int nnodes, NView N, int* __restrict__ tile_count, int ntiles, int nodal) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntiles) tile_count[t] = 0;
+  if (t >= nnodes) return;
+  const size_t A = (size_t)n0 + t;
+  N.seed[A] = 0;  // Shape-Functions.c:38-46
+  if (nodal) {
+#pragma unroll
+    for (int a = 0; a < 1 + ND; a++) N.nm[A * (1 + ND) + a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      N.force[A * ND + a] = 0.0;
+      N.fixed[A * ND + a] = 0;
+    }
+  }
+}
+
+// 1-ring activation (LME.c:949-960): the particles only mark their I0 (one byte store each instead of 3^d
+// scattered ones); node n is active iff some I0 lies in its 1-ring.
+template <int ND>
+__global__ void k_dilate(int n0, int nnodes, GridD g, NView N) {
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  A += n0;
+  const int i0 = A % g.n[0], j0 = (A / g.n[0]) % g.n[1], k0 = A / (g.n[0] * g.n[1]);
+  unsigned any = 0u;
 #pragma unroll
   for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
 #pragma unroll
     for (int dj = -1; dj <= 1; dj++)
 #pragma unroll
       for (int di = -1; di <= 1; di++) {
-        int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
-        if (i < 0 || i >= g.n[0] || j < 0 || j >= g.n[1]) continue;
-        if (ND == 3 && (k < 0 || k >= g.n[2])) continue;
-        active[i + g.n[0] * (j + g.n[1] * k)] = 1;
+        const int i = i0 + di, j = j0 + dj, k = k0 + dk;
+        const bool ok = i >= 0 && i < g.n[0] && j >= 0 && j < g.n[1] && (ND == 2 || (k >= 0 && k < g.n[2]));
+        if (ok) any |= N.seed[i + g.n[0] * (j + g.n[1] * k)];
       }
+  N.active[A] = any ? 1 : 0;
 }
 
 template <int ND>
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const
       I0 = (ijk[0] + bestc % 3 - 1) + g.n[0] * ((ijk[1] + (bestc / 3) % 3 - 1) + g.n[1] * (ijk[2] + bestc / 9 - 1));
       P.I0[p] = I0;
     }
-    activate_ring<ND>(g, N.active, I0);
+    N.seed[I0] = 1;
   }
   bin_particle<ND>(P, g, tc, p, I0, valid);
 }
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N, Tile
           }
         }
       P.I0[p] = bestnode;
-      activate_ring<ND>(g, N.active, bestnode);
+      N.seed[bestnode] = 1;
     }
   }
   bin_particle<ND>(P, g, tc, p, bestnode, valid);
@@ -841,6 +868,7 @@ extern "C" int nlps_gpu_set_node_window(nlps_gpu* h, int layer_lo, int layer_hi)
   // clean slate outside the new window (nothing resets those nodes any more)
   const size_t nn = (size_t)h->g.nnodes, ND = (size_t)h->nd;
   HIPCHK(hipMemsetAsync(h->N.active, 0, nn, h->stream));
+  HIPCHK(hipMemsetAsync(h->N.seed, 0, nn, h->stream));
   HIPCHK(hipMemsetAsync(h->N.nm, 0, nn * (1 + ND) * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(h->N.dU, 0, nn * ND * sizeof(double), h->stream));
   HIPCHK(hipMemsetAsync(h->N.force, 0, nn * ND * sizeof(double), h->stream));
@@ -963,6 +991,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   size_t nn = (size_t)g.nnodes;
   int ND = g.nd;
   if (dev_alloc(h, &h->N.active, nn)) return 1;
+  if (dev_alloc(h, &h->N.seed, nn)) return 1;
   if (dev_alloc(h, &h->N.nm, nn * (1 + ND))) return 1;
   if (dev_alloc(h, &h->N.dU, nn * ND)) return 1;
   if (dev_alloc(h, &h->N.force, nn * ND)) return 1;
@@ -1168,7 +1197,7 @@ extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
 extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   if (!h) return 0;
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.nm,
+  void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
@@ -1334,8 +1363,8 @@ static TileD tile_view(nlps_gpu* h) {
 // beta and the Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`, tiled form only)
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm) {
   int np = h->P.np;
-  HIPCHK(hipMemsetAsync(h->N.active + h->n0, 0, (size_t)h->nwn, h->stream));  // Shape-Functions.c:38-46
-  HIPCHK(hipMemsetAsync(h->tile_count_d + h->tile0, 0, (size_t)h->ntw * sizeof(int), h->stream));
+  LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
+            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0);
   TileCnt tc = tile_cnt(h, true);
   if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
   else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
@@ -1345,6 +1374,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                      h->order_d);
   HIPCHK(hipGetLastError());
+  LAUNCH_ND((k_dilate<2>), (k_dilate<3>), nblk(h->nwn), h->n0, h->nwn, h->g, h->N);
   if (halo(h, h->N.active, 1, 1, 1)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
   TileD td = tile_view(h);
@@ -1602,10 +1632,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   h->steps_since_sort++;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  const size_t n0 = (size_t)h->n0, nw = (size_t)h->nwn;  // node window: all nodes on a single GPU
-  HIPCHK(hipMemsetAsync(h->N.nm + n0 * (1 + ND), 0, nw * (1 + ND) * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->N.force + n0 * ND, 0, nw * ND * sizeof(double), h->stream));
-  HIPCHK(hipMemsetAsync(h->N.fixed + n0 * ND, 0, nw * ND, h->stream));
+  // (nodal accumulators of the node window are reset by k_step_clear inside search_and_lists)
   // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel)
   if (search_and_lists(h, false, true, dt, gamma_nm)) return 1;
   if (halo(h, h->N.nm, 1 + ND, 8, 0)) return 1;
