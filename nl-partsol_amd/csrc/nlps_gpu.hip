@@ -701,6 +701,7 @@ struct nlps_gpu {
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int* nwork_d = nullptr;
+  unsigned long long* phase_d = nullptr;
   int* order_d;
 
   nlps_halo_fn halo;
@@ -880,6 +881,20 @@ extern "C" int nlps_gpu_set_node_window(nlps_gpu* h, int layer_lo, int layer_hi)
   h->binned = false;
   return 0;
 }
+
+#if NLPS_PHASE_TIMING
+extern "C" int nlps_gpu_debug_phases(nlps_gpu* h, unsigned long long* out, int reset) {
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<unsigned long long> tmp(16 * 1024);
+  HIPCHK(hipMemcpy(tmp.data(), h->phase_d, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 16; k++) {
+    out[k] = 0;
+    for (int b = 0; b < 1024; b++) out[k] += tmp[k + 16 * b];
+  }
+  if (reset) HIPCHK(hipMemset(h->phase_d, 0, tmp.size() * sizeof(unsigned long long)));
+  return 0;
+}
+#endif
 
 extern "C" int nlps_gpu_touched_layers(nlps_gpu* h, int* lo, int* hi) {
   *lo = h->slab_lo;
@@ -1085,6 +1100,9 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->work1_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
   if (dev_alloc(h, &h->nwork_d, 2)) return 1;
+#if NLPS_PHASE_TIMING
+  if (dev_alloc(h, &h->phase_d, 16 * 1024)) return 1;
+#endif
   {
     std::vector<double> tmp(h->P.npad);
     int T = h->T;
@@ -1353,6 +1371,7 @@ static TileD tile_view(nlps_gpu* h) {
   td.work[0] = h->work1_d;
   td.work[1] = h->work2_d;
   td.nwork = h->nwork_d;
+  td.phase = h->phase_d;
   td.start = h->tile_start_d;
   td.count = h->tile_count_d;
   td.order = h->order_d;

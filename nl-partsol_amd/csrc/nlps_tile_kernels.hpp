@@ -29,7 +29,16 @@ struct TileCfg<2> {
 // TILE_SPLIT-th chunk of 256 particles and flushes with atomics): twice as many, half as long work
 // units shorten the partially filled last round of workgroups (tail) without changing the data flow.
 // Measured at 1 M particles: pays for K2 (0.42 -> 0.39 ms), costs for K3 (double window load + flush).
-static constexpr int K2_SPLIT = 2, K3_SPLIT = 1, K5_SPLIT = 1;
+#ifndef NLPS_K2_SPLIT
+#define NLPS_K2_SPLIT 2
+#endif
+#ifndef NLPS_K3_SPLIT
+#define NLPS_K3_SPLIT 1
+#endif
+#ifndef NLPS_K5_SPLIT
+#define NLPS_K5_SPLIT 1
+#endif
+static constexpr int K2_SPLIT = NLPS_K2_SPLIT, K3_SPLIT = NLPS_K3_SPLIT, K5_SPLIT = NLPS_K5_SPLIT;
 
 struct TileD {
   int nt[3];
@@ -44,7 +53,27 @@ struct TileD {
   // the 8 XCDs whatever the shape of the cloud (tile-index order left XCDs 23 % apart for the cube).
   const int2* work[2];
   const int* nwork;
+  unsigned long long* phase;  // -DNLPS_PHASE_TIMING=1 only: per-phase wave-cycle sums (developer profiling)
 };
+
+// Developer profiling: wall-clock cycles per kernel phase, summed per wave (slot spread over 1024 rows to keep
+// the atomics off one address).  Compiled out by default.
+#ifndef NLPS_PHASE_TIMING
+#define NLPS_PHASE_TIMING 0
+#endif
+#if NLPS_PHASE_TIMING
+#define PH_INIT long long ph_t0 = clock64();
+#define PH(k)                                                                                               \
+  {                                                                                                         \
+    long long ph_t1 = clock64();                                                                            \
+    if ((threadIdx.x & 63) == 0)                                                                            \
+      atomicAdd(&td.phase[(k) + 16 * (blockIdx.x & 1023)], (unsigned long long)(ph_t1 - ph_t0));           \
+    ph_t0 = ph_t1;                                                                                          \
+  }
+#else
+#define PH_INIT
+#define PH(k)
+#endif
 
 template <int ND>
 __device__ __forceinline__ int tile_of_node(const GridD& g, const int* nt, int I0) {
@@ -185,6 +214,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
   const int2 wk = td.work[K2_SPLIT - 1][blockIdx.x];
   const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
+  PH_INIT
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int r = threadIdx.x; r < NROWS; r += BLK) actrow[r] = 0u;
@@ -202,6 +232,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
   }
   __syncthreads();
   const int start = td.start[tile];
+  PH(0)
   for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K2_SPLIT) {
     const int p = td.order[start + s];
     Lme<ND> c;
@@ -267,6 +298,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
     }
     const double hv = N.h_avg[I0];
     const double beta = prm.gamma_lme / (hv * hv);
+    PH(1)
     int st = 0, NumIter = 0;
     double Zinv = 0.0;
     while (NumIter <= prm.max_iter_lme) {  // __lambda_Newton_Rapson, LME.c:272-353
@@ -294,6 +326,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
       }
     }
     if (NumIter >= prm.max_iter_lme) st |= ST_NEWTON;
+    PH(2)
     P.nn[p] = nn;
     P.mlo[p] = mlo;
     P.mhi[p] = mhi;
@@ -335,9 +368,11 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
           }
       }
     }
+    PH(3)
   }
   if (!P2G) return;
   __syncthreads();
+  PH(4)
   for (int q = threadIdx.x; q < NW * NF; q += BLK) {
     int f = q % NF, idx = q / NF;
     double v = acc[f * NW + idx];
@@ -374,6 +409,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
   const int2 wk = td.work[K3_SPLIT - 1][blockIdx.x];
   const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
+  PH_INIT
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
@@ -394,6 +430,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
   const double2* du2 = reinterpret_cast<const double2*>(duxy);
   const double2* dv2 = reinterpret_cast<const double2*>(dvxy);
   const int start = td.start[tile];
+  PH(8)
   for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K3_SPLIT) {
     const int p = td.order[start + s];
     Lme<ND> c;
@@ -401,6 +438,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     const int base = window_base<ND>(c.ijk, w0);
     NLPS_YZ_LOCALS(c);
+    PH(9)
     // pass 1: moments (rows -> planes) and G[a][m] = sum e dU_a l_m (rows)
     double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
     double G[ND * ND], Gv[RATES ? ND * ND : 1];
@@ -510,6 +548,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
         }
       }
     }
+    PH(10)
     const double Zinv = 1.0 / Z;
     rx *= Zinv;
     ry *= Zinv;
@@ -592,7 +631,9 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
     PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
     double tau[ND * ND], B[ND * ND];
     st |= stress_update<ND, LAW>(P, p, mats, prm, Fn1, DF, Jn1, tau);
-    if (force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0)) {
+    const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0);
+    PH(11)
+    if (fo_ok) {
       // pass 2: -f_A = p_A * (B l_A), B l = B[.][x] lx_i + (B[.][y] ly_j + B[.][z] lz_k)
 #pragma unroll 1
       for (int k = 0; k < KN; k++) {
@@ -625,9 +666,11 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
       atomicOr(&P.status[p], st);
       atomicOr(gstatus, st);
     }
+    PH(12)
   }
   if (MODE != 1) return;
   __syncthreads();
+  PH(13)
   for (int qq = threadIdx.x; qq < NW * ND; qq += BLK) {
     int f = qq % ND, idx = qq / ND;
     double v = fac[f * NW + idx];
