@@ -608,6 +608,15 @@ __device__ __forceinline__ unsigned plane_bits(const Lme<ND>& c, int k) {
     lz5[i_] = (ND == 3) ? (c).lz[i_ % Lme<ND>::KN] : 0.0;         \
   }
 
+// Weight of stencil member i of a row: e when bit i of `bits` is set, otherwise e with its high word cleared
+// (one v_bfe_i32 + one v_and_b32 instead of a bit test and two v_cndmask).  What is left of a non-member is
+// a denormal below 2^-1042; every sum it enters also holds members of relative weight >= TOL_zero (or is itself
+// discarded), so no bit of any result changes with respect to an exact zero.
+__device__ __forceinline__ double masked_weight(double e, unsigned bits, int i) {
+  const int m = __builtin_amdgcn_sbfe((int)bits, (unsigned)i, 1u);
+  return __hiloint2double(__double2hiint(e) & m, __double2loint(e));
+}
+
 // Z^-1, r = sum p l, J = sum p l(x)l - r(x)r  (LME.c:766-832) by rows and planes
 template <int ND>
 __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
@@ -625,7 +634,7 @@ __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, do
       double A0 = 0.0, A1 = 0.0, A2 = 0.0;
 #pragma unroll
       for (int i = 0; i < 5; i++) {
-        const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0, m1 = m0 * c.lx[i];
+        const double m0 = masked_weight(c.ex[i], bits, i), m1 = m0 * c.lx[i];
         A0 += m0;
         A1 += m1;
         A2 = fma(m1, c.lx[i], A2);

@@ -463,9 +463,8 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
         for (int a = 0; a < ND; a++) R0[a] = R1[a] = V0r[a] = V1r[a] = 0.0;
 #pragma unroll
         for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
-          const bool on = (bits >> i) & 1u;
           const int li = basek + (i - 2) + W * (j - 2);
-          const double m0 = on ? c.ex[i] : 0.0, m1 = m0 * c.lx[i];
+          const double m0 = masked_weight(c.ex[i], bits, i), m1 = m0 * c.lx[i];
           A0 += m0;
           A1 += m1;
           A2 = fma(m1, c.lx[i], A2);
@@ -736,7 +735,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll
         for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
           const int li = basek + (i - 2) + W * (j - 2);
-          const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+          const double m0 = masked_weight(c.ex[i], bits, i);
           A0 += m0;
 #pragma unroll
           for (int q = 0; q < NP; q++) {
@@ -795,7 +794,7 @@ __device__ __forceinline__ double lme_zinv(const Lme<ND>& c) {
       const unsigned bits = (pb >> (5 * j)) & 31u;
       double A0 = 0.0;
 #pragma unroll
-      for (int i = 0; i < 5; i++) A0 += ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+      for (int i = 0; i < 5; i++) A0 += masked_weight(c.ex[i], bits, i);
       P0 = fma(ey5[j], A0, P0);
     }
     Z = fma(ez5[k], P0, Z);
@@ -992,7 +991,7 @@ __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD 
 #pragma unroll
         for (int i = 0; i < 5; i++) {
           const int li = basek + (i - 2) + W * (j - 2);
-          const double m0 = ((bits >> i) & 1u) ? c.ex[i] : 0.0;
+          const double m0 = masked_weight(c.ex[i], bits, i);
           A0 += m0;
 #pragma unroll
           for (int q = 0; q < NP; q++) {

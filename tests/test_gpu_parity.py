@@ -230,6 +230,48 @@ def test_explicit_steps(ndim, material):
             assert_close(st[k], P[ok], 1e-9, f"step {t} {k}")
 
 
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_long_flight_index_maps(ndim):
+    """A soft block thrown through the grid at Mach 1 with a velocity gradient: every particle changes its
+    closest node several times, crosses cell mid-planes (the tie rule of Nodes-Tools.c:476-538), the neighbour
+    lists are rebuilt around moving I0s and the device re-sorts itself every 7 steps.  I0, NumberNodes, the
+    lists in chain order and ActiveNode have to stay bit-identical to the oracle all the way."""
+    o = orc()
+    n = nlps()
+    soft = {"type": 0, "E": 1.0e5, "nu": 0.3}  # celerity 10
+    if ndim == 2:
+        case = make_case(2, [12, 24], [3, 15], [5, 5], material=soft, velocity=[2.0, -10.0])
+    else:
+        case = make_case(3, [10, 10, 20], [3, 3, 12], [4, 4, 4], material=soft, velocity=[2.0, -1.0, -10.0])
+    x = case["cloud"]["x"]
+    xc = x.mean(axis=0)
+    case["cloud"]["vel"][:, ndim - 1] *= 1.0 + 0.2 * (x[:, 0] - xc[0]) / 2.5  # shear: real deformation
+    nsteps = 40
+    bcs_list = [dirichlet_plane(case, ndim - 1, 2, nsteps)]
+    dt = 0.25 * case["h"] / 20.0
+    M, P, prm, mats = oracle_setup(case)
+    I0_start = P["I0"].copy()
+    S = gpu_setup(case, nsteps=nsteps)
+    S.set_resort_interval(7)
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps)
+    gb = n.BccSet(bcs_list)
+    for t in range(nsteps):
+        assert stepper.step(t, dt) == 0, f"oracle failed at step {t}"
+        S.explicit_step(gb, t, dt)
+        if t % 8 == 7 or t == nsteps - 1:
+            st = S.download_state()
+            assert np.array_equal(st["I0"], P["I0"]), f"step {t}: I0"
+            nn, lst = S.download_lists()
+            assert np.array_equal(nn, P["nn"]) and lists_equal(nn, lst, P["list"]), f"step {t}: lists"
+            assert np.array_equal(S.download_active(), M.active()), f"step {t}: ActiveNode"
+            for k, ok in (("x", "x"), ("vel", "vel"), ("F_n", "F_n"), ("lambda", "lambda")):
+                assert_close(st[k], P[ok], 1e-8, f"step {t} {k}")
+            assert_close(st["Stress"], P["stress"], 1e-7, f"step {t} stress")
+    assert S.status_flags() == 0
+    moved = np.abs(M.coords().reshape(-1, ndim)[P["I0"]] - M.coords().reshape(-1, ndim)[I0_start]).max(axis=0)
+    assert moved[ndim - 1] >= 4.0, "the block has to travel several cells"
+
+
 def test_device_pointer_nodal_vectors():
     """Nodal Vec arrays may live on the device (torch tensors) as well as on the host."""
     import torch
