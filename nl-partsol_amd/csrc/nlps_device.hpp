@@ -74,7 +74,7 @@ struct ParamsD {
 #define NLPS_JUNROLL_SCATTER 5
 #endif
 #ifndef NLPS_K3_WAVES
-#define NLPS_K3_WAVES 1
+#define NLPS_K3_WAVES 2
 #endif
 
 __device__ __forceinline__ double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }  // Macros.h:49-50
@@ -161,61 +161,63 @@ __device__ __forceinline__ double rcond_ref(const double* A) {
 }
 
 // Symmetric eigen-decomposition by cyclic Jacobi, all in registers (replaces LAPACKE_dsyev,
-// TensorLib.c:208 / Drucker-Prager.c:635).  Eigenvector A = COLUMN A of v.  Unsorted: every use on
-// the path is a permutation- and sign-invariant sum over A.
+// TensorLib.c:208 / Drucker-Prager.c:635).  Eigenvector A = COLUMN A of v, eigenvalues ascending like dsyev.
 template <int N>
 __device__ __forceinline__ void sym_eigen(double* w, double* v, const double* Ain) {
-  double a[N * N];
+  // cyclic Jacobi on the upper triangle (Rutishauser's update formulas): per rotation one sqrt, one
+  // division and one reciprocal square root; the rotated pair is annihilated exactly.
+  double d[N], o[N == 3 ? 3 : 1];  // diagonal; off-diagonals o[0] = a01, o[1] = a02, o[2] = a12
 #pragma unroll
-  for (int i = 0; i < N; i++)
+  for (int i = 0; i < N; i++) {
+    d[i] = Ain[i * N + i];
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-      a[i * N + j] = (j >= i) ? Ain[i * N + j] : Ain[j * N + i];
-      v[i * N + j] = (i == j) ? 1.0 : 0.0;
-    }
+    for (int j = 0; j < N; j++) v[i * N + j] = (i == j) ? 1.0 : 0.0;
+  }
+  o[0] = Ain[1];
+  if (N == 3) {
+    o[1 % (N == 3 ? 3 : 1)] = Ain[2 % (N * N)];
+    o[2 % (N == 3 ? 3 : 1)] = Ain[5 % (N * N)];
+  }
 #pragma unroll 1
   for (int sweep = 0; sweep < 12; sweep++) {
     double off = 0.0, dg = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; i++)
+    for (int i = 0; i < N; i++) dg += d[i] * d[i];
 #pragma unroll
-      for (int j = 0; j < N; j++) {
-        if (i != j) off += a[i * N + j] * a[i * N + j];
-        else dg += a[i * N + j] * a[i * N + j];
-      }
+    for (int i = 0; i < (N == 3 ? 3 : 1); i++) off += 2.0 * o[i] * o[i];
     if (off <= 1e-32 * dg || off == 0.0) break;
 #pragma unroll
-    for (int p = 0; p < N - 1; p++)
+    for (int r = 0; r < (N == 3 ? 3 : 1); r++) {
+      // pair (p,q) and the third index m: r = 0 -> (0,1) m=2 ; r = 1 -> (0,2) m=1 ; r = 2 -> (1,2) m=0
+      const int p = (r == 2) ? 1 : 0, q = (r == 0) ? 1 : 2;
+      const double apq = o[r];
+      if (apq != 0.0) {
+        const double df = d[q] - d[p];
+        // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = df / (2 apq)
+        const double t = (df >= 0.0 ? 2.0 : -2.0) * apq / (fabs(df) + sqrt(fma(df, df, 4.0 * apq * apq)));
+        const double c = rsqrt(fma(t, t, 1.0)), sn = t * c;
+        d[p] -= t * apq;
+        d[q] += t * apq;
+        o[r] = 0.0;
+        if (N == 3) {
+          // the two other off-diagonals couple p and q with the third index m
+          const int ip = (r == 0) ? 1 : (r == 1 ? 0 : 0);  // index in o[] of a_{p m}
+          const int iq = (r == 0) ? 2 : (r == 1 ? 2 : 1);  // index in o[] of a_{q m}
+          const double apm = o[ip % (N == 3 ? 3 : 1)], aqm = o[iq % (N == 3 ? 3 : 1)];
+          o[ip % (N == 3 ? 3 : 1)] = c * apm - sn * aqm;
+          o[iq % (N == 3 ? 3 : 1)] = sn * apm + c * aqm;
+        }
 #pragma unroll
-      for (int q = p + 1; q < N; q++) {
-        double apq = a[p * N + q];
-        if (apq != 0.0) {
-          double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
-          double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-          for (int k = 0; k < N; k++) {
-            double akp = a[k * N + p], akq = a[k * N + q];
-            a[k * N + p] = c * akp - s * akq;
-            a[k * N + q] = s * akp + c * akq;
-          }
-#pragma unroll
-          for (int k = 0; k < N; k++) {
-            double apk = a[p * N + k], aqk = a[q * N + k];
-            a[p * N + k] = c * apk - s * aqk;
-            a[q * N + k] = s * apk + c * aqk;
-          }
-#pragma unroll
-          for (int k = 0; k < N; k++) {
-            double vkp = v[k * N + p], vkq = v[k * N + q];
-            v[k * N + p] = c * vkp - s * vkq;
-            v[k * N + q] = s * vkp + c * vkq;
-          }
+        for (int k = 0; k < N; k++) {
+          const double vkp = v[k * N + p], vkq = v[k * N + q];
+          v[k * N + p] = c * vkp - sn * vkq;
+          v[k * N + q] = sn * vkp + c * vkq;
         }
       }
+    }
   }
 #pragma unroll
-  for (int i = 0; i < N; i++) w[i] = a[i * N + i];
+  for (int i = 0; i < N; i++) w[i] = d[i];
   // ascending eigenvalues like LAPACK's dsyev (Matlib/LAPACK.c): the stress is order-invariant, but the
   // Drucker-Prager tangent moduli C_ep are stored per principal direction
 #pragma unroll
