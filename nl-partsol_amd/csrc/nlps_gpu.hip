@@ -54,8 +54,14 @@ struct PView {
   u64* mhi;
   int* tile;  // tile of I0 (per-step binning)
   int* rank;  // arrival rank inside the tile
+  int flip;   // 1: the n / n+1 slots of F and b_e are swapped (the explicit step rolls them by renaming)
 };
 #define PF(P, f, p) ((P).d[(size_t)(f) * (P).npad + (size_t)(p)])
+// first component of F_n, F_n+1, b_e,n, b_e,n+1 under the current renaming
+__host__ __device__ __forceinline__ int fFN(const PView& P) { return P.flip ? F_FN1 : F_FN; }
+__host__ __device__ __forceinline__ int fFN1(const PView& P) { return P.flip ? F_FN : F_FN1; }
+__host__ __device__ __forceinline__ int fBEN(const PView& P) { return P.flip ? F_BEN1 : F_BEN; }
+__host__ __device__ __forceinline__ int fBEN1(const PView& P) { return P.flip ? F_BEN : F_BEN1; }
 
 struct NView {
   unsigned char* active;  // [nnodes]
@@ -368,9 +374,9 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
     law_hencky<ND>(m, Fn1, o);
   } else {
     double be[ND * ND], bzz;
-    load_block<ND>(P, F_BEN, p, be, bzz);
+    load_block<ND>(P, fBEN(P), p, be, bzz);
     law_drucker_prager<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
-    store_block<ND>(P, F_BEN1, p, o.be, o.be_zz, true);
+    store_block<ND>(P, fBEN1(P), p, o.be, o.be_zz, true);
     PF(P, F_KN1, p) = o.kappa;
     PF(P, F_EN1, p) = o.eps;
     if (CEP) {
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict_
   int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
   double Fn1[ND * ND], DF[ND * ND], tau[ND * ND], z;
-  load_block<ND>(P, F_FN1, p, Fn1, z);
+  load_block<ND>(P, fFN1(P), p, Fn1, z);
   load_block<ND>(P, F_DF, p, DF, z);
   int st = stress_update<ND, -1, true>(P, p, mats, prm, Fn1, DF, PF(P, F_JN1, p), tau);
   if (st) {
@@ -433,6 +439,21 @@ __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict_
 }
 
 // __update_particles_internal_variables (U-Newmark-beta.c:1917-1978)
+// After explicit steps the n+1 slots of F and b_e hold the previous step's values (rolled by renaming);
+// the reference's copy semantics (n+1 == n after the roll) are restored on demand, before any level-B stage
+// or download looks at them.
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  constexpr int T = (ND == 2) ? 5 : 9;
+#pragma unroll
+  for (int s = 0; s < T; s++) {
+    PF(P, fFN1(P) + s, p) = PF(P, fFN(P) + s, p);
+    PF(P, fBEN1(P) + s, p) = PF(P, fBEN(P) + s, p);
+  }
+}
+
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_roll(PView P) {
   int p = blockIdx.x * BLK + threadIdx.x;
@@ -445,8 +466,8 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
   constexpr int T = (ND == 2) ? 5 : 9;
 #pragma unroll
   for (int s = 0; s < T; s++) {
-    PF(P, F_BEN + s, p) = PF(P, F_BEN1 + s, p);
-    PF(P, F_FN + s, p) = PF(P, F_FN1 + s, p);
+    PF(P, fBEN(P) + s, p) = PF(P, fBEN1(P) + s, p);
+    PF(P, fFN(P) + s, p) = PF(P, fFN1(P) + s, p);
     PF(P, F_DTFN + s, p) = PF(P, F_DTFN1 + s, p);
   }
 }
@@ -675,6 +696,7 @@ struct nlps_gpu {
   int nactive, nfree;
   bool masks_valid;
   bool binned;  // order[] / tile tables describe the current I0s
+  bool rolled = false;  // explicit steps renamed the n/n+1 tensor slots since the last materialise_roll()
   bool level_b_fields = false;  // C_ep / rate tensors hold data (a level-B constitutive or rate call was made)
 
   // scratch nodal arrays
@@ -1241,7 +1263,10 @@ static int download_field(nlps_gpu* h, int f, int ncomp, double* dst, int stride
   return 0;
 }
 
+static int materialise_roll(nlps_gpu* h);
+
 extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
+  if (materialise_roll(h)) return 1;
   HIPCHK(hipStreamSynchronize(h->stream));
   if (refresh_perm(h)) return 1;
   int ND = h->nd, T = h->T, np = h->P.np;
@@ -1250,12 +1275,12 @@ extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
   if (download_field(h, F_DIS, ND, o->dis, ND, tmp)) return 1;
   if (download_field(h, F_VEL, ND, o->vel, ND, tmp)) return 1;
   if (download_field(h, F_ACC, ND, o->acc, ND, tmp)) return 1;
-  if (download_field(h, F_FN, T, o->F_n, T, tmp)) return 1;
-  if (download_field(h, F_FN1, T, o->F_n1, T, tmp)) return 1;
+  if (download_field(h, fFN(h->P), T, o->F_n, T, tmp)) return 1;
+  if (download_field(h, fFN1(h->P), T, o->F_n1, T, tmp)) return 1;
   if (download_field(h, F_DF, T, o->DF, T, tmp)) return 1;
   if (download_field(h, F_TAU, T, o->Stress, T, tmp)) return 1;
-  if (download_field(h, F_BEN, T, o->b_e_n, T, tmp)) return 1;
-  if (download_field(h, F_BEN1, T, o->b_e_n1, T, tmp)) return 1;
+  if (download_field(h, fBEN(h->P), T, o->b_e_n, T, tmp)) return 1;
+  if (download_field(h, fBEN1(h->P), T, o->b_e_n1, T, tmp)) return 1;
   if (download_field(h, F_JN, 1, o->J_n, 1, tmp)) return 1;
   if (download_field(h, F_JN1, 1, o->J_n1, 1, tmp)) return 1;
   if (download_field(h, F_RHO, 1, o->rho, 1, tmp)) return 1;
@@ -1408,6 +1433,14 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   HIPCHK(hipGetLastError());
   h->masks_valid = false;
   h->binned = true;
+  return 0;
+}
+
+static int materialise_roll(nlps_gpu* h) {
+  if (!h->rolled) return 0;
+  LAUNCH_ND((k_copy_n_to_n1<2>), (k_copy_n_to_n1<3>), nblk(h->P.np), h->P);
+  HIPCHK(hipGetLastError());
+  h->rolled = false;
   return 0;
 }
 
@@ -1580,6 +1613,7 @@ extern "C" int nlps_gpu_nodal_field_n(nlps_gpu* h, double* V, double* A, const d
 
 extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const double* dU_dt) {
   if (need_masks(h, "nlps_gpu_compatibility")) return 1;
+  if (materialise_roll(h)) return 1;
   if (to_grid(h, h->N.dU, dU, h->nd)) return 1;
   if (dU_dt && to_grid(h, h->gridB, dU_dt, h->nd)) return 1;
   if (dU_dt) h->level_b_fields = true;
@@ -1598,6 +1632,7 @@ extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const doubl
 }
 
 extern "C" int nlps_gpu_constitutive(nlps_gpu* h) {
+  if (materialise_roll(h)) return 1;
   h->level_b_fields = true;
   LAUNCH_ND((k_stress<2>), (k_stress<3>), nblk(h->P.np), h->P, h->mats_d, h->prm, h->gstatus_d);
   HIPCHK(hipGetLastError());
@@ -1606,6 +1641,7 @@ extern "C" int nlps_gpu_constitutive(nlps_gpu* h) {
 
 extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
   if (need_masks(h, "nlps_gpu_internal_forces")) return 1;
+  if (materialise_roll(h)) return 1;
   int ND = h->nd;
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
   {
@@ -1619,6 +1655,7 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
 }
 
 extern "C" int nlps_gpu_roll_state(nlps_gpu* h) {
+  if (materialise_roll(h)) return 1;
   LAUNCH_ND((k_roll<2>), (k_roll<3>), nblk(h->P.np), h->P);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1718,6 +1755,8 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
 #undef NLPS_K5
   }
   HIPCHK(hipGetLastError());
+  h->P.flip ^= 1;  // F_n <- F_n+1, b_e,n <- b_e,n+1 by renaming
+  h->rolled = true;
   if (h->timing) {
     HIPCHK(hipEventRecord(h->ev[6], h->stream));
     HIPCHK(hipEventSynchronize(h->ev[6]));

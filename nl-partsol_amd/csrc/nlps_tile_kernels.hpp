@@ -442,6 +442,9 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
     // pass 1: moments (rows -> planes) and G[a][m] = sum e dU_a l_m (rows)
     double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
     double G[ND * ND], Gv[RATES ? ND * ND : 1];
+    double U[ND];  // sum e dU: the value gather of U-Verlet.c:962-1010, by-product of the gradient rows
+#pragma unroll
+    for (int a = 0; a < ND; a++) U[a] = 0.0;
 #pragma unroll
     for (int a = 0; a < ND * ND; a++) G[a] = 0.0;
 #pragma unroll
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
           G[a * ND + 0] = fma(z0, Gx[a], G[a * ND + 0]);
           G[a * ND + 1] = fma(z0, Gy[a], G[a * ND + 1]);
           G[a * ND + (2 % ND)] = fma(z1, Gz[a], G[a * ND + (2 % ND)]);
+          if (MODE == 1) U[a] = fma(z0, Gz[a], U[a]);
           if (RATES) {
             Gv[(a * ND + 0) % (RATES ? ND * ND : 1)] = fma(z0, Hx[a], Gv[(a * ND + 0) % (RATES ? ND * ND : 1)]);
             Gv[(a * ND + 1) % (RATES ? ND * ND : 1)] = fma(z0, Hy[a], Gv[(a * ND + 1) % (RATES ? ND * ND : 1)]);
@@ -540,6 +544,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
         for (int a = 0; a < ND; a++) {
           G[a * ND + 0] = Gx[a];
           G[a * ND + 1] = Gy[a];
+          if (MODE == 1) U[a] = Gz[a];
           if (RATES) {
             Gv[(a * ND + 0) % (RATES ? ND * ND : 1)] = Hx[a];
             Gv[(a * ND + 1) % (RATES ? ND * ND : 1)] = Hy[a];
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
         for (int m = 0; m < ND; m++) v = fma(G[i * ND + m] * Zinv, Jm1[j * ND + m], v);
         DF[i * ND + j] = ((i == j) ? 1.0 : 0.0) - v;
       }
-    load_block<ND>(P, F_FN, p, Fn, fzz);
+    load_block<ND>(P, fFN(P), p, Fn, fzz);
 #pragma unroll
     for (int i = 0; i < ND; i++)
 #pragma unroll
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
       if (MODE != 1) Jn1 = 0.0;
     }
     store_block<ND>(P, F_DF, p, DF, 0.0, false);
-    store_block<ND>(P, F_FN1, p, Fn1, 0.0, false);
+    store_block<ND>(P, fFN1(P), p, Fn1, 0.0, false);
     PF(P, F_JN1, p) = Jn1;
     if (RATES) {
       double dDF[ND * ND], dFn[ND * ND], dFn1[ND * ND], zz;
@@ -628,6 +633,8 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
       continue;
     }
     PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
+#pragma unroll
+    for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, p) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
     double tau[ND * ND], B[ND * ND];
     st |= stress_update<ND, LAW>(P, p, mats, prm, Fn1, DF, Jn1, tau);
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0);
@@ -682,17 +689,16 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: G2P of nodal acceleration and dU, corrector, roll                   (S5)
-// The gather window is AoS: the 2d doubles {dU, a} of one node are contiguous and 16-B aligned, read
-// as double2 (ds_read_b128, full LDS rate, conflict-free for the tile's 64 I0 positions) instead of
-// 2d separate 8-byte reads that the compiler pairs into half-rate ds_read2_b64.
+// K5: G2P of the nodal acceleration, corrector, roll                     (S5)
+// (the value gather of dU is a by-product of K3's gradient rows and arrives in F_DDIS).  The gather window
+// keeps {ax, ay} as one 16-B double2 per node (ds_read_b128) and az in a separate 8-B array, the layout that
+// is conflict-free for the tile's 64 I0 positions (see K3).
 // ------------------------------------------------------------------------------------------------
 template <int ND, int LAW>
 __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
-  constexpr int NV = 2 * ND;           // values per node: dU[ND], accel[ND]
-  constexpr int NP = (NV + 1) / 2;     // double2 per node (2-D: 2, 3-D: 3)
-  __shared__ __attribute__((aligned(16))) double win[NW * 2 * NP];
+  __shared__ __attribute__((aligned(16))) double axy[2 * NW];
+  __shared__ double az[(ND == 3) ? NW : 1];
   if ((int)blockIdx.x >= td.nwork[K5_SPLIT - 1]) return;
   const int2 wk = td.work[K5_SPLIT - 1][blockIdx.x];
   const int tile = wk.x, part = wk.y;
@@ -702,14 +708,12 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
     bool in;
     int node = window_node<ND>(g, w0, idx, in);
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      win[idx * 2 * NP + a] = in ? N.dU[(size_t)node * ND + a] : 0.0;
-      win[idx * 2 * NP + ND + a] = in ? N.accel[(size_t)node * ND + a] : 0.0;
-    }
+    axy[2 * idx] = in ? N.accel[(size_t)node * ND + 0] : 0.0;
+    axy[2 * idx + 1] = in ? N.accel[(size_t)node * ND + 1] : 0.0;
+    if (ND == 3) az[idx % ((ND == 3) ? NW : 1)] = in ? N.accel[(size_t)node * ND + (2 % ND)] : 0.0;
   }
   __syncthreads();
-  const double2* win2 = reinterpret_cast<const double2*>(win);
+  const double2* a2 = reinterpret_cast<const double2*>(axy);
   const int start = td.start[tile];
   for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K5_SPLIT) {
     const int p = td.order[start + s];
@@ -718,9 +722,9 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     const int base = window_base<ND>(c.ijk, w0);
     NLPS_YZ_LOCALS(c);
-    double Z = 0.0, sv[2 * NP];
+    double Z = 0.0, sv[ND];
 #pragma unroll
-    for (int a = 0; a < 2 * NP; a++) sv[a] = 0.0;
+    for (int a = 0; a < ND; a++) sv[a] = 0.0;
 #pragma unroll 1
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
@@ -729,47 +733,41 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll NLPS_JUNROLL_K5
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
-        double A0 = 0.0, R[2 * NP];
+        double A0 = 0.0, R[ND];
 #pragma unroll
-        for (int a = 0; a < 2 * NP; a++) R[a] = 0.0;
+        for (int a = 0; a < ND; a++) R[a] = 0.0;
 #pragma unroll
         for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
           const int li = basek + (i - 2) + W * (j - 2);
           const double m0 = masked_weight(c.ex[i], bits, i);
           A0 += m0;
-#pragma unroll
-          for (int q = 0; q < NP; q++) {
-            const double2 v = win2[li * NP + q];
-            R[2 * q] = fma(m0, v.x, R[2 * q]);
-            R[2 * q + 1] = fma(m0, v.y, R[2 * q + 1]);
-          }
+          const double2 v01 = a2[li];
+          R[0] = fma(m0, v01.x, R[0]);
+          R[1] = fma(m0, v01.y, R[1]);
+          if (ND == 3) R[2 % ND] = fma(m0, az[li % ((ND == 3) ? NW : 1)], R[2 % ND]);
         }
         const double w = ey5[j] * z0;
         Z = fma(w, A0, Z);
 #pragma unroll
-        for (int a = 0; a < 2 * NP; a++) sv[a] = fma(w, R[a], sv[a]);
+        for (int a = 0; a < ND; a++) sv[a] = fma(w, R[a], sv[a]);
       }
     }
     const double Zinv = 1.0 / Z;
 #pragma unroll
     for (int a = 0; a < ND; a++) {
-      double dd = sv[a] * Zinv, av = sv[ND + a] * Zinv;
+      const double dd = PF(P, F_DDIS + a, p), av = sv[a] * Zinv;
       PF(P, F_ACC + a, p) = av;
-      PF(P, F_DDIS + a, p) = dd;
       PF(P, F_VEL + a, p) = PF(P, F_VEL + a, p) + gamma_nm * dt * av;
       PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
       PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
     }
     PF(P, F_JN, p) = PF(P, F_JN1, p);
-    constexpr int T = (ND == 2) ? 5 : 9;
-#pragma unroll
-    for (int s2 = 0; s2 < T; s2++) PF(P, F_FN + s2, p) = PF(P, F_FN1 + s2, p);
+    // F_n <- F_n+1 and b_e,n <- b_e,n+1 (U-Verlet.c:1062-1075) cost no traffic: the host swaps the roles of
+    // the two slots after this kernel (PView::flip); the stale slot is rewritten in full by the next K3.
     if (LAW != NLPS_MAT_NEO_HOOKEAN && LAW != NLPS_MAT_HENCKY) {
-      // kappa, eps-bar and b_e exist for the plastic law only (Constitutive.c:160-168)
+      // kappa and eps-bar exist for the plastic law only (Constitutive.c:160-168)
       PF(P, F_KN, p) = PF(P, F_KN1, p);
       PF(P, F_EN, p) = PF(P, F_EN1, p);
-#pragma unroll
-      for (int s2 = 0; s2 < T; s2++) PF(P, F_BEN + s2, p) = PF(P, F_BEN1 + s2, p);
     }
   }
 }
