@@ -65,10 +65,10 @@ struct ParamsD {
 #define NLPS_LAMBDA_EXTRAPOLATE 0
 #endif
 #ifndef NLPS_JUNROLL_K3
-#define NLPS_JUNROLL_K3 1
+#define NLPS_JUNROLL_K3 5
 #endif
 #ifndef NLPS_JUNROLL_K5
-#define NLPS_JUNROLL_K5 1
+#define NLPS_JUNROLL_K5 5
 #endif
 #ifndef NLPS_JUNROLL_SCATTER
 #define NLPS_JUNROLL_SCATTER 5
