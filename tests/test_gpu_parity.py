@@ -272,6 +272,49 @@ def test_long_flight_index_maps(ndim):
     assert moved[ndim - 1] >= 4.0, "the block has to travel several cells"
 
 
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_mixed_materials(ndim):
+    """Three laws in one cloud (MatIdx selects the law per particle, Constitutive.c:28-258): the kernels
+    compiled for run-time dispatch instead of the single-law specialisations."""
+    o = orc()
+    n = nlps()
+    vel = [0.0, -2.0] if ndim == 2 else [0.0, 0.0, -2.0]
+    soft_nh = {"type": 0, "E": 2.0e4, "nu": 0.3}
+    soft_hencky = {"type": 1, "E": 1.0e4, "nu": 0.25}
+    case = small_case(ndim, material=DP, velocity=vel)
+    case["materials"] = [soft_nh, soft_hencky, DP]
+    npart = case["cloud"]["x"].shape[0]
+    case["cloud"]["matidx"] = (np.arange(npart) % 3).astype(np.int32)
+    nsteps = 8
+    bcs_list = [dirichlet_plane(case, ndim - 1, 2, nsteps)]
+    grav = [0.0] * (ndim - 1) + [-9.81]
+    dt = 0.1 * case["h"] / np.sqrt(2.0e4 / 1000.0)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps, gravity=grav)
+    gb = n.BccSet(bcs_list)
+    for t in range(nsteps):
+        assert stepper.step(t, dt) == 0
+        S.explicit_step(gb, t, dt, 0.5, grav)
+    st = S.download_state()
+    assert np.array_equal(st["I0"], P["I0"])
+    for k, ok in (("x", "x"), ("vel", "vel"), ("F_n", "F_n"), ("Stress", "stress"), ("W", "W"), ("b_e_n", "b_e_n"),
+                  ("Kappa_n", "kappa_n"), ("EPS_n", "eps_n"), ("rho", "rho")):
+        assert_close(st[k], P[ok], 1e-9, f"mixed laws: {k}")
+    for m in range(3):  # every law contributes a visible stress
+        assert np.abs(P["stress"][case["cloud"]["matidx"] == m]).max() > 1.0
+    # level-B constitutive stage with the same mixed cloud
+    n2m, d2m, na = masks(S, M, bcs_list, 0, nsteps)
+    rng = np.random.default_rng(3)
+    dU = 5e-3 * rng.normal(size=na * ndim)
+    assert o.compatibility(dU, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+    S.local_compatibility_conditions(dU)
+    S.constitutive_update()
+    st = S.download_state()
+    for k, ok in (("F_n1", "F_n1"), ("Stress", "stress"), ("b_e_n1", "b_e_n1"), ("Kappa_n1", "kappa_n1")):
+        assert_close(st[k], P[ok], 1e-9, f"mixed laws, level B: {k}")
+
+
 def test_device_pointer_nodal_vectors():
     """Nodal Vec arrays may live on the device (torch tensors) as well as on the host."""
     import torch
