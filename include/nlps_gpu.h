@@ -192,6 +192,26 @@ int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force
 int nlps_gpu_resort(nlps_gpu *h);
 int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
 
+/* ------------------------------------------------------------------ tangent assembly */
+
+/* __jacobian_evaluation (U-Newmark-beta.c:1646-1830) for Neo-Hookean particles
+ * (compute_stiffness_density_Neo_Hookean, Hyperelastic/Neo-Hookean.c:89-141): the d x d blocks
+ * V0 * stiffness_density(A, B) of every node pair a particle connects are summed on the device, from the state
+ * the compatibility + constitutive stages left (DF, F_n, J_n1) and the current lists / lambda.  *nnz = number
+ * of COO entries = d*d * (number of structurally visited node pairs, the reference's sparsity pattern).
+ * Needs nlps_gpu_active_masks() first.  EXIT_FAILURE if a particle has another law: the spectral tangents of
+ * Hencky / Drucker-Prager divide by eigenvalue differences down to 1e-14 and are not reproduced. */
+int nlps_gpu_tangent_assemble(nlps_gpu *h, long long *nnz);
+/* The assembled matrix as COO triplets (masked dof numbering, every visited pair present even when its value is
+ * zero, like MatSetValues ... ADD_VALUES): rows[nnz], cols[nnz], vals[nnz], host or device pointers.
+ * lumped_mass (masked [N_A*d], may be NULL): alpha_1 * M is added on the diagonal (:1797-1807).
+ * apply_dirichlet != 0: rows and columns of the dofs fixed at the step given to nlps_gpu_active_masks() become
+ * identity rows (MatZeroRowsColumnsIS, :1822). */
+int nlps_gpu_tangent_coo(nlps_gpu *h, double alpha_1, const double *lumped_mass, int apply_dirichlet, int *rows,
+                         int *cols, double *vals);
+/* __create_sparsity_pattern (U-Newmark-beta.c:1568-1632): visited columns per dof row, nnz_per_row[N_A*d] */
+int nlps_gpu_sparsity_pattern(nlps_gpu *h, int *nnz_per_row);
+
 /* ------------------------------------------------------------------ multi-GPU hooks */
 
 /* Halo exchange callback, invoked by explicit_step / the P2G stages after a nodal scatter, on the

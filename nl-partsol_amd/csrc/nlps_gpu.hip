@@ -623,6 +623,7 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 }
 
 #include "nlps_tile_kernels.hpp"
+#include "nlps_tangent_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // physical re-sort of the particle SoA (maintenance, every few dozen steps): restores the
@@ -724,6 +725,13 @@ struct nlps_gpu {
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int* nwork_d = nullptr;
   unsigned long long* phase_d = nullptr;
+  // tangent assembly, allocated on first use
+  double* kst_d = nullptr;           // [nnodes][S][d*d]
+  unsigned char* ktouched_d = nullptr;  // [nnodes][S]
+  int *kcnt_d = nullptr, *koffs_d = nullptr;  // visited blocks per row node, exclusive scan
+  void* kscan_tmp = nullptr;
+  size_t kscan_bytes = 0;
+  long long knnz_blocks = -1;
   int* order_d;
 
   nlps_halo_fn halo;
@@ -1241,7 +1249,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp};
+                  h->gather_tmp, h->cub_tmp, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -1797,3 +1805,94 @@ extern "C" int nlps_gpu_explicit_nodal(nlps_gpu* h, double* mass, double* dU, do
   if (reaction && from_grid(h, reaction, h->N.reaction, ND, ND, 0, 0, 0, nullptr)) return 1;
   return check_status(h, ST_NEWTON | ST_CONNECT | ST_JACOBIAN | ST_CONSTITUTIVE | ST_HALO, "nlps_gpu_explicit_step()");
 }
+
+// ------------------------------------------------------------------------------------------------
+// tangent assembly
+// ------------------------------------------------------------------------------------------------
+extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
+  if (need_masks(h, "nlps_gpu_tangent_assemble")) return 1;
+  if (materialise_roll(h)) return 1;
+  const int ND = h->nd, S = ND == 3 ? TanCfg<3>::S : TanCfg<2>::S;
+  const size_t nn = (size_t)h->g.nnodes, nblk_st = nn * S;
+  if (!h->kst_d) {
+    HIPCHK(hipMalloc((void**)&h->kst_d, nblk_st * ND * ND * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&h->ktouched_d, nblk_st));
+    HIPCHK(hipMalloc((void**)&h->kcnt_d, (nn + 1) * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->koffs_d, (nn + 1) * sizeof(int)));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, h->kscan_bytes, h->kcnt_d, h->koffs_d, (int)nn + 1, h->stream));
+    HIPCHK(hipMalloc(&h->kscan_tmp, h->kscan_bytes + 16));
+  }
+  HIPCHK(hipMemsetAsync(h->kst_d, 0, nblk_st * ND * ND * sizeof(double), h->stream));
+  HIPCHK(hipMemsetAsync(h->ktouched_d, 0, nblk_st, h->stream));
+  HIPCHK(hipMemsetAsync(h->kcnt_d, 0, (nn + 1) * sizeof(int), h->stream));
+  const int np = h->P.np;
+  if (np > 0) {
+    if (ND == 2) hipLaunchKernelGGL(k_tangent_nh<2>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
+    else hipLaunchKernelGGL(k_tangent_nh<3>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
+  }
+  LAUNCH_ND((k_tangent_count<2>), (k_tangent_count<3>), nblk((int)nn), (int)nn, h->ktouched_d, h->kcnt_d);
+  HIPCHK(hipGetLastError());
+  size_t bytes = h->kscan_bytes;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->kscan_tmp, bytes, h->kcnt_d, h->koffs_d, (int)nn + 1, h->stream));
+  int total = 0;
+  HIPCHK(hipMemcpyAsync(&total, h->koffs_d + nn, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (check_status(h, ST_NEWTON | ST_CONSTITUTIVE, "nlps_gpu_tangent_assemble() (Neo-Hookean particles only)")) return 1;
+  h->knnz_blocks = total;
+  if (nnz) *nnz = (long long)total * ND * ND;
+  return 0;
+}
+
+extern "C" int nlps_gpu_tangent_coo(nlps_gpu* h, double alpha_1, const double* lumped_mass, int apply_dirichlet,
+                                    int* rows, int* cols, double* vals) {
+  if (h->knnz_blocks < 0) {
+    h->err = "nlps_gpu_tangent_coo: call nlps_gpu_tangent_assemble() first";
+    return 1;
+  }
+  if (need_masks(h, "nlps_gpu_tangent_coo")) return 1;
+  const int ND = h->nd, nn = h->g.nnodes;
+  const size_t ne = (size_t)h->knnz_blocks * ND * ND;
+  if (ne == 0) return 0;
+  const double* mass_d = nullptr;
+  if (lumped_mass) {
+    if (ensure_masked(h, (size_t)h->nactive * ND)) return 1;
+    HIPCHK(hipMemcpyAsync(h->maskedA, lumped_mass, (size_t)h->nactive * ND * sizeof(double), hipMemcpyDefault, h->stream));
+    mass_d = h->maskedA;
+  }
+  int *rows_d = nullptr, *cols_d = nullptr;
+  double* vals_d = nullptr;
+  HIPCHK(hipMalloc((void**)&rows_d, ne * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&cols_d, ne * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&vals_d, ne * sizeof(double)));
+  LAUNCH_ND((k_tangent_emit<2>), (k_tangent_emit<3>), nblk(nn), nn, h->g, h->ktouched_d, h->kst_d, h->koffs_d, h->n2m_d,
+            apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows_d, cols_d, vals_d);
+  int st = 0;
+  if (hipGetLastError() != hipSuccess) st = 1;
+  if (!st && hipMemcpyAsync(rows, rows_d, ne * sizeof(int), hipMemcpyDefault, h->stream) != hipSuccess) st = 1;
+  if (!st && hipMemcpyAsync(cols, cols_d, ne * sizeof(int), hipMemcpyDefault, h->stream) != hipSuccess) st = 1;
+  if (!st && hipMemcpyAsync(vals, vals_d, ne * sizeof(double), hipMemcpyDefault, h->stream) != hipSuccess) st = 1;
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(rows_d);
+  (void)hipFree(cols_d);
+  (void)hipFree(vals_d);
+  if (st) h->err = "nlps_gpu_tangent_coo: HIP error while emitting the triplets";
+  return st;
+}
+
+extern "C" int nlps_gpu_sparsity_pattern(nlps_gpu* h, int* nnz_per_row) {
+  if (h->knnz_blocks < 0) {
+    h->err = "nlps_gpu_sparsity_pattern: call nlps_gpu_tangent_assemble() first";
+    return 1;
+  }
+  if (need_masks(h, "nlps_gpu_sparsity_pattern")) return 1;
+  const int ND = h->nd, nn = h->g.nnodes;
+  int* pat_d = nullptr;
+  HIPCHK(hipMalloc((void**)&pat_d, (size_t)h->nactive * ND * sizeof(int) + 16));
+  LAUNCH_ND((k_tangent_pattern<2>), (k_tangent_pattern<3>), nblk(nn), nn, h->kcnt_d, h->n2m_d, pat_d);
+  int st = hipGetLastError() != hipSuccess;
+  if (!st && hipMemcpyAsync(nnz_per_row, pat_d, (size_t)h->nactive * ND * sizeof(int), hipMemcpyDefault, h->stream) != hipSuccess) st = 1;
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(pat_d);
+  if (st) h->err = "nlps_gpu_sparsity_pattern: HIP error";
+  return st;
+}
+

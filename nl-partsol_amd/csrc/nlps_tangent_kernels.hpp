@@ -1,0 +1,184 @@
+// tangent (Jacobian) assembly of the implicit driver, Neo-Hookean particles.
+//
+// Restates __jacobian_evaluation (Formulations/Displacements/U-Newmark-beta.c:1646-1830) with
+// stiffness_density__Constitutive__ -> compute_stiffness_density_Neo_Hookean (Constitutive.c:262-283,
+// Hyperelastic/Neo-Hookean.c:89-141) and __create_sparsity_pattern (:1568-1632).
+//
+// Layout.  On the GramsBox lattice two nodes can only share a particle when they are at most 4 nodes apart per
+// axis, so the block-sparse matrix is a dense "stencil" array K[node A][offset B-A in [-4,4]^d][d][d] in GRID
+// numbering plus one byte per (A, offset) that records the structural visits of the reference's
+// MatSetValues/sparsity pattern.  One wave assembles one particle: the lanes first build the particle's member
+// table in LDS (grad N^n, its push-forward DF^-T grad N^n and b_n grad N^n per member), then share the
+// N_n x N_n node pairs and add their d x d blocks with global f64 atomics (the pair space is far too large
+// for LDS staging: 81 / 729 blocks per window node).  k_tangent_emit then walks the stencil array and writes
+// COO triplets in the masked dof numbering PETSc uses, with alpha_1 * M on the diagonal (:1797-1807) and the
+// Dirichlet rows/columns reduced to the identity (MatZeroRowsColumnsIS, :1822).
+#pragma once
+
+template <int ND>
+struct TanCfg {
+  static constexpr int S = (ND == 3) ? 729 : 81;    // stencil offsets per row node
+  static constexpr int MAXM = (ND == 3) ? 125 : 25;  // members of one particle
+};
+
+template <int ND>
+__device__ __forceinline__ int tangent_offset_index(int sA, int sB) {
+  const int dx = (sB % 5) - (sA % 5), dy = ((sB / 5) % 5) - ((sA / 5) % 5), dz = (ND == 3) ? (sB / 25) - (sA / 25) : 0;
+  return (dx + 4) + 9 * ((dy + 4) + (ND == 3 ? 9 * (dz + 4) : 0));
+}
+
+template <int ND>
+__global__ __launch_bounds__(64) void k_tangent_nh(PView P, GridD g, const MatD* __restrict__ mats,
+                                                   double* __restrict__ Kst, unsigned char* __restrict__ touched,
+                                                   int* __restrict__ gstatus) {
+  constexpr int S = TanCfg<ND>::S, MAXM = TanCfg<ND>::MAXM, KN = Lme<ND>::KN;
+  __shared__ double tab[6][5];  // ex, ey, ez, lx, ly, lz of this particle
+  __shared__ double gn[MAXM][ND], g1[MAXM][ND], ub[MAXM][ND];
+  __shared__ int mnode[MAXM], mcode[MAXM];
+  const int p = blockIdx.x, lane = threadIdx.x;
+  if (p >= P.np) return;
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;  // no neighbourhood: flagged by the search already
+  const MatD m = mats[P.mat[p]];
+  if (m.type != NLPS_MAT_NEO_HOOKEAN) {  // only this law's tangent is restated
+    if (lane == 0) {
+      atomicOr(&P.status[p], ST_CONSTITUTIVE);
+      atomicOr(gstatus, ST_CONSTITUTIVE);
+    }
+    return;
+  }
+  double Zinv, r[ND], J[ND * ND], Jm1[ND * ND], DF[ND * ND], DFm1[ND * ND], Fn[ND * ND], bn[ND * ND], zz;
+  lme_moments_h<ND>(c, Zinv, r, J);
+  load_block<ND>(P, F_DF, p, DF, zz);
+  load_block<ND>(P, fFN(P), p, Fn, zz);
+  if (!inverse<ND>(Jm1, J) || !inverse<ND>(DFm1, DF)) {  // dp__LME__ (LME.c:836-891), push_forward_dN (Shape-Functions.c:405-448)
+    if (lane == 0) {
+      atomicOr(&P.status[p], ST_NEWTON);
+      atomicOr(gstatus, ST_NEWTON);
+    }
+    return;
+  }
+  left_cauchy_green<ND>(bn, Fn);
+#pragma unroll
+  for (int i = 0; i < 5; i++)  // every lane holds the same factors; static register indices only
+    if (lane == i) {
+      tab[0][i] = c.ex[i];
+      tab[1][i] = c.ey[i];
+      tab[2][i] = (ND == 3) ? c.ez[i % KN] : 1.0;
+      tab[3][i] = c.lx[i];
+      tab[4][i] = c.ly[i];
+      tab[5][i] = (ND == 3) ? c.lz[i % KN] : 0.0;
+    }
+  __syncthreads();
+  int nn = 0;
+  for (int s0 = 0; s0 < MAXM; s0 += 64) {
+    const int s = s0 + lane;
+    const bool mem = s < MAXM && c.on(s);
+    const u64 bal = __ballot(mem);
+    if (mem) {
+      const int pos = nn + (int)__popcll(bal & ((1ull << lane) - 1ull));
+      const int i = s % 5, j = (s / 5) % 5, k = s / 25;
+      const double l[3] = {tab[3][i], tab[4][j], tab[5][k]};
+      const double pa = tab[0][i] * tab[1][j] * tab[2][k] * Zinv;
+      double ga[ND];
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        double v = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < ND; b2++) v = fma(Jm1[a * ND + b2], l[b2], v);
+        ga[a] = -pa * v;
+      }
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        double v1 = 0.0, vb = 0.0;
+#pragma unroll
+        for (int b2 = 0; b2 < ND; b2++) {
+          v1 = fma(DFm1[b2 * ND + a], ga[b2], v1);  // DF^-T
+          vb = fma(bn[a * ND + b2], ga[b2], vb);
+        }
+        gn[pos][a] = ga[a];
+        g1[pos][a] = v1;
+        ub[pos][a] = vb;
+      }
+      mnode[pos] = c.I0 + c.node_offset(g, i, j, k);
+      mcode[pos] = s;
+    }
+    nn += (int)__popcll(bal);
+  }
+  __syncthreads();
+  const double Jp = PF(P, F_JN1, p), sqrJ = Jp * Jp, V0 = PF(P, F_VOL0, p);
+  const double c0 = m.lame * sqrJ, c1 = m.G - 0.5 * m.lame * (sqrJ - 1);  // Neo-Hookean.c:107-110
+  for (int q = lane; q < nn * nn; q += 64) {
+    const int A = q / nn, B = q - A * nn;
+    const size_t blk = (size_t)mnode[A] * S + tangent_offset_index<ND>(mcode[A], mcode[B]);
+    double len0 = 0.0;
+#pragma unroll
+    for (int a = 0; a < ND; a++) len0 = fma(gn[B][a], ub[A][a], len0);  // dN_beta_n . (b_n dN_alpha_n)
+    double* out = Kst + blk * (ND * ND);
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++) {
+        const double v = c0 * g1[A][i] * g1[B][j] + (i == j ? m.G * len0 : 0.0) + c1 * g1[A][j] * g1[B][i];
+        atomic_add_f64(out + i * ND + j, v * V0);
+      }
+    touched[blk] = 1;
+  }
+}
+
+// number of structurally visited blocks of every row node (both ends active by construction)
+template <int ND>
+__global__ void k_tangent_count(int nnodes, const unsigned char* __restrict__ touched, int* __restrict__ cnt) {
+  constexpr int S = TanCfg<ND>::S;
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  int c = 0;
+  const unsigned char* t = touched + (size_t)A * S;
+  for (int s = 0; s < S; s++) c += t[s];
+  cnt[A] = c;
+}
+
+// __create_sparsity_pattern, U-Newmark-beta.c:1568-1632: visited columns per dof row (masked numbering)
+template <int ND>
+__global__ void k_tangent_pattern(int nnodes, const int* __restrict__ cnt, const int* __restrict__ n2m,
+                                  int* __restrict__ pattern) {
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes || n2m[A] < 0) return;
+#pragma unroll
+  for (int i = 0; i < ND; i++) pattern[n2m[A] * ND + i] = ND * cnt[A];
+}
+
+// COO triplets in masked dof numbering; entry order: row node (grid order), stencil offset, i, j
+template <int ND>
+__global__ void k_tangent_emit(int nnodes, GridD g, const unsigned char* __restrict__ touched,
+                               const double* __restrict__ Kst, const int* __restrict__ offs,
+                               const int* __restrict__ n2m, const int* __restrict__ d2m, double alpha_1,
+                               const double* __restrict__ mass, int* __restrict__ rows, int* __restrict__ cols,
+                               double* __restrict__ vals) {
+  constexpr int S = TanCfg<ND>::S;
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  size_t e = (size_t)offs[A] * (ND * ND);
+  const int mA = n2m[A];
+  for (int s = 0; s < S; s++) {
+    if (!touched[(size_t)A * S + s]) continue;
+    const int dx = s % 9 - 4, dy = (s / 9) % 9 - 4, dz = (ND == 3) ? s / 81 - 4 : 0;
+    const int B = A + dx + g.n[0] * (dy + g.n[1] * dz);
+    const int mB = n2m[B];
+    const double* blk = Kst + ((size_t)A * S + s) * (ND * ND);
+#pragma unroll
+    for (int i = 0; i < ND; i++)
+#pragma unroll
+      for (int j = 0; j < ND; j++) {
+        const int ra = mA * ND + i, cb = mB * ND + j;
+        double v = blk[i * ND + j];
+        if (ra == cb && mass) v += alpha_1 * mass[ra];  // :1797-1807
+        if (d2m && (d2m[ra] == -1 || d2m[cb] == -1)) v = (ra == cb) ? 1.0 : 0.0;  // MatZeroRowsColumnsIS, :1822
+        rows[e] = ra;
+        cols[e] = cb;
+        vals[e] = v;
+        e++;
+      }
+  }
+}

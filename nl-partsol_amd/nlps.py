@@ -65,6 +65,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
            "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window",
+           "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_coo", "nlps_gpu_sparsity_pattern",
            "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
 
 
@@ -89,6 +90,9 @@ def lib():
                                       C.POINTER(Material), C.c_int, C.POINTER(Particles), C.c_int, C.c_void_p]
         L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.nlps_gpu_tangent_assemble.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        L.nlps_gpu_tangent_coo.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, _ip, _ip, _dp]
+        L.nlps_gpu_sparsity_pattern.argtypes = [C.c_void_p, _ip]
         for name in ["nlps_gpu_destroy", "nlps_gpu_synchronize", "nlps_gpu_initialize_lme", "nlps_gpu_resort",
                      "nlps_gpu_local_search", "nlps_gpu_constitutive", "nlps_gpu_roll_state"]:
             getattr(L, name).argtypes = [C.c_void_p]
@@ -368,6 +372,21 @@ class Solver:
         lo, hi = C.c_int(0), C.c_int(0)
         self._chk(self.L.nlps_gpu_touched_layers(self.h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def jacobian_evaluation(self, alpha_1=0.0, lumped_mass=None, apply_dirichlet=False):  # __jacobian_evaluation
+        """COO triplets (rows, cols, vals) of the tangent matrix in masked dof numbering (Neo-Hookean)."""
+        nnz = C.c_longlong(0)
+        self._chk(self.L.nlps_gpu_tangent_assemble(self.h, C.byref(nnz)))
+        n = int(nnz.value)
+        rows, cols, vals = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n)
+        self._chk(self.L.nlps_gpu_tangent_coo(self.h, float(alpha_1), _vp(lumped_mass), 1 if apply_dirichlet else 0,
+                                              _i(rows), _i(cols), _d(vals)))
+        return rows, cols, vals
+
+    def create_sparsity_pattern(self):                  # __create_sparsity_pattern (after jacobian_evaluation)
+        pat = np.zeros(self.nactive * self.ndim, dtype=np.int32)
+        self._chk(self.L.nlps_gpu_sparsity_pattern(self.h, _i(pat)))
+        return pat
 
     def set_node_window(self, layer_lo, layer_hi):
         self._chk(self.L.nlps_gpu_set_node_window(self.h, int(layer_lo), int(layer_hi)))

@@ -1207,6 +1207,99 @@ int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, co
   return STATUS;
 }
 
+/* compute_stiffness_density_Neo_Hookean, Hyperelastic/Neo-Hookean.c:89-141 (the only law whose tangent is
+ * restated: the spectral tangents of Hencky and the elastoplastic laws divide by eigenvalue differences down to
+ * 1e-14 (Hencky.c:205-214, Elastoplastic-Tangent-Matrix.c:137-147), which no second eigen-solver reproduces) */
+static void stiffness_density_neo_hookean(double *Kd, int ndim, const double *dNa_n1, const double *dNb_n1,
+                                          const double *dNa_n, const double *dNb_n, const double *F_n,
+                                          double J, const orc_material *mat) {
+  double G = mat->E / (2 * (1 + mat->nu));
+  double lambda = mat->nu * mat->E / ((1 - mat->nu * 2) * (1 + mat->nu));
+  double sqr_J = J * J;
+  double c0 = lambda * sqr_J;
+  double c1 = G - 0.5 * lambda * (sqr_J - 1);
+  double b_n[9];
+  left_cauchy_green(b_n, F_n, ndim);
+  double lenght_0 = 0.0, lenght_0_aux = 0.0;
+  for (int i = 0; i < ndim; i++) {
+    for (int j = 0; j < ndim; j++) lenght_0_aux += b_n[i * ndim + j] * dNa_n[j];
+    lenght_0 += dNb_n[i] * lenght_0_aux;
+    lenght_0_aux = 0.0;
+  }
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++)
+      Kd[i * ndim + j] = c0 * dNa_n1[i] * dNb_n1[j] + G * lenght_0 * (i == j) + c1 * dNa_n1[j] * dNb_n1[i];
+}
+
+/* __jacobian_evaluation, U-Newmark-beta.c:1646-1830, as a dense matrix K[ntot][ntot] (row-major, masked dof
+ * numbering, ntot = nactive*ndim): particle loop with stiffness_density__Constitutive__ (Constitutive.c:262-283)
+ * times V0 (:1768-1774), alpha_1 * lumped mass on the diagonal (:1797-1807) and, when dofs2mask is given,
+ * MatZeroRowsColumnsIS on the Dirichlet dofs with 1.0 on their diagonal (:1822).  pattern[ntot] (optional) is
+ * __create_sparsity_pattern, :1568-1632: the number of structurally visited columns of every row.
+ * Neo-Hookean particles only (returns 1 otherwise). */
+int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lumped_mass, const orc_particles *P,
+                       const orc_mesh *M, const orc_material *mats, const int *nodes2mask, const int *dofs2mask,
+                       int nactive) {
+  int ndim = M->ndim, T = P->T;
+  size_t ntot = (size_t)nactive * ndim;
+  int STATUS = 0;
+  unsigned char *visited = pattern ? (unsigned char *)calloc(ntot * ntot, 1) : NULL;
+  memset(K, 0, ntot * ntot * sizeof(double));
+  for (int p = 0; p < P->np; p++) {
+    const orc_material *mat = &mats[P->matidx[p]];
+    if (mat->type != 0) {
+      STATUS = 1;
+      break;
+    }
+    double dN[ORC_MAXNB * 3], dN1[ORC_MAXNB * 3], d_phi_mT[9];
+    int nn = orc_compute_dN(dN, P, M, p);
+    if (nn < 0 || adjunt(d_phi_mT, &P->DF[p * T], ndim)) { /* push_forward_dN__MeshTools__, Shape-Functions.c:405-448 */
+      STATUS = 1;
+      continue;
+    }
+    for (int A = 0; A < nn; A++)
+      for (int i = 0; i < ndim; i++) {
+        double s = 0.0;
+        for (int j = 0; j < ndim; j++) s += d_phi_mT[i * ndim + j] * dN[A * ndim + j];
+        dN1[A * ndim + i] = s;
+      }
+    double V0_p = P->vol0[p];
+    const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+    for (int A = 0; A < nn; A++) {
+      int Mask_node_A = nodes2mask[conn[A]];
+      for (int B = 0; B < nn; B++) {
+        int Mask_node_B = nodes2mask[conn[B]];
+        double Kd[9];
+        stiffness_density_neo_hookean(Kd, ndim, &dN1[A * ndim], &dN1[B * ndim], &dN[A * ndim], &dN[B * ndim],
+                                      &P->F_n[p * T], P->J_n1[p], mat);
+        for (int i = 0; i < ndim; i++)
+          for (int j = 0; j < ndim; j++) {
+            size_t at = ((size_t)Mask_node_A * ndim + i) * ntot + (size_t)Mask_node_B * ndim + j;
+            K[at] += Kd[i * ndim + j] * V0_p;
+            if (visited) visited[at] = 1;
+          }
+      }
+    }
+  }
+  if (lumped_mass)
+    for (size_t d = 0; d < ntot; d++) K[d * ntot + d] += alpha_1 * lumped_mass[d];
+  if (dofs2mask)
+    for (size_t d = 0; d < ntot; d++)
+      if (dofs2mask[d] == -1) {
+        for (size_t e = 0; e < ntot; e++) K[d * ntot + e] = K[e * ntot + d] = 0.0;
+        K[d * ntot + d] = 1.0;
+      }
+  if (pattern) {
+    for (size_t a = 0; a < ntot; a++) {
+      int c = 0;
+      for (size_t b = 0; b < ntot; b++) c += visited[a * ntot + b];
+      pattern[a] = c;
+    }
+    free(visited);
+  }
+  return STATUS;
+}
+
 /* __update_particles_internal_variables, U-Newmark-beta.c:1917-1978 */
 void orc_roll_state(orc_particles *P) {
   int T = P->T;

@@ -125,6 +125,10 @@ int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, con
                    double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep);
 int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
                         const int *dofs2mask);
+/* __jacobian_evaluation + __create_sparsity_pattern (U-Newmark-beta.c:1568-1830), Neo-Hookean, dense */
+int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lumped_mass, const orc_particles *P,
+                       const orc_mesh *M, const orc_material *mats, const int *nodes2mask, const int *dofs2mask,
+                       int nactive);
 void orc_roll_state(orc_particles *P);
 int orc_update_kinetics(double alpha_blend, const double *dU, const double *Un_dt,
                         const double *dU_dt, const double *dU_dt2, orc_particles *P,

@@ -276,6 +276,19 @@ def internal_forces(P, M, n2m, d2m, nactive):
     return R, st
 
 
+def tangent_matrix(P, M, mats, n2m, d2m, nactive, alpha_1=0.0, lumped_mass=None, with_pattern=True):
+    """dense Jacobian [ntot, ntot] in masked numbering and the per-row sparsity pattern"""
+    ntot = nactive * P.ndim
+    K = np.zeros((ntot, ntot))
+    pat = np.zeros(ntot, dtype=np.int32) if with_pattern else None
+    f = lib().orc_tangent_matrix
+    f.argtypes = [_dp, _ip, C.c_double, _dp, C.POINTER(CParticles), C.POINTER(Mesh), C.c_void_p, _ip, _ip, C.c_int]
+    st = f(_d(K), _i(pat) if pat is not None else None, float(alpha_1),
+           _d(lumped_mass) if lumped_mass is not None else None, C.byref(P.c), M.ptr, mats, _i(n2m),
+           _i(d2m) if d2m is not None else None, int(nactive))
+    return K, pat, st
+
+
 def roll_state(P):
     lib().orc_roll_state(C.byref(P.c))
 

@@ -315,6 +315,51 @@ def test_mixed_materials(ndim):
         assert_close(st[k], P[ok], 1e-9, f"mixed laws, level B: {k}")
 
 
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_tangent_matrix_neo_hookean(ndim):
+    """__jacobian_evaluation for Neo-Hookean particles.  The COO triplets of the device, summed
+    into a dense matrix, against the oracle's restatement of the reference loop: values, the alpha_1*M diagonal,
+    the Dirichlet identity rows and the sparsity pattern (integers: exact)."""
+    o = orc()
+    if ndim == 2:
+        case = make_case(2, [12, 11], [3, 3], [5, 4], material=NH, velocity=[1.0, -2.0])
+    else:
+        case = make_case(3, [8, 8, 7], [3, 3, 2], [2, 2, 2], material=NH, velocity=[1.0, -2.0, 0.5])
+    nsteps = 2
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    n2m, d2m, na = masks(S, M, bcs_list, 1, nsteps)
+    rng = np.random.default_rng(11)
+    dU = 2e-2 * rng.normal(size=na * ndim)
+    assert o.compatibility(dU, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+    S.local_compatibility_conditions(dU)
+    S.constitutive_update()
+    Mv = o.lumped_mass(P, M, n2m, na)
+    ntot = na * ndim
+    for alpha_1, mass, dirichlet in ((0.0, None, False), (4.0e4, Mv, True)):
+        K_o, pat_o, st = o.tangent_matrix(P, M, mats, n2m, d2m if dirichlet else None, na, alpha_1, mass)
+        assert st == 0
+        rows, cols, vals = S.jacobian_evaluation(alpha_1, mass, dirichlet)
+        assert rows.min() >= 0 and rows.max() < ntot and cols.min() >= 0 and cols.max() < ntot
+        K_g = np.zeros((ntot, ntot))
+        np.add.at(K_g, (rows, cols), vals)
+        assert_close(K_g, K_o, 1e-10, f"tangent matrix (alpha_1={alpha_1}, dirichlet={dirichlet})")
+        # every structurally visited entry is present exactly once
+        key = rows.astype(np.int64) * ntot + cols
+        assert np.unique(key).size == key.size
+        assert np.array_equal(S.create_sparsity_pattern(), pat_o), "sparsity pattern"
+        assert np.array_equal(np.bincount(rows, minlength=ntot), pat_o), "COO rows vs pattern"
+    assert np.abs(K_o - K_o.T).max() <= 1e-12 * np.abs(K_o).max()
+    # another law in the cloud is refused, not silently skipped
+    case2 = dict(case)
+    case2["materials"] = [HENCKY]
+    S2 = gpu_setup(case2, nsteps=nsteps)
+    masks(S2, M, bcs_list, 1, nsteps)
+    with pytest.raises(nlps().NlpsError):
+        S2.jacobian_evaluation()
+
+
 def test_device_pointer_nodal_vectors():
     """Nodal Vec arrays may live on the device (torch tensors) as well as on the host."""
     import torch

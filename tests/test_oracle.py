@@ -323,3 +323,56 @@ def test_config1_2d_10k_particles_cpu_path():
         assert abs(st.nodal("mass").reshape(-1, 2)[:, 0].sum() / m0 - 1) < 1e-12
     assert np.all(P["J_n"] > 0) and np.isfinite(P["stress"]).all()
     assert P["x"][:, 0].mean() > case["cloud"]["x"][:, 0].mean()
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_tangent_matrix_is_the_derivative_of_the_internal_forces(ndim):
+    """SURVEY §8f n1.  The restated __jacobian_evaluation (Neo-Hookean stiffness density, Neo-Hookean.c:89-141) has
+    no reference fixture; what pins it is calculus: column k of the matrix equals the central finite difference of
+    the internal-force vector (compatibility -> constitutive -> __nodal_internal_forces) with respect to dU_k.
+    Also: symmetry, the sparsity pattern against the lists, the Dirichlet identity rows."""
+    o = orc()
+    if ndim == 2:
+        case = make_case(2, [9, 8], [3, 3], [3, 2])
+    else:
+        case = make_case(3, [7, 7, 7], [3, 3, 3], [1, 1, 1])
+    M, P, prm, mats = oracle_setup(case)
+    n2m, na = o.active_nodes(M)
+    ntot = na * ndim
+    free = np.arange(ntot, dtype=np.int32)
+    rng = np.random.default_rng(1)
+    dU = 2e-2 * rng.normal(size=ntot)
+
+    def forces(u):
+        assert o.compatibility(u, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+        R, st = o.internal_forces(P, M, n2m, free, na)
+        assert st == 0
+        return R
+
+    forces(dU)
+    K, pat, st = o.tangent_matrix(P, M, mats, n2m, None, na)
+    assert st == 0
+    assert np.abs(K - K.T).max() <= 1e-13 * np.abs(K).max()
+    eps = 1e-6
+    for k in rng.choice(ntot, size=8, replace=False):
+        e = np.zeros(ntot)
+        e[k] = eps
+        fd = (forces(dU + e) - forces(dU - e)) / (2 * eps)
+        assert np.abs(fd - K[:, k]).max() <= 1e-8 * np.abs(K).max(), f"column {k}"
+    # pattern: a dof row sees ndim columns per node that shares a particle with its node
+    share = np.zeros((na, na), dtype=bool)
+    for p in range(P.np):
+        ids = n2m[P["list"][p, :P["nn"][p]]]
+        share[np.ix_(ids, ids)] = True
+    assert np.array_equal(pat, np.repeat(share.sum(axis=1) * ndim, ndim))
+    # Dirichlet dofs: identity rows and columns, the rest untouched
+    forces(dU)
+    d2m = free.copy()
+    d2m[[0, ntot - 1]] = -1
+    Kd, _, _ = o.tangent_matrix(P, M, mats, n2m, d2m, na, 3.0, np.full(ntot, 2.0))
+    for d in (0, ntot - 1):
+        row = np.zeros(ntot)
+        row[d] = 1.0
+        assert np.array_equal(Kd[d], row) and np.array_equal(Kd[:, d], row)
+    inner = np.ix_(np.arange(1, ntot - 1), np.arange(1, ntot - 1))
+    assert np.abs(Kd[inner] - (K + 6.0 * np.eye(ntot))[inner]).max() <= 1e-13 * np.abs(K).max(), "mass diagonal"
