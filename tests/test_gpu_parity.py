@@ -360,6 +360,123 @@ def test_tangent_matrix_neo_hookean(ndim):
         S2.jacobian_evaluation()
 
 
+class _OracleStages:
+    def __init__(self, case, nsteps):
+        self.o = orc()
+        self.ndim, self.nsteps = case["ndim"], nsteps
+        self.M, self.P, self.prm, self.mats = oracle_setup(case)
+
+    def local_search(self):
+        assert self.o.local_search(self.P, self.M, self.prm) == 0
+
+    def masks(self, bcs, step):
+        self.n2m, self.na = self.o.active_nodes(self.M)
+        self.d2m, _ = self.o.active_dofs(self.n2m, self.na, self.ndim, self.o.BccSet(bcs), step, self.nsteps)
+        return self.n2m, self.d2m, self.na
+
+    def lumped_mass(self):
+        return self.o.lumped_mass(self.P, self.M, self.n2m, self.na)
+
+    def nodal_field_n(self, Mv):
+        return self.o.nodal_field_n(Mv, self.P, self.M, self.n2m, self.d2m, self.na)
+
+    def compatibility(self, dU, dU_dt):
+        assert self.o.compatibility(dU, dU_dt, self.P, self.M, self.n2m) == 0
+
+    def constitutive(self):
+        assert self.o.constitutive(self.P, self.mats, self.prm) == 0
+
+    def internal_forces(self):
+        R, st = self.o.internal_forces(self.P, self.M, self.n2m, self.d2m, self.na)
+        assert st == 0
+        return R
+
+    def tangent(self, alpha_1, Mv):
+        K, _, st = self.o.tangent_matrix(self.P, self.M, self.mats, self.n2m, self.d2m, self.na, alpha_1, Mv,
+                                         with_pattern=False)
+        assert st == 0
+        return K
+
+    def roll(self):
+        self.o.roll_state(self.P)
+
+    def update_kinetics(self, dU, Un_dt, dU_dt, dU_dt2):
+        self.o.update_kinetics(1.0, dU, Un_dt, dU_dt, dU_dt2, self.P, self.M, self.n2m)
+
+
+class _DeviceStages:
+    def __init__(self, case, nsteps):
+        self.n = nlps()
+        self.ndim = case["ndim"]
+        self.S = gpu_setup(case, nsteps=nsteps)
+
+    def local_search(self):
+        self.S.local_search()
+
+    def masks(self, bcs, step):
+        n2m, d2m = self.S.active_masks(self.n.BccSet(bcs), step)
+        return n2m, d2m, self.S.nactive
+
+    def lumped_mass(self):
+        return self.S.compute_nodal_lumped_mass()
+
+    def nodal_field_n(self, Mv):
+        return self.S.get_nodal_field_n(Mv)
+
+    def compatibility(self, dU, dU_dt):
+        self.S.local_compatibility_conditions(dU, dU_dt)
+
+    def constitutive(self):
+        self.S.constitutive_update()
+
+    def internal_forces(self):
+        return self.S.nodal_internal_forces(np.zeros(self.S.nactive * self.ndim))
+
+    def tangent(self, alpha_1, Mv):
+        rows, cols, vals = self.S.jacobian_evaluation(alpha_1, Mv, True)
+        ntot = self.S.nactive * self.ndim
+        K = np.zeros((ntot, ntot))
+        np.add.at(K, (rows, cols), vals)
+        return K
+
+    def roll(self):
+        self.S.update_particles_internal_variables()
+
+    def update_kinetics(self, dU, Un_dt, dU_dt, dU_dt2):
+        self.S.update_particles_kinetics_FLIP_PIC(1.0, dU, Un_dt, dU_dt, dU_dt2)
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_implicit_newmark_steps_with_device_stages(ndim):
+    """The maintained driver's time step (U_Newmark_Beta, U-Newmark-beta.c:192-409) composed from the level-B
+    stage calls and the device tangent, three steps with gravity and a fixed floor, against the same host algebra
+    (tests/newmark.py) over the oracle.  The Newton iteration must converge quadratically with the device
+    tangent, take the same number of iterations and leave the same particles behind."""
+    from newmark import newmark_step
+    soft = {"type": 0, "E": 2.0e5, "nu": 0.3}
+    if ndim == 2:
+        case = make_case(2, [12, 11], [3, 3], [5, 4], material=soft, velocity=[0.5, -1.0])
+    else:
+        case = make_case(3, [8, 8, 7], [3, 3, 2], [2, 2, 2], material=soft, velocity=[0.5, 0.2, -1.0])
+    nsteps = 3
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3 if ndim == 2 else 2, nsteps)]
+    grav = [0.0] * (ndim - 1) + [-9.81]
+    dt = 2.0e-2  # 2.8 x the explicit CFL limit h / c: only an implicit step is stable here
+    A, B = _OracleStages(case, nsteps), _DeviceStages(case, nsteps)
+    for step in range(nsteps):
+        dU_o, hist_o = newmark_step(A, ndim, bcs_list, step, nsteps, dt, grav)
+        dU_g, hist_g = newmark_step(B, ndim, bcs_list, step, nsteps, dt, grav)
+        assert len(hist_o) == len(hist_g) and 2 <= len(hist_g) <= 8, (hist_o, hist_g)
+        assert hist_g[-1] <= 1e-10 * max(1.0, hist_g[0]), hist_g
+        if len(hist_g) >= 4:  # quadratic tail: the device tangent is the true Jacobian
+            assert hist_g[-1] <= 1e-3 * hist_g[-2], hist_g
+        assert_close(dU_g, dU_o, 1e-8, f"step {step}: converged dU")
+    st = B.S.download_state()
+    for k, ok in (("x", "x"), ("vel", "vel"), ("acc", "acc"), ("F_n", "F_n"), ("Stress", "stress"), ("J_n", "J_n")):
+        assert_close(st[k], A.P[ok], 1e-8, f"after implicit steps: {k}")
+    assert np.abs(A.P["stress"]).max() > 10.0
+
+
 def test_device_pointer_nodal_vectors():
     """Nodal Vec arrays may live on the device (torch tensors) as well as on the host."""
     import torch
