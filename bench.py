@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=16, help="cells per axis of the CPU-baseline sample")
     ap.add_argument("--halo", choices=["p2p", "allreduce"], default="p2p")
+    ap.add_argument("--overlap", type=int, choices=[0, 1], default=1,
+                    help="N > 1: run the halo exchanges behind the interior tiles (1) or blocking in place (0)")
     return ap.parse_args()
 
 
@@ -129,10 +131,13 @@ def main():
         halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)
         nnodes = gn[0] * gn[1] * gn[2]
 
-        def exchange(dptr, nfield, elem, kind):
-            return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind)
+        def exchange(dptr, nfield, elem, kind, phase):
+            return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind, phase)
 
         S.set_halo_exchange(exchange)
+        # the three exchanges of a step run behind the tiles that do not touch a ghost band
+        band_lo, band_hi = halo.ghost_bands(rank)
+        S.set_ghost_bands(band_lo, band_hi, a.overlap == 1)
         # per-step nodal work only on the layers this rank can touch (the grid grows with the rank count)
         S.set_node_window(lo[rank], hi[rank])
     S.initialise_shapefun()

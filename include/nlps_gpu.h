@@ -218,14 +218,22 @@ int nlps_gpu_sparsity_pattern(nlps_gpu *h, int *nnz_per_row);
  * handle's stream order.  dptr = device array [nnodes_grid][nfield] of `elem_bytes`-sized elements in
  * GRID numbering (x fastest, slab axis slowest => a slab halo is one contiguous byte range);
  * kind: 0 = sum doubles, 1 = OR bytes.  The callee sums/ORs the halo layers with the neighbouring
- * ranks (RCCL send/recv or all-reduce).  NULL = single GPU. */
-typedef int (*nlps_halo_fn)(void *ctx, void *dptr, int nfield, int elem_bytes, int kind);
+ * ranks (RCCL send/recv or all-reduce).  NULL = single GPU.
+ * phase: 0 = exchange now, in the order of the handle's stream; 1 = start the exchange (the callee may run it on
+ * a stream of its own, after making that stream wait for the work queued on the handle's stream so far);
+ * 2 = make the handle's stream wait for the exchange started by the matching phase-1 call.  Phases 1/2 are only
+ * used by nlps_gpu_explicit_step when nlps_gpu_set_ghost_bands(..., overlap = 1) was called. */
+typedef int (*nlps_halo_fn)(void *ctx, void *dptr, int nfield, int elem_bytes, int kind, int phase);
 int nlps_gpu_set_halo_exchange(nlps_gpu *h, nlps_halo_fn fn, void *ctx);
 /* Promise that the 5^d stencils of this rank's particles stay inside node layers [layer_lo, layer_hi] of the
  * slab (slowest) axis: the per-step nodal work of explicit_step / local_search (resets, nodal kernels, tile
  * launches) is limited to that window instead of the whole grid, so a rank's cost does not grow with the number
  * of ranks.  A particle that leaves the window raises status flag 16.  Default: the whole grid. */
 int nlps_gpu_set_node_window(nlps_gpu *h, int layer_lo, int layer_hi);
+/* Ghost bands of this rank: node layers <= band_lo and >= band_hi (slab axis) are shared with a neighbouring
+ * rank (pass band_lo < 0 / band_hi >= n_layers for "none").  overlap != 0: explicit_step orders its work so that
+ * every halo exchange runs behind the tiles and nodes that do not touch a band (two-phase callback above). */
+int nlps_gpu_set_ghost_bands(nlps_gpu *h, int band_lo, int band_hi, int overlap);
 /* Range of node layers along the slab axis this rank's particles may touch (5^d stencil reach). */
 int nlps_gpu_touched_layers(nlps_gpu *h, int *lo, int *hi);
 

@@ -73,6 +73,9 @@ struct ParamsD {
 #ifndef NLPS_JUNROLL_SCATTER
 #define NLPS_JUNROLL_SCATTER 5
 #endif
+#ifndef NLPS_JUNROLL_MASK
+#define NLPS_JUNROLL_MASK 1
+#endif
 #ifndef NLPS_K3_WAVES
 #define NLPS_K3_WAVES 2
 #endif

@@ -476,10 +476,10 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
 // nodal kernels (grid numbering)
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ void k_nodal_dU(int n0, int nnodes, NView N) {  // U-Verlet.c:357-362
-  int A = blockIdx.x * blockDim.x + threadIdx.x;
-  if (A >= nnodes) return;
-  A += n0;
+__global__ void k_nodal_dU(int n0, int nnodes, int n0b, int nnodesb, NView N) {  // U-Verlet.c:357-362
+  int A = blockIdx.x * blockDim.x + threadIdx.x;  // two node ranges: [n0, n0+nnodes) and [n0b, n0b+nnodesb)
+  if (A >= nnodes + nnodesb) return;
+  A = A < nnodes ? n0 + A : n0b + (A - nnodes);
   bool act = N.active[A];
   double M = N.nm[(size_t)A * (1 + ND)];
 #pragma unroll
@@ -488,10 +488,11 @@ __global__ void k_nodal_dU(int n0, int nnodes, NView N) {  // U-Verlet.c:357-362
 
 template <int ND>
 __global__ void k_bc(const int* __restrict__ nodes, int n, int dim, int dirbits, double v0, double v1, double v2,
-                     NView N) {  // impose_Dirichlet_Boundary_Conditions, U-Verlet.c:455-527
+                     NView N, int r0, int r1, int inside) {  // impose_Dirichlet_Boundary_Conditions, U-Verlet.c:455-527
   int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   int A = nodes[q];
+  if (((A >= r0 && A < r1) ? 1 : 0) != inside) return;  // node-range filter (interior / ghost-band passes)
   if (!N.active[A]) return;
   double v[3] = {v0, v1, v2};
 #pragma unroll
@@ -503,10 +504,10 @@ __global__ void k_bc(const int* __restrict__ nodes, int n, int dim, int dirbits,
 }
 
 template <int ND>
-__global__ void k_nodal_accel(int n0, int nnodes, NView N, double g0, double g1, double g2) {  // U-Verlet.c:947-957
+__global__ void k_nodal_accel(int n0, int nnodes, int n0b, int nnodesb, NView N, double g0, double g1, double g2) {  // U-Verlet.c:947-957
   int A = blockIdx.x * blockDim.x + threadIdx.x;
-  if (A >= nnodes) return;
-  A += n0;
+  if (A >= nnodes + nnodesb) return;
+  A = A < nnodes ? n0 + A : n0b + (A - nnodes);
   bool act = N.active[A];
   double M = N.nm[(size_t)A * (1 + ND)];
   double gv[3] = {g0, g1, g2};
@@ -723,7 +724,9 @@ struct nlps_gpu {
   int* tile_count_d;
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
-  int* nwork_d = nullptr;
+  int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists (k_tile_scan)
+  int band_lo = -(1 << 30), band_hi = 1 << 30;  // ghost bands: layers <= band_lo and >= band_hi are shared with neighbours
+  bool overlap = false;     // overlap the halo exchanges with the interior tiles (needs bands + a two-phase callback)
   unsigned long long* phase_d = nullptr;
   // tangent assembly, allocated on first use
   double* kst_d = nullptr;           // [nnodes][S][d*d]
@@ -925,6 +928,13 @@ extern "C" int nlps_gpu_debug_phases(nlps_gpu* h, unsigned long long* out, int r
   return 0;
 }
 #endif
+
+extern "C" int nlps_gpu_set_ghost_bands(nlps_gpu* h, int band_lo, int band_hi, int overlap) {
+  h->band_lo = band_lo;
+  h->band_hi = band_hi;
+  h->overlap = overlap != 0;
+  return 0;
+}
 
 extern "C" int nlps_gpu_touched_layers(nlps_gpu* h, int* lo, int* hi) {
   *lo = h->slab_lo;
@@ -1129,7 +1139,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->tile_start_d, (size_t)h->ntiles + 1)) return 1;
   if (dev_alloc(h, &h->work1_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
-  if (dev_alloc(h, &h->nwork_d, 2)) return 1;
+  if (dev_alloc(h, &h->nwork_d, 12)) return 1;
 #if NLPS_PHASE_TIMING
   if (dev_alloc(h, &h->phase_d, 16 * 1024)) return 1;
 #endif
@@ -1359,9 +1369,9 @@ extern "C" int nlps_gpu_status_flags(nlps_gpu* h, int* flags) {
   return 0;
 }
 
-static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind) {
+static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase = 0) {
   if (!h->halo) return 0;
-  int st = h->halo(h->halo_ctx, dptr, nfield, elem, kind);
+  int st = h->halo(h->halo_ctx, dptr, nfield, elem, kind, phase);
   if (st) {
     h->err = "halo exchange callback failed";
     return 1;
@@ -1396,14 +1406,14 @@ static TileCnt tile_cnt(nlps_gpu* h, bool on) {
   tc.gstatus = h->gstatus_d;
   return tc;
 }
-static TileD tile_view(nlps_gpu* h) {
+static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 boundary, 2 interior
   TileD td;
   for (int a = 0; a < 3; a++) td.nt[a] = h->nt[a];
   td.ntiles = h->ntiles;
   td.tile0 = h->tile0;
   td.work[0] = h->work1_d;
   td.work[1] = h->work2_d;
-  td.nwork = h->nwork_d;
+  td.range = h->nwork_d + 4 * cls;
   td.phase = h->phase_d;
   td.start = h->tile_start_d;
   td.count = h->tile_count_d;
@@ -1413,23 +1423,23 @@ static TileD tile_view(nlps_gpu* h) {
 
 // S1: closest node + activation (+ binning of the particles to I0-tiles when `tiled`), then lists,
 // beta and the Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`, tiled form only)
-static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm) {
-  int np = h->P.np;
-  LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
-            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0);
-  TileCnt tc = tile_cnt(h, true);
-  if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
-  else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d + h->tile0,
-                     h->tile_start_d + h->tile0, h->ntw, h->tile0, h->work1_d, h->work2_d, h->nwork_d);
-  hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
-                     h->order_d);
-  HIPCHK(hipGetLastError());
-  LAUNCH_ND((k_dilate<2>), (k_dilate<3>), nblk(h->nwn), h->n0, h->nwn, h->g, h->N);
-  if (halo(h, h->N.active, 1, 1, 1)) return 1;
-  if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  TileD td = tile_view(h);
+// node ranges of the per-step nodal kernels: part 0 = the whole node window, 1 = the nodes outside the ghost
+// bands, 2 = the ghost bands (two ranges)
+struct NodeRanges {
+  int a0, an, b0, bn;
+};
+static NodeRanges node_ranges(nlps_gpu* h, int part) {
+  const int plane = h->g.nnodes / h->g.n[h->nd - 1];
+  const int lo = h->win_lo, hi = h->win_hi;
+  const int il = std::max(lo, std::min(hi + 1, h->band_lo + 1));  // first layer outside the low band
+  const int ih = std::min(hi + 1, std::max(il, h->band_hi));      // first layer of the high band
+  if (part == 0) return {lo * plane, (hi - lo + 1) * plane, 0, 0};
+  if (part == 1) return {il * plane, (ih - il) * plane, 0, 0};
+  return {lo * plane, (il - lo) * plane, ih * plane, (hi + 1 - ih) * plane};
+}
+
+static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm) {
+  TileD td = tile_view(h, cls);
   const dim3 grid(h->ntw * K2_SPLIT), blk(BLK);
   if (h->nd == 2) {
     if (p2g) hipLaunchKernelGGL((k2_tile<2, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
@@ -1437,6 +1447,36 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   } else {
     if (p2g) hipLaunchKernelGGL((k2_tile<3, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
     else hipLaunchKernelGGL((k2_tile<3, false>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+  }
+}
+
+// S1: closest-node update + 1-ring activation + binning of the particles to I0-tiles, then lists, beta and the
+// Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`).  With `overlap` the exchange of the active
+// flags runs behind the tiles that do not touch a ghost band.
+static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, bool overlap = false) {
+  int np = h->P.np;
+  LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
+            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0);
+  TileCnt tc = tile_cnt(h, true);
+  if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
+  else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
+  LAUNCH_ND((k_dilate<2>), (k_dilate<3>), nblk(h->nwn), h->n0, h->nwn, h->g, h->N);
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->N.active, 1, 1, 1, overlap ? 1 : 0)) return 1;
+  const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d + h->tile0,
+                     h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB, h->band_lo,
+                     h->band_hi, h->work1_d, h->work2_d, h->nwork_d);
+  hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
+                     h->order_d);
+  HIPCHK(hipGetLastError());
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
+  if (overlap) {
+    launch_k2(h, p2g, 2, dt, gamma_nm);
+    if (halo(h, h->N.active, 1, 1, 1, 2)) return 1;
+    launch_k2(h, p2g, 1, dt, gamma_nm);
+  } else {
+    launch_k2(h, p2g, 0, dt, gamma_nm);
   }
   HIPCHK(hipGetLastError());
   h->masks_valid = false;
@@ -1696,31 +1736,43 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   h->steps_since_sort++;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  // (nodal accumulators of the node window are reset by k_step_clear inside search_and_lists)
-  // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel)
-  if (search_and_lists(h, false, true, dt, gamma_nm)) return 1;
-  if (halo(h, h->N.nm, 1 + ND, 8, 0)) return 1;
-  if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-  // nodal: dU = (sum m N dD) / M, Dirichlet values
-  if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N);
-  else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N);
-  for (int i = 0; i < nbcc; i++) {
-    if (h->bcs[i].n == 0) continue;
-    double v[3] = {0, 0, 0};
-    for (int k = 0; k < bcc[i].dim && k < 3; k++) v[k] = bcc[i].value[(size_t)k * h->nsteps + step];
-    int bits = dirbits_of(bcc[i], step, h->nsteps);
-    if (ND == 2)
-      hipLaunchKernelGGL(k_bc<2>, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n,
-                         bcc[i].dim, bits, v[0], v[1], v[2], h->N);
-    else
-      hipLaunchKernelGGL(k_bc<3>, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n,
-                         bcc[i].dim, bits, v[0], v[1], v[2], h->N);
-  }
-  HIPCHK(hipGetLastError());
-  if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-  // S3 + S4
-  {
-    TileD td = tile_view(h);
+  // With a halo callback and ghost bands set, every exchange is started right after the tiles that touch a
+  // ghost band have produced their part and is waited for only before those tiles need the result; the tiles
+  // (and nodes) away from the bands run in between, on the handle's stream, while the exchange proceeds on the
+  // callee's stream.  Without overlap each stage is one pass over all tiles and the exchange blocks in place.
+  const bool ov = h->halo && h->overlap;
+  double gv[3] = {0, 0, 0};
+  if (gravity)
+    for (int a = 0; a < ND; a++) gv[a] = gravity[a];
+  auto nodal_dU = [&](int part) {
+    const NodeRanges r = node_ranges(h, part);
+    if (r.an + r.bn == 0) return;
+    if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N);
+    else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N);
+    // Dirichlet values (nodes of the same range only)
+    const NodeRanges in = node_ranges(h, 1);
+    for (int i = 0; i < nbcc; i++) {
+      if (h->bcs[i].n == 0) continue;
+      double v[3] = {0, 0, 0};
+      for (int k = 0; k < bcc[i].dim && k < 3; k++) v[k] = bcc[i].value[(size_t)k * h->nsteps + step];
+      int bits = dirbits_of(bcc[i], step, h->nsteps);
+      const int r0 = part == 0 ? 0 : in.a0, r1 = part == 0 ? h->g.nnodes : in.a0 + in.an, inside = part == 2 ? 0 : 1;
+      if (ND == 2)
+        hipLaunchKernelGGL(k_bc<2>, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n,
+                           bcc[i].dim, bits, v[0], v[1], v[2], h->N, r0, r1, inside);
+      else
+        hipLaunchKernelGGL(k_bc<3>, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n,
+                           bcc[i].dim, bits, v[0], v[1], v[2], h->N, r0, r1, inside);
+    }
+  };
+  auto nodal_accel = [&](int part) {
+    const NodeRanges r = node_ranges(h, part);
+    if (r.an + r.bn == 0) return;
+    if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2]);
+    else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2]);
+  };
+  auto launch_k3 = [&](int cls) {
+    TileD td = tile_view(h, cls);
 #define NLPS_K3(NDv, LAWv)                                                                                      \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d, (const double*)nullptr)
@@ -1737,19 +1789,9 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else NLPS_K3(3, -1);
     }
 #undef NLPS_K3
-  }
-  HIPCHK(hipGetLastError());
-  if (halo(h, h->N.force, ND, 8, 0)) return 1;
-  if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
-  double gv[3] = {0, 0, 0};
-  if (gravity)
-    for (int a = 0; a < ND; a++) gv[a] = gravity[a];
-  if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N, gv[0], gv[1], gv[2]);
-  else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(h->nwn)), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N, gv[0], gv[1], gv[2]);
-  if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
-  // S5
-  {
-    TileD td = tile_view(h);
+  };
+  auto launch_k5 = [&](int cls) {
+    TileD td = tile_view(h, cls);
 #define NLPS_K5(NDv, LAWv) \
   hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
     const int law = h->uniform_law;
@@ -1761,6 +1803,40 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else NLPS_K5(3, 2);
     }
 #undef NLPS_K5
+  };
+  // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel; the nodal accumulators of
+  // the node window are reset by k_step_clear inside search_and_lists)
+  if (search_and_lists(h, false, true, dt, gamma_nm, ov)) return 1;
+  if (halo(h, h->N.nm, 1 + ND, 8, 0, ov ? 1 : 0)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+  // nodal dU = (sum m N dD) / M + Dirichlet values; S3 + S4
+  if (ov) {
+    nodal_dU(1);
+    launch_k3(2);
+    if (halo(h, h->N.nm, 1 + ND, 8, 0, 2)) return 1;
+    nodal_dU(2);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    launch_k3(1);
+  } else {
+    nodal_dU(0);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    launch_k3(0);
+  }
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->N.force, ND, 8, 0, ov ? 1 : 0)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
+  // nodal acceleration; S5
+  if (ov) {
+    nodal_accel(1);
+    launch_k5(2);
+    if (halo(h, h->N.force, ND, 8, 0, 2)) return 1;
+    nodal_accel(2);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    launch_k5(1);
+  } else {
+    nodal_accel(0);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    launch_k5(0);
   }
   HIPCHK(hipGetLastError());
   h->P.flip ^= 1;  // F_n <- F_n+1, b_e,n <- b_e,n+1 by renaming

@@ -52,7 +52,10 @@ struct TileD {
   // Consecutive workgroups go to different XCDs, so a compacted list spreads the populated tiles evenly over
   // the 8 XCDs whatever the shape of the cloud (tile-index order left XCDs 23 % apart for the cube).
   const int2* work[2];
-  const int* nwork;
+  // Workgroup range of the launch inside work[S-1]: {begin, end} at range[2*(S-1)].  The lists hold the tiles whose
+  // window touches a ghost band (nodes shared with a neighbouring rank) first, so a launch can take all tiles,
+  // only the "boundary" ones or only the "interior" ones (overlap of the halo exchange with interior work).
+  const int* range;
   unsigned long long* phase;  // -DNLPS_PHASE_TIMING=1 only: per-phase wave-cycle sums (developer profiling)
 };
 
@@ -137,28 +140,48 @@ __device__ __forceinline__ int block_scan_1024(int v, int* sh, int* total) {
 
 // exclusive scan of the per-tile particle counts + the compacted work lists (one 1024-thread block).
 // count/start are already offset to the first tile of the node window; tile0 = that tile's index.
-__global__ void k_tile_scan(const int* __restrict__ count, int* __restrict__ start, int n, int tile0,
-                            int2* __restrict__ work1, int2* __restrict__ work2, int* __restrict__ nwork) {
+// A tile is "boundary" when its node window reaches a ghost band: slow-axis layers <= band_lo or >= band_hi
+// (tpl = tiles per slow-axis tile layer, TB = tile edge).  ranges[cls][S-1] = {begin, end} in work<S> for
+// cls 0 = all, 1 = boundary, 2 = interior.
+__global__ void k_tile_scan(const int* __restrict__ count, int* __restrict__ start, int n, int tile0, int tpl, int TB,
+                            int band_lo, int band_hi, int2* __restrict__ work1, int2* __restrict__ work2,
+                            int* __restrict__ ranges) {
   __shared__ int sh[1024];
   int chunk = (n + 1023) / 1024;
-  int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0, n1 = 0, n2 = 0;
+  int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0, b1 = 0, b2 = 0, i1 = 0, i2 = 0;
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
     c += cq;
-    n1 += cq > 0;
-    n2 += (cq > 0) + (cq > BLK);
+    const int tz = (tile0 + q) / tpl;
+    const bool bnd = (tz * TB - 2 <= band_lo) || (tz * TB + TB + 1 >= band_hi);
+    const int e1 = cq > 0, e2 = (cq > 0) + (cq > BLK);
+    if (bnd) {
+      b1 += e1;
+      b2 += e2;
+    } else {
+      i1 += e1;
+      i2 += e2;
+    }
   }
-  int tot;
+  int nb1, nb2, ni1, ni2, tot;
   int run = block_scan_1024(c, sh, &tot);
-  int r1 = block_scan_1024(n1, sh, &tot);
-  if (threadIdx.x == 0) nwork[0] = tot;
-  int r2 = block_scan_1024(n2, sh, &tot);
-  if (threadIdx.x == 0) nwork[1] = tot;
+  int rb1 = block_scan_1024(b1, sh, &nb1);
+  int rb2 = block_scan_1024(b2, sh, &nb2);
+  int ri1 = block_scan_1024(i1, sh, &ni1) + nb1;
+  int ri2 = block_scan_1024(i2, sh, &ni2) + nb2;
+  if (threadIdx.x == 0) {
+    const int r[12] = {0, nb1 + ni1, 0, nb2 + ni2, 0, nb1, 0, nb2, nb1, nb1 + ni1, nb2, nb2 + ni2};
+    for (int k = 0; k < 12; k++) ranges[k] = r[k];
+  }
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
     start[q] = run;
     run += cq;
     if (cq > 0) {
+      const int tz = (tile0 + q) / tpl;
+      const bool bnd = (tz * TB - 2 <= band_lo) || (tz * TB + TB + 1 >= band_hi);
+      int& r1 = bnd ? rb1 : ri1;
+      int& r2 = bnd ? rb2 : ri2;
       work1[r1++] = make_int2(tile0 + q, 0);
       work2[r2++] = make_int2(tile0 + q, 0);
       if (cq > BLK) work2[r2++] = make_int2(tile0 + q, 1);
@@ -210,8 +233,9 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
   constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NW];
   __shared__ unsigned actrow[NROWS];
-  if ((int)blockIdx.x >= td.nwork[K2_SPLIT - 1]) return;
-  const int2 wk = td.work[K2_SPLIT - 1][blockIdx.x];
+  const int wb = td.range[2 * (K2_SPLIT - 1)] + (int)blockIdx.x;
+  if (wb >= td.range[2 * (K2_SPLIT - 1) + 1]) return;
+  const int2 wk = td.work[K2_SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
   PH_INIT
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
     for (int k = 0; k < KN; k++) {
       const double lz2k = (ND == 3) ? lz2[k] : 0.0;
       unsigned pbits = 0u;
-#pragma unroll 1
+#pragma unroll NLPS_JUNROLL_MASK
       for (int j = 0; j < 5; j++) {
         const int row = (by + j - 2) + (ND == 3 ? W * (bz + k - 2) : 0);
         const unsigned actbits = (actrow[row] >> (bx - 2)) & 31u;
@@ -405,8 +429,9 @@ __global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, 
   __shared__ __attribute__((aligned(16))) double duxy[2 * NW];
   __shared__ double duz[(ND == 3) ? NW : 1];
   __shared__ double fac[ND * NW];
-  if ((int)blockIdx.x >= td.nwork[K3_SPLIT - 1]) return;
-  const int2 wk = td.work[K3_SPLIT - 1][blockIdx.x];
+  const int wb = td.range[2 * (K3_SPLIT - 1)] + (int)blockIdx.x;
+  if (wb >= td.range[2 * (K3_SPLIT - 1) + 1]) return;
+  const int2 wk = td.work[K3_SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
   PH_INIT
@@ -699,8 +724,9 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ __attribute__((aligned(16))) double axy[2 * NW];
   __shared__ double az[(ND == 3) ? NW : 1];
-  if ((int)blockIdx.x >= td.nwork[K5_SPLIT - 1]) return;
-  const int2 wk = td.work[K5_SPLIT - 1][blockIdx.x];
+  const int wb = td.range[2 * (K5_SPLIT - 1)] + (int)blockIdx.x;
+  if (wb >= td.range[2 * (K5_SPLIT - 1) + 1]) return;
+  const int2 wk = td.work[K5_SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
   int w0[3];
@@ -807,8 +833,9 @@ __global__ __launch_bounds__(BLK) void kb_p2g_tile(PView P, GridD g, TileD td, d
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NF = MODE == 0 ? 1 : 2 * ND;
   __shared__ double acc[NF * NW];
-  if ((int)blockIdx.x >= td.nwork[0]) return;
-  const int tile = td.work[0][blockIdx.x].x;
+  const int wb = td.range[0] + (int)blockIdx.x;
+  if (wb >= td.range[1]) return;
+  const int tile = td.work[0][wb].x;
   const int cnt = td.count[tile];
   int w0[3];
   tile_origin<ND>(td, tile, w0);
@@ -872,8 +899,9 @@ __global__ __launch_bounds__(BLK) void kb_fint_tile(PView P, GridD g, TileD td, 
                                                     int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ double fac[ND * NW];
-  if ((int)blockIdx.x >= td.nwork[0]) return;
-  const int tile = td.work[0][blockIdx.x].x;
+  const int wb = td.range[0] + (int)blockIdx.x;
+  if (wb >= td.range[1]) return;
+  const int tile = td.work[0][wb].x;
   const int cnt = td.count[tile];
   int w0[3];
   tile_origin<ND>(td, tile, w0);
@@ -943,8 +971,9 @@ __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD 
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NV = 4 * ND, NP = NV / 2;
   __shared__ __attribute__((aligned(16))) double win[NW * NV];
-  if ((int)blockIdx.x >= td.nwork[0]) return;
-  const int tile = td.work[0][blockIdx.x].x;
+  const int wb = td.range[0] + (int)blockIdx.x;
+  if (wb >= td.range[1]) return;
+  const int tile = td.work[0][wb].x;
   const int cnt = td.count[tile];
   int w0[3];
   tile_origin<ND>(td, tile, w0);

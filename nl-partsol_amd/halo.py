@@ -15,7 +15,7 @@ class SlabHalo:
         self.torch, self.dist, self.rank, self.world, self.mode = torch, dist, rank, world, mode
         self.plane, self.nz = int(plane_nodes), int(nlayers)
         self.lo, self.hi = list(lo), list(hi)
-        self.plans, self.tensors = {}, {}
+        self.plans, self.tensors, self.pending, self.side = {}, {}, {}, None
         for r in range(world - 2):
             if self.hi[r] >= self.lo[r + 2]:
                 raise ValueError("slabs too thin: rank %d overlaps rank %d" % (r, r + 2))
@@ -97,13 +97,39 @@ class SlabHalo:
                 torch.maximum(sl, r, out=sl)
         return 0
 
-    def exchange_ptr(self, dptr, nelem, nfield, elem_bytes, kind):
-        """Entry point for the C callback: wraps the raw device pointer once and reuses the tensor."""
+    def ghost_bands(self, rank):
+        """(band_lo, band_hi): node layers <= band_lo are shared with rank-1, layers >= band_hi with rank+1."""
+        lo_ov = self.overlap(rank, rank - 1) if rank > 0 else None
+        hi_ov = self.overlap(rank, rank + 1) if rank + 1 < self.world else None
+        return (lo_ov[1] if lo_ov else -1), (hi_ov[0] if hi_ov else self.nz)
+
+    def exchange_ptr(self, dptr, nelem, nfield, elem_bytes, kind, phase=0):
+        """Entry point for the C callback: wraps the raw device pointer once and reuses the tensor.
+        phase 0: exchange in the order of the current stream.  phase 1: start the exchange on a side stream that
+        first waits for everything queued on the current stream; phase 2: the current stream waits for it.  The
+        library runs the tiles that do not touch a ghost band between the two (nlps_gpu_set_ghost_bands)."""
+        torch = self.torch
         t = self.tensors.get((dptr, nelem, elem_bytes))
         if t is None:
-            t = device_tensor(self.torch, dptr, nelem, elem_bytes)
+            t = device_tensor(torch, dptr, nelem, elem_bytes)
             self.tensors[(dptr, nelem, elem_bytes)] = t
-        return self.exchange(t, nfield, kind)
+        if phase == 0 or self.world == 1:
+            return self.exchange(t, nfield, kind) if phase != 2 else 0
+        if phase == 1:
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                st = self.exchange(t, nfield, kind)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self.pending[(dptr, nfield, kind)] = ev
+            return st
+        ev = self.pending.pop((dptr, nfield, kind), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return 0
 
 
 def device_tensor(torch, dptr, n, elem_bytes):

@@ -53,7 +53,7 @@ class Bcc(C.Structure):
     _fields_ = [("nnodes", C.c_int), ("nodes", _ip), ("dim", C.c_int), ("dir", _ip), ("value", _dp)]
 
 
-HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int)
 
 _LIB = None
 
@@ -64,7 +64,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window",
+           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_coo", "nlps_gpu_sparsity_pattern",
            "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
 
@@ -90,6 +90,7 @@ def lib():
                                       C.POINTER(Material), C.c_int, C.POINTER(Particles), C.c_int, C.c_void_p]
         L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.nlps_gpu_set_ghost_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_tangent_assemble.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.nlps_gpu_tangent_coo.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, _ip, _ip, _dp]
         L.nlps_gpu_sparsity_pattern.argtypes = [C.c_void_p, _ip]
@@ -346,14 +347,21 @@ class Solver:
 
     # ------------------------------------------------------------------ multi-GPU / measurement
     def set_halo_exchange(self, pyfunc):
-        """pyfunc(dptr:int, nfield:int, elem_bytes:int, kind:int) -> int"""
+        """pyfunc(dptr:int, nfield:int, elem_bytes:int, kind:int[, phase:int]) -> int
+        (phase 0 = exchange now, 1 = start, 2 = wait; a 4-argument function only ever sees blocking exchanges)"""
         if pyfunc is None:
             self._halo_cb = None
             self._chk(self.L.nlps_gpu_set_halo_exchange(self.h, C.cast(None, HALO_FN), None))
             return
+        import inspect
+        with_phase = len(inspect.signature(pyfunc).parameters) >= 5
 
-        def _cb(ctx, dptr, nfield, elem, kind):
+        def _cb(ctx, dptr, nfield, elem, kind, phase):
             try:
+                if with_phase:
+                    return int(pyfunc(dptr, nfield, elem, kind, phase) or 0)
+                if phase == 2:
+                    return 0  # the matching start call already did the whole exchange in stream order
                 return int(pyfunc(dptr, nfield, elem, kind) or 0)
             except Exception as e:  # never let an exception cross the C boundary
                 print("halo exchange failed:", repr(e))
@@ -387,6 +395,9 @@ class Solver:
         pat = np.zeros(self.nactive * self.ndim, dtype=np.int32)
         self._chk(self.L.nlps_gpu_sparsity_pattern(self.h, _i(pat)))
         return pat
+
+    def set_ghost_bands(self, band_lo, band_hi, overlap=True):
+        self._chk(self.L.nlps_gpu_set_ghost_bands(self.h, int(band_lo), int(band_hi), 1 if overlap else 0))
 
     def set_node_window(self, layer_lo, layer_hi):
         self._chk(self.L.nlps_gpu_set_node_window(self.h, int(layer_lo), int(layer_hi)))

@@ -45,8 +45,12 @@ def main():
     lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[2], reach=3)
     halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi)
     nnodes = gn[0] * gn[1] * gn[2]
-    S.set_halo_exchange(lambda dptr, nfield, elem, kind: halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind))
+    S.set_halo_exchange(lambda dptr, nfield, elem, kind, phase: halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem,
+                                                                                 kind, phase))
     S.set_node_window(lo[rank], hi[rank])
+    overlap = os.environ.get("NLPS_OVERLAP", "1") == "1"
+    band_lo, band_hi = halo.ghost_bands(rank)
+    S.set_ghost_bands(band_lo, band_hi, overlap)  # exchanges behind the interior tiles (two-phase callback)
     S.set_resort_interval(2)
     S.initialise_shapefun()
     gb = nlps.BccSet([bc])
@@ -86,7 +90,7 @@ def main():
             got = np.concatenate([p[k] for p in parts])
             util.assert_close(got, ref[k], 1e-11 if k != "lambda" else 1e-9, "%s partitioned vs whole" % k)
         assert np.abs(ref["Stress"]).max() > 1.0, "the case must deform"
-        print("MULTIRANK_GPU_OK world=%d particles=%d" % (world, ref["x"].shape[0]))
+        print("MULTIRANK_GPU_OK world=%d particles=%d overlap=%s" % (world, ref["x"].shape[0], overlap))
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1

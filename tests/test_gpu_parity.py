@@ -585,14 +585,49 @@ def test_halo_callback_and_rccl_on_library_memory():
     S2.explicit_step(gb, 0, 1e-3)
     a, b = S.download_state(), S2.download_state()
     assert_close(a["x"], b["x"], 1e-13, "x with/without halo hook")
+    # two-phase form: every exchange is an RCCL all-reduce on a side stream, started behind the boundary tiles and
+    # waited for before they need it (ghost bands inside the cloud make both tile classes non-empty)
+    S3 = gpu_setup(case, nsteps=3, stream=stream)
+    side = torch.cuda.Stream()
+    pending, phases = {}, []
+
+    def exchange2(dptr, nfield, elem, kind, phase):
+        phases.append(phase)
+        t = halo_mod.device_tensor(torch, dptr, nnodes * nfield, elem)
+        if phase == 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == 0 else dist.ReduceOp.MAX)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            pending[(dptr, kind)] = ev
+        elif phase == 2:
+            torch.cuda.current_stream().wait_event(pending.pop((dptr, kind)))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if kind == 0 else dist.ReduceOp.MAX)
+        return 0
+
+    S3.set_halo_exchange(exchange2)
+    lo, hi = S3.touched_layers()
+    S3.set_ghost_bands(lo + 4, hi - 4, True)
+    for t in range(3):
+        S3.explicit_step(gb, t, 1e-3)
+        S2.explicit_step(gb, t, 1e-3) if t > 0 else None
+    S3.synchronize()
+    assert phases[:6] == [1, 2, 1, 2, 1, 2] and not pending and S3.status_flags() == 0
+    c, b = S3.download_state(), S2.download_state()
+    for k in ("x", "vel", "Stress", "F_n"):
+        assert_close(c[k], b[k], 1e-12, f"{k}: overlapped exchanges vs none")
+    assert np.array_equal(c["I0"], b["I0"])
     if created:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multirank_on_one_gpu(world):
+@pytest.mark.parametrize("world,overlap", [(2, 1), (3, 1), (3, 0)])
+def test_multirank_on_one_gpu(world, overlap):
     """N > 1 rehearsal on the one card of the test box: `world` processes, each with its slab, the halo
-    callback, the node window and periodic re-sorts, against one solver holding the whole cloud
+    callback (with and without overlapping the exchanges with the interior tiles), the node window and periodic
+    re-sorts, against one solver holding the whole cloud
     (tests/mr_gpu_worker.py; gloo with host staging stands in for RCCL, which needs one GPU per rank)."""
     import os
     import subprocess
@@ -601,7 +636,8 @@ def test_multirank_on_one_gpu(world):
     port = 29600 + (os.getpid() + world) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mr_gpu_worker.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    env = dict(os.environ, NLPS_OVERLAP=str(overlap))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
