@@ -654,6 +654,12 @@ __global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __
   vals[p] = p;
 }
 template <class T>
+__global__ void k_copy(T* __restrict__ out, const T* __restrict__ in, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+template <class T>
 __global__ void k_gather(T* __restrict__ out, const T* __restrict__ in, const int* __restrict__ idx, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[idx[i]];
@@ -843,7 +849,9 @@ static void host_h_avg(const nlps_grid& G, const nlps_host::StencilTables& tab, 
 template <class T>
 static int dev_alloc(nlps_gpu* h, T** p, size_t n) {
   HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
-  HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(T), h->stream));
+  // default stream, like the uploads that may follow: on the handle's stream a caller-provided NON-BLOCKING
+  // stream (torch's are) could run this after them and wipe the upload
+  HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
   return 0;
 }
 
@@ -1197,6 +1205,9 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
                                             0, 64, h->stream));
   HIPCHK(hipMalloc(&h->cub_tmp, h->cub_tmp_bytes + 16));
   HIPCHK(hipStreamSynchronize(h->stream));
+  // the uploads above are ordered on the default stream only: a caller-provided non-blocking stream (torch
+  // streams are) would not wait for their DMA
+  HIPCHK(hipDeviceSynchronize());
   return 0;
 }
 
@@ -1219,17 +1230,17 @@ static int resort(nlps_gpu* h) {
   for (int f = 0; f < nf; f++) {
     double* fld = h->P.d + (size_t)f * npad;
     hipLaunchKernelGGL(k_gather<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->gather_tmp, fld, idx, np);
-    HIPCHK(hipMemcpyAsync(fld, h->gather_tmp, (size_t)np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_copy<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, fld, (const double*)h->gather_tmp, np);
   }
   int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d};
   for (int* a : iarr) {
     hipLaunchKernelGGL(k_gather<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (int*)h->gather_tmp, a, idx, np);
-    HIPCHK(hipMemcpyAsync(a, h->gather_tmp, (size_t)np * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_copy<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, a, (const int*)h->gather_tmp, np);
   }
   u64* uarr[] = {h->P.mlo, h->P.mhi};
   for (u64* a : uarr) {
     hipLaunchKernelGGL(k_gather<u64>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (u64*)h->gather_tmp, a, idx, np);
-    HIPCHK(hipMemcpyAsync(a, h->gather_tmp, (size_t)np * sizeof(u64), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_copy<u64>, dim3(nblk(np)), dim3(BLK), 0, h->stream, a, (const u64*)h->gather_tmp, np);
   }
   HIPCHK(hipGetLastError());
   h->perm_dirty = true;
@@ -1537,6 +1548,9 @@ static int ensure_bcs(nlps_gpu* h, const nlps_bcc* bcc, int nbcc) {
     }
     h->bcs.push_back(b);
   }
+  // the copies above are ordered on the default stream only: a caller-provided non-blocking stream (torch
+  // streams are) would not wait for their DMA
+  HIPCHK(hipDeviceSynchronize());
   return 0;
 }
 

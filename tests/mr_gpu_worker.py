@@ -40,7 +40,9 @@ def main():
     bc = {"nodes": synth.plane_nodes(gn, 2, MARGIN + 1), "dim": 3, "dir": np.ones((3, NSTEPS), dtype=np.int32),
           "value": np.zeros((3, NSTEPS))}
     dt = 0.4 / 100.0
-    stream = torch.cuda.current_stream().cuda_stream
+    work_stream = torch.cuda.Stream()  # as bench.py: library kernels and callback ops share one real stream
+    torch.cuda.set_stream(work_stream)
+    stream = work_stream.cuda_stream
     S = nlps.Solver(3, gn, [0.0] * 3, 1.0, cloud, mats, nsteps=NSTEPS, stream=stream)
     lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[2], reach=3)
     halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi)

@@ -695,6 +695,45 @@ def test_node_window(ndim):
     assert S3.status_flags() & 16
 
 
+def test_caller_provided_nonblocking_stream():
+    """The handle may run on a stream the caller owns.  torch streams are NON-BLOCKING: nothing orders them with
+    the default stream, so an upload that went through the default stream must be complete (and not be wiped by a
+    late allocation memset) before the first kernel runs.  Same steps on such a stream and on the library's own
+    stream, with a shuffled upload, two materials, uploaded I0/lambda and re-sorts: identical state."""
+    import torch
+    n = nlps()
+    case = small_case(3, velocity=[1.0, 0.5, -10.0])
+    rng = np.random.default_rng(4)
+    npart = case["cloud"]["x"].shape[0]
+    perm = rng.permutation(npart)
+    for k, v in list(case["cloud"].items()):
+        if isinstance(v, np.ndarray) and v.shape[:1] == (npart,):
+            case["cloud"][k] = np.ascontiguousarray(v[perm])
+    case["materials"] = [NH, HENCKY]
+    case["cloud"]["matidx"] = (np.arange(npart) % 2).astype(np.int32)
+    nsteps = 6
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, nsteps)])
+    out = {}
+    prev = torch.cuda.current_stream()
+    for kind in ("own", "caller"):
+        ts = torch.cuda.Stream()
+        if kind == "caller":
+            torch.cuda.set_stream(ts)
+        S = gpu_setup(case, nsteps=nsteps, stream=ts.cuda_stream if kind == "caller" else None)
+        S.set_resort_interval(2)
+        for t in range(nsteps):
+            S.explicit_step(gb, t, 2e-3)
+        out[kind] = (S.download_state(), S.download_lists())
+        assert S.status_flags() == 0
+        S.close()
+    torch.cuda.set_stream(prev)
+    (a, (na, la)), (b, (nb, lb)) = out["own"], out["caller"]
+    assert np.array_equal(a["I0"], b["I0"]) and np.array_equal(na, nb) and lists_equal(na, la, lb)
+    for k in ("x", "vel", "Stress", "F_n", "lambda"):
+        assert_close(b[k], a[k], 1e-12, f"{k}: caller's stream vs own stream")
+    assert np.abs(a["Stress"]).max() > 1.0
+
+
 @pytest.mark.parametrize("ndim", [2, 3])
 def test_shuffled_upload_and_periodic_resort(ndim):
     """Caller's particle order is arbitrary (shuffled here); the device keeps its own tile-major order,
