@@ -108,10 +108,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    # rehearsal knobs (tests only): several ranks on the one GPU of a test box, gloo standing in for RCCL
+    backend = os.environ.get("NLPS_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("NLPS_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     nlps = importlib.import_module("nl-partsol_amd.nlps")
     synth = importlib.import_module("nl-partsol_amd.synth")
 
@@ -168,7 +174,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     flags = S.status_flags()

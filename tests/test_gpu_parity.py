@@ -641,6 +641,28 @@ def test_multirank_on_one_gpu(world, overlap):
     assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py --gpus 2 end to end (slab clouds, shared stream, halo callback with overlap, node window, ghost
+    bands, barrier + max-over-ranks timing, JSON line) with two ranks on the one card of the test box; gloo stands
+    in for RCCL (NLPS_BENCH_BACKEND), the real launch is the driver's on an 8-GPU node."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--cells", "16", "--no-cpu-baseline"]
+    env = dict(os.environ, NLPS_BENCH_BACKEND="gloo", NLPS_BENCH_DEVICE="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["particles_total"] == 2 * 16 ** 3 * 8
+
+
 @pytest.mark.parametrize("ndim", [2, 3])
 def test_node_window(ndim):
     """nlps_gpu_set_node_window limits the per-step nodal work to the layers a rank can touch: the same
