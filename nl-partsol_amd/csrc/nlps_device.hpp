@@ -53,7 +53,7 @@ struct ParamsD {
 #define NLPS_JUNROLL_MOMENTS 5  // rows per iteration of the moments row loop (1 = real loop, 5 = unrolled)
 #endif
 #ifndef NLPS_K2_WAVES
-#define NLPS_K2_WAVES 3  // 168 VGPRs (small spill) beat 235 VGPRs at 2 waves/SIMD: 0.52 -> 0.41 ms with the row unroll
+#define NLPS_K2_WAVES 3  // 168 VGPRs + 132 B of scratch per lane; the spill-free 2-wave build is ~7 % slower
 #endif
 // The reference warm-starts the lambda Newton iteration from the previous step's lambda (LME.c:998) and
 // stops at |r| <= TOL_wrapper_LME = 1e-10, so its lambda carries a solver error of ~1e-10/|J| that
@@ -65,7 +65,7 @@ struct ParamsD {
 #define NLPS_LAMBDA_EXTRAPOLATE 0
 #endif
 #ifndef NLPS_JUNROLL_K3
-#define NLPS_JUNROLL_K3 5
+#define NLPS_JUNROLL_K3 5  // unrolled gather rows: the LDS reads of the next rows overlap this row's arithmetic (-3 %)
 #endif
 #ifndef NLPS_JUNROLL_K5
 #define NLPS_JUNROLL_K5 5
@@ -74,10 +74,10 @@ struct ParamsD {
 #define NLPS_JUNROLL_SCATTER 5
 #endif
 #ifndef NLPS_JUNROLL_MASK
-#define NLPS_JUNROLL_MASK 1
+#define NLPS_JUNROLL_MASK 1  // neighbourhood-mask rows: unrolling only costs registers (measured)
 #endif
 #ifndef NLPS_K3_WAVES
-#define NLPS_K3_WAVES 2
+#define NLPS_K3_WAVES 2  // Hencky / Drucker-Prager need > 256 VGPRs otherwise (1 wave/SIMD: 0.54 -> 0.37 ms at 2)
 #endif
 
 __device__ __forceinline__ double dsqr(double a) { return a == 0.0 ? 0.0 : a * a; }  // Macros.h:49-50

@@ -2,14 +2,17 @@
 // stress-update hot path.  See include/nlps_gpu.h for the boundary and DESIGN.md for the layout.
 //
 // Layout in HBM
-//   particles : SoA, one contiguous run of `npad` doubles per scalar component (83 components),
-//               sorted by background-grid cell at upload; lane p of a wave reads consecutive
-//               doubles of every component => fully coalesced 512-B wave loads.
+//   particles : SoA, one contiguous run of `npad` doubles per scalar component (enum below), physically
+//               sorted (tile of the closest node I0, corner type, I0) at upload and by the periodic device
+//               re-sort; lane p of a wave reads consecutive doubles of every component => coalesced
+//               512-B wave loads.
 //   nodes     : AoS per node in GRID numbering (x fastest, slab axis slowest): nm[node][1+d] =
 //               {mass, momentum}, dU[node][d], force[node][d], accel[node][d]; a slab halo is one
-//               contiguous byte range.  active[node], fixed[node][d] are bytes.
+//               contiguous byte range.  active[node], seed[node], fixed[node][d] are bytes.
 // One lane = one particle.  All LME quantities (15 separable exp factors, Z, r, J, J^-1, DF, tau)
-// live in that lane's registers; no MFMA (<=3x3 contractions), no LDS in the gather kernels.
+// live in that lane's registers; no MFMA (<=3x3 contractions).  The particle<->grid kernels work per tile of
+// closest nodes with the tile's node window in LDS (nlps_tile_kernels.hpp); this file holds the search, the
+// nodal kernels, the per-particle level-B kernels and the C-ABI host code.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
