@@ -237,6 +237,25 @@ int nlps_gpu_set_ghost_bands(nlps_gpu *h, int band_lo, int band_hi, int overlap)
 /* Range of node layers along the slab axis this rank's particles may touch (5^d stencil reach). */
 int nlps_gpu_touched_layers(nlps_gpu *h, int *lo, int *hi);
 
+/* ---- particle migration between slab ranks.  Ownership follows the closest node: a particle whose
+ * I0 lies below node layer keep_lo moves to the rank below, above keep_hi to the rank above.  The caller moves the
+ * packed rows between ranks (RCCL send/recv, see nl-partsol_amd/halo.py::SlabHalo.migrate) between the two calls.
+ * Call it every few steps, before a particle can leave the node window (status flag 16). */
+/* step 1: select and pack.  n_down / n_up rows of row_words 8-byte words each wait in two device buffers owned by
+ * the handle (valid until the next select). */
+int nlps_gpu_migration_select(nlps_gpu *h, int keep_lo, int keep_hi, int *n_down, int *n_up, int *row_words,
+                              void **down_rows, void **up_rows);
+/* step 2: the selected particles leave, n_a + n_b immigrants (packed rows received from the two neighbours, host
+ * or device pointers, may be NULL/0) join; the arrays are re-sorted.  Capacity is fixed at create:
+ * np + max(np/4, 1024) particles. */
+int nlps_gpu_migration_commit(nlps_gpu *h, const void *rows_a, int n_a, const void *rows_b, int n_b);
+/* current number of particles of this handle */
+int nlps_gpu_num_particles(nlps_gpu *h, int *np);
+/* global particle ids (default: the index in the arrays given to nlps_gpu_create).  After the first migration
+ * nlps_gpu_download_state / _lists / _ids return their rows in ascending id (arrays of nlps_gpu_num_particles rows). */
+int nlps_gpu_set_particle_ids(nlps_gpu *h, const int *ids);
+int nlps_gpu_download_ids(nlps_gpu *h, int *ids);
+
 /* ------------------------------------------------------------------ host-only helpers (no GPU needed) */
 
 /* Stencil-order tables the library derives for the canonical grid numbering (see csrc/nlps_tables.hpp):

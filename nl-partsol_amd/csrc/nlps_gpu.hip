@@ -29,6 +29,12 @@
 #include "nlps_device.hpp"
 #include "nlps_tables.hpp"
 
+#define LAUNCH_ND(kern2, kern3, grid, ...)                                                     \
+  do {                                                                                         \
+    if (h->nd == 2) hipLaunchKernelGGL(kern2, dim3(grid), dim3(BLK), 0, h->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern3, dim3(grid), dim3(BLK), 0, h->stream, __VA_ARGS__);          \
+  } while (0)
+
 using namespace nlps;
 
 // ------------------------------------------------------------------------------------------------
@@ -634,9 +640,15 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 // (tile of I0, corner type, I0 in tile) memory order that makes waves hit distinct window slots
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+__global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __restrict__ keys, int* __restrict__ vals,
+                            const unsigned char* __restrict__ leaving) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.np) return;
+  if (leaving && leaving[p]) {  // migration: the emigrants sort behind everything that stays
+    keys[p] = ~0ull;
+    vals[p] = p;
+    return;
+  }
   constexpr int TB = TileCfg<ND>::TB;
   const int I0 = P.I0[p];
   int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
@@ -656,6 +668,64 @@ __global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __
   keys[p] = (kt * mc + kc) * mn + kn;
   vals[p] = p;
 }
+// ---- particle migration between slab ranks: packed rows of MIG_WORDS 8-byte words:
+// the NFD fields in canonical order (F_n / b_e,n in their n slots whatever the current renaming), then
+// I0, material, NumberNodes, status, caller index, global id (as integers in words), then the two mask words.
+static constexpr int MIG_WORDS = NFD + 8;
+__device__ __forceinline__ int mig_field(const PView& P, int f) {  // canonical field -> current physical field
+  if (!P.flip) return f;
+  if (f >= F_FN && f < F_FN + 9) return f + (F_FN1 - F_FN);
+  if (f >= F_FN1 && f < F_FN1 + 9) return f - (F_FN1 - F_FN);
+  if (f >= F_BEN && f < F_BEN + 9) return f + (F_BEN1 - F_BEN);
+  if (f >= F_BEN1 && f < F_BEN1 + 9) return f - (F_BEN1 - F_BEN);
+  return f;
+}
+template <int ND>
+__global__ void k_mig_flag(PView P, GridD g, int keep_lo, int keep_hi, unsigned char* __restrict__ leaving,
+                           int* __restrict__ slot, int* __restrict__ counts) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.np) return;
+  const int layer = P.I0[p] / (g.nnodes / g.n[ND - 1]);
+  const int dir = layer < keep_lo ? 1 : (layer > keep_hi ? 2 : 0);
+  leaving[p] = (unsigned char)dir;
+  if (dir) slot[p] = atomicAdd(&counts[dir - 1], 1);
+}
+__global__ void k_mig_pack(PView P, const unsigned char* __restrict__ leaving, const int* __restrict__ slot,
+                           const int* __restrict__ perm, const int* __restrict__ gid, double* __restrict__ down,
+                           double* __restrict__ up) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.np || !leaving[p]) return;
+  double* row = (leaving[p] == 1 ? down : up) + (size_t)slot[p] * MIG_WORDS;
+  for (int f = 0; f < NFD; f++) row[f] = PF(P, mig_field(P, f), p);
+  long long* w = reinterpret_cast<long long*>(row + NFD);
+  w[0] = P.I0[p];
+  w[1] = P.mat[p];
+  w[2] = P.nn[p];
+  w[3] = P.status[p];
+  w[4] = perm[p];
+  w[5] = gid[p];
+  w[6] = (long long)P.mlo[p];
+  w[7] = (long long)P.mhi[p];
+}
+__global__ void k_mig_unpack(PView P, int first, int n, const double* __restrict__ rows, int* __restrict__ perm,
+                             int* __restrict__ gid, unsigned char* __restrict__ leaving) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int p = first + j;
+  const double* row = rows + (size_t)j * MIG_WORDS;
+  for (int f = 0; f < NFD; f++) PF(P, mig_field(P, f), p) = row[f];
+  const long long* w = reinterpret_cast<const long long*>(row + NFD);
+  P.I0[p] = (int)w[0];
+  P.mat[p] = (int)w[1];
+  P.nn[p] = (int)w[2];
+  P.status[p] = (int)w[3];
+  perm[p] = (int)w[4];
+  gid[p] = (int)w[5];
+  P.mlo[p] = (u64)w[6];
+  P.mhi[p] = (u64)w[7];
+  leaving[p] = 0;
+}
+
 template <class T>
 __global__ void k_copy(T* __restrict__ out, const T* __restrict__ in, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,6 +777,15 @@ struct nlps_gpu {
   int nactive, nfree;
   bool masks_valid;
   bool binned;  // order[] / tile tables describe the current I0s
+  // migration
+  int* gid_d = nullptr;               // global particle id (default: the caller's index)
+  unsigned char* leaving_d = nullptr;  // 0 stay, 1 leaves downwards, 2 upwards (between select and commit)
+  int* mig_slot_d = nullptr;
+  int* mig_cnt_d = nullptr;
+  double *mig_down_d = nullptr, *mig_up_d = nullptr;
+  int mig_n[2] = {0, 0};
+  bool mig_selected = false;
+  bool migrated = false;             // downloads are ordered by ascending global id from now on
   bool rolled = false;  // explicit steps renamed the n/n+1 tensor slots since the last materialise_roll()
   bool level_b_fields = false;  // C_ep / rate tensors hold data (a level-B constitutive or rate call was made)
 
@@ -1095,8 +1174,8 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   // particles: sort by background-grid cell
   int np = host->np;
   h->P.np = np;
-  h->P.npad = ((size_t)np + 255) / 256 * 256;
-  if (h->P.npad == 0) h->P.npad = 256;
+  // capacity: room for immigrants (nlps_gpu_migration_commit), fixed at create
+  h->P.npad = ((size_t)np + std::max<size_t>((size_t)np / 4, 1024) + 255) / 256 * 256;
   h->perm.resize(np);
   std::iota(h->perm.begin(), h->perm.end(), 0);
   {
@@ -1199,13 +1278,18 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   // re-sort buffers
   if (dev_alloc(h, &h->perm_d, h->P.npad)) return 1;
   HIPCHK(hipMemcpy(h->perm_d, h->perm.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice));
+  if (dev_alloc(h, &h->gid_d, h->P.npad)) return 1;
+  HIPCHK(hipMemcpy(h->gid_d, h->perm.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice));
+  if (dev_alloc(h, &h->leaving_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->mig_slot_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->mig_cnt_d, 2)) return 1;
   if (dev_alloc(h, &h->skey_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->skey2_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->sval_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->sval2_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->gather_tmp, h->P.npad)) return 1;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, h->cub_tmp_bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np,
-                                            0, 64, h->stream));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, h->cub_tmp_bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                                            (int)h->P.npad, 0, 64, h->stream));
   HIPCHK(hipMalloc(&h->cub_tmp, h->cub_tmp_bytes + 16));
   HIPCHK(hipStreamSynchronize(h->stream));
   // the uploads above are ordered on the default stream only: a caller-provided non-blocking stream (torch
@@ -1215,14 +1299,14 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
 }
 
 // Physical re-sort of every particle array by (tile of I0, corner type, I0 in tile).
-static int resort(nlps_gpu* h) {
+static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr) {
   const int np = h->P.np;
   if (np == 0) return 0;
   TileCnt tc;
   for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
   tc.count = nullptr;
-  if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d);
-  else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d);
+  if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving);
+  else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving);
   HIPCHK(hipGetLastError());
   size_t bytes = h->cub_tmp_bytes;
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
@@ -1235,7 +1319,7 @@ static int resort(nlps_gpu* h) {
     hipLaunchKernelGGL(k_gather<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->gather_tmp, fld, idx, np);
     hipLaunchKernelGGL(k_copy<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, fld, (const double*)h->gather_tmp, np);
   }
-  int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d};
+  int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
   for (int* a : iarr) {
     hipLaunchKernelGGL(k_gather<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (int*)h->gather_tmp, a, idx, np);
     hipLaunchKernelGGL(k_copy<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, a, (const int*)h->gather_tmp, np);
@@ -1255,8 +1339,115 @@ static int resort(nlps_gpu* h) {
 static int refresh_perm(nlps_gpu* h) {
   if (!h->perm_dirty) return 0;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(h->perm.data(), h->perm_d, (size_t)h->P.np * sizeof(int), hipMemcpyDeviceToHost));
+  const int np = h->P.np;
+  h->perm.resize(np);
+  if (!h->migrated) {
+    HIPCHK(hipMemcpy(h->perm.data(), h->perm_d, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+  } else if (np > 0) {
+    // after a migration the caller's original order is gone: rows come back in ascending global id
+    std::vector<int> gid(np), idx(np);
+    HIPCHK(hipMemcpy(gid.data(), h->gid_d, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return gid[a] < gid[b]; });
+    for (int r = 0; r < np; r++) h->perm[idx[r]] = r;
+  }
   h->perm_dirty = false;
+  return 0;
+}
+
+extern "C" int nlps_gpu_num_particles(nlps_gpu* h, int* np) {
+  *np = h->P.np;
+  return 0;
+}
+
+extern "C" int nlps_gpu_set_particle_ids(nlps_gpu* h, const int* ids) {
+  if (refresh_perm(h)) return 1;
+  const int np = h->P.np;
+  std::vector<int> g(np);
+  for (int s = 0; s < np; s++) g[s] = ids[h->perm[s]];
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->gid_d, g.data(), (size_t)np * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
+extern "C" int nlps_gpu_download_ids(nlps_gpu* h, int* ids) {
+  if (refresh_perm(h)) return 1;
+  const int np = h->P.np;
+  std::vector<int> g(np);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (np) HIPCHK(hipMemcpy(g.data(), h->gid_d, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+  for (int s = 0; s < np; s++) ids[h->perm[s]] = g[s];
+  return 0;
+}
+
+// Migration, step 1: particles whose closest node lies below layer keep_lo leave "down", above keep_hi "up";
+// their packed rows are written to two device buffers owned by the handle.
+extern "C" int nlps_gpu_migration_select(nlps_gpu* h, int keep_lo, int keep_hi, int* n_down, int* n_up, int* row_words,
+                                         void** down_rows, void** up_rows) {
+  const int np = h->P.np;
+  HIPCHK(hipMemsetAsync(h->mig_cnt_d, 0, 2 * sizeof(int), h->stream));
+  HIPCHK(hipMemsetAsync(h->leaving_d, 0, h->P.npad, h->stream));
+  if (np > 0) LAUNCH_ND((k_mig_flag<2>), (k_mig_flag<3>), nblk(np), h->P, h->g, keep_lo, keep_hi, h->leaving_d, h->mig_slot_d, h->mig_cnt_d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->mig_n, h->mig_cnt_d, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->mig_down_d) (void)hipFree(h->mig_down_d);
+  if (h->mig_up_d) (void)hipFree(h->mig_up_d);
+  h->mig_down_d = h->mig_up_d = nullptr;
+  HIPCHK(hipMalloc((void**)&h->mig_down_d, ((size_t)h->mig_n[0] + 1) * MIG_WORDS * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&h->mig_up_d, ((size_t)h->mig_n[1] + 1) * MIG_WORDS * sizeof(double)));
+  if (h->mig_n[0] + h->mig_n[1] > 0) {
+    hipLaunchKernelGGL(k_mig_pack, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->leaving_d, h->mig_slot_d, h->perm_d,
+                       h->gid_d, h->mig_down_d, h->mig_up_d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  *n_down = h->mig_n[0];
+  *n_up = h->mig_n[1];
+  *row_words = MIG_WORDS;
+  if (down_rows) *down_rows = h->mig_down_d;
+  if (up_rows) *up_rows = h->mig_up_d;
+  h->mig_selected = true;
+  return 0;
+}
+
+// Migration, step 2: the selected particles leave, the immigrants (packed rows from the neighbours, host or device
+// pointers) join, the arrays are re-sorted and the next search re-bins everything.
+extern "C" int nlps_gpu_migration_commit(nlps_gpu* h, const void* rows_a, int n_a, const void* rows_b, int n_b) {
+  if (!h->mig_selected) {
+    h->err = "nlps_gpu_migration_commit: call nlps_gpu_migration_select() first";
+    return 1;
+  }
+  const int np = h->P.np, n_in = n_a + n_b, n_out = h->mig_n[0] + h->mig_n[1];
+  if ((size_t)np + n_in > h->P.npad) {
+    h->err = "nlps_gpu_migration_commit: more immigrants than the capacity reserved at create (np + max(np/4, 1024))";
+    return 1;
+  }
+  h->mig_selected = false;
+  if (n_in == 0 && n_out == 0) return 0;
+  const void* src[2] = {rows_a, rows_b};
+  const int cnt[2] = {n_a, n_b};
+  int first = np;
+  for (int k = 0; k < 2; k++) {
+    if (cnt[k] <= 0) continue;
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)cnt[k] * MIG_WORDS * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(tmp, src[k], (size_t)cnt[k] * MIG_WORDS * sizeof(double), hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(k_mig_unpack, dim3(nblk(cnt[k])), dim3(BLK), 0, h->stream, h->P, first, cnt[k], tmp, h->perm_d,
+                       h->gid_d, h->leaving_d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+    first += cnt[k];
+  }
+  h->P.np = np + n_in;
+  if (resort(h, h->leaving_d)) return 1;  // emigrants sort to the end ...
+  h->P.np = np + n_in - n_out;           // ... and fall off
+  h->migrated = true;
+  h->perm_dirty = true;
+  h->masks_valid = false;
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -1273,7 +1464,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -1393,11 +1584,7 @@ static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int pha
   return 0;
 }
 
-#define LAUNCH_ND(kern2, kern3, grid, ...)                                                     \
-  do {                                                                                         \
-    if (h->nd == 2) hipLaunchKernelGGL(kern2, dim3(grid), dim3(BLK), 0, h->stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kern3, dim3(grid), dim3(BLK), 0, h->stream, __VA_ARGS__);          \
-  } while (0)
+
 
 static int compute_node_mask(nlps_gpu* h) {
   int nn = h->g.nnodes, nb = (nn + 1023) / 1024;

@@ -97,6 +97,48 @@ class SlabHalo:
                 torch.maximum(sl, r, out=sl)
         return 0
 
+    def migrate(self, S, keep_lo, keep_hi):
+        """Moves the particles whose closest node left [keep_lo, keep_hi] (node layers) to the neighbouring rank:
+        select + pack on the device, counts and rows exchanged with the two neighbours, commit.  Returns
+        (sent_down, sent_up, received)."""
+        torch, dist = self.torch, self.dist
+        n_down, n_up, rw, dptr_down, dptr_up = S.migration_select(keep_lo, keep_hi)
+        if self.world == 1:
+            S.migration_commit(0, 0, 0, 0)
+            return n_down, n_up, 0
+        nbrs = [(self.rank - 1, n_down, dptr_down), (self.rank + 1, n_up, dptr_up)]
+        nbrs = [(r, n, p) for r, n, p in nbrs if 0 <= r < self.world]
+        staged = dist.get_backend() == "gloo"
+        dev = "cpu" if staged else "cuda"
+        # 1. how many rows come from each neighbour
+        send_n = {r: torch.tensor([n], dtype=torch.int64, device=dev) for r, n, _ in nbrs}
+        recv_n = {r: torch.zeros(1, dtype=torch.int64, device=dev) for r, _, _ in nbrs}
+        ops = []
+        for r, _, _ in nbrs:
+            ops += [dist.P2POp(dist.isend, send_n[r], r), dist.P2POp(dist.irecv, recv_n[r], r)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        # 2. the rows
+        ops, keep, recv = [], [], {}
+        for r, n, p in nbrs:
+            if n > 0:
+                t = device_tensor(torch, p, n * rw, 8)
+                t = t.cpu() if staged else t
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, r))
+            m = int(recv_n[r].item())
+            if m > 0:
+                recv[r] = torch.empty(m * rw, dtype=torch.float64, device=dev)
+                ops.append(dist.P2POp(dist.irecv, recv[r], r))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if not staged:
+            torch.cuda.current_stream().synchronize()
+        got = [(recv[r].data_ptr(), recv[r].numel() // rw) for r in sorted(recv)] + [(0, 0), (0, 0)]
+        S.migration_commit(got[0][0], got[0][1], got[1][0], got[1][1])
+        return n_down, n_up, got[0][1] + got[1][1]
+
     def ghost_bands(self, rank):
         """(band_lo, band_hi): node layers <= band_lo are shared with rank-1, layers >= band_hi with rank+1."""
         lo_ov = self.overlap(rank, rank - 1) if rank > 0 else None

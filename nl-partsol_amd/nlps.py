@@ -66,6 +66,8 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
            "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_coo", "nlps_gpu_sparsity_pattern",
+           "nlps_gpu_migration_select", "nlps_gpu_migration_commit", "nlps_gpu_num_particles",
+           "nlps_gpu_set_particle_ids", "nlps_gpu_download_ids",
            "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
 
 
@@ -94,6 +96,12 @@ def lib():
         L.nlps_gpu_tangent_assemble.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.nlps_gpu_tangent_coo.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, _ip, _ip, _dp]
         L.nlps_gpu_sparsity_pattern.argtypes = [C.c_void_p, _ip]
+        L.nlps_gpu_migration_select.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _ip, C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_void_p)]
+        L.nlps_gpu_migration_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.nlps_gpu_num_particles.argtypes = [C.c_void_p, _ip]
+        L.nlps_gpu_set_particle_ids.argtypes = [C.c_void_p, _ip]
+        L.nlps_gpu_download_ids.argtypes = [C.c_void_p, _ip]
         for name in ["nlps_gpu_destroy", "nlps_gpu_synchronize", "nlps_gpu_initialize_lme", "nlps_gpu_resort",
                      "nlps_gpu_local_search", "nlps_gpu_constitutive", "nlps_gpu_roll_state"]:
             getattr(L, name).argtypes = [C.c_void_p]
@@ -395,6 +403,36 @@ class Solver:
         pat = np.zeros(self.nactive * self.ndim, dtype=np.int32)
         self._chk(self.L.nlps_gpu_sparsity_pattern(self.h, _i(pat)))
         return pat
+
+    # ------------------------------------------------------------------ migration
+    def num_particles(self):
+        n = C.c_int(0)
+        self._chk(self.L.nlps_gpu_num_particles(self.h, C.byref(n)))
+        self.np = n.value
+        return n.value
+
+    def set_particle_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self._chk(self.L.nlps_gpu_set_particle_ids(self.h, _i(ids)))
+
+    def download_ids(self):
+        ids = np.zeros(self.num_particles(), dtype=np.int32)
+        self._chk(self.L.nlps_gpu_download_ids(self.h, _i(ids)))
+        return ids
+
+    def migration_select(self, keep_lo, keep_hi):
+        """-> (n_down, n_up, row_words, down_dptr, up_dptr): packed rows of the particles that leave"""
+        nd, nu, rw = C.c_int(0), C.c_int(0), C.c_int(0)
+        dp, up = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.nlps_gpu_migration_select(self.h, int(keep_lo), int(keep_hi), C.byref(nd), C.byref(nu),
+                                                   C.byref(rw), C.byref(dp), C.byref(up)))
+        return nd.value, nu.value, rw.value, dp.value, up.value
+
+    def migration_commit(self, rows_a, n_a, rows_b, n_b):
+        """rows_*: raw pointers (int) of packed rows, host or device"""
+        self._chk(self.L.nlps_gpu_migration_commit(self.h, C.c_void_p(rows_a) if rows_a else None, int(n_a),
+                                                   C.c_void_p(rows_b) if rows_b else None, int(n_b)))
+        self.num_particles()
 
     def set_ghost_bands(self, band_lo, band_hi, overlap=True):
         self._chk(self.L.nlps_gpu_set_ghost_bands(self.h, int(band_lo), int(band_hi), 1 if overlap else 0))

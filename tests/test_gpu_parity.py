@@ -641,6 +641,68 @@ def test_multirank_on_one_gpu(world, overlap):
     assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_migration_select_commit_round_trip():
+    """One rank: the particles above a layer are selected and packed, then handed straight back as immigrants.
+    Nothing may change (matched by global id), capacity is respected, and stepping on is identical to a solver
+    that never migrated."""
+    n = nlps()
+    case = small_case(3, velocity=[1.0, 0.5, -10.0], material=DP)
+    nsteps = 6
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, nsteps)])
+    A, B = gpu_setup(case, nsteps=nsteps), gpu_setup(case, nsteps=nsteps)
+    npart = case["cloud"]["x"].shape[0]
+    ids = (np.arange(npart) * 7 + 3).astype(np.int32)  # arbitrary distinct global ids
+    A.set_particle_ids(ids)
+    B.set_particle_ids(ids)
+    for t in range(3):
+        A.explicit_step(gb, t, 2e-3)
+        B.explicit_step(gb, t, 2e-3)
+    cut = int(np.median(case["cloud"]["x"][:, 2]))
+    n_down, n_up, rw, dptr_down, dptr_up = A.migration_select(0, cut)
+    assert n_down == 0 and 0 < n_up < npart and rw > 100
+    A.migration_commit(dptr_up, n_up, 0, 0)       # they come straight back
+    assert A.num_particles() == npart
+    for t in range(3, nsteps):
+        A.explicit_step(gb, t, 2e-3)
+        B.explicit_step(gb, t, 2e-3)
+    a, b = A.download_state(), B.download_state()
+    ia, ib = A.download_ids(), B.download_ids()
+    assert np.array_equal(ia, np.sort(ids)) and np.array_equal(np.sort(ib), np.sort(ids))
+    order_b = np.argsort(ib)
+    na, _ = A.download_lists()
+    nb, _ = B.download_lists()
+    assert np.array_equal(a["I0"], b["I0"][order_b]) and np.array_equal(na, nb[order_b])
+    for k in ("x", "vel", "Stress", "F_n", "b_e_n", "Kappa_n", "lambda", "rho"):
+        assert_close(a[k], b[k][order_b], 1e-12, f"{k} after select/commit round trip")
+    # a real removal: they leave and nobody comes
+    n_down, n_up, rw, _, _ = A.migration_select(0, cut)
+    A.migration_commit(0, 0, 0, 0)
+    assert A.num_particles() == npart - n_up and A.download_ids().size == npart - n_up
+    A.explicit_step(gb, nsteps - 1, 2e-3)
+    assert A.status_flags() == 0
+    # capacity: more immigrants than reserved at create is an error, not a crash
+    big = np.zeros(5000 * rw)
+    A.migration_select(0, 10 ** 6)
+    with pytest.raises(n.NlpsError):
+        A.migration_commit(big.ctypes.data, 5000, 0, 0)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_migration_between_ranks_on_one_gpu(world):
+    """a block flying along the slab axis changes owner; halo exchange + migration every 4 steps against
+    one solver holding everything (tests/mr_gpu_migrate_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (os.getpid() + world) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "mr_gpu_migrate_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "MIGRATION_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_bench_multi_rank_path_rehearsal():
     """bench.py --gpus 2 end to end (slab clouds, shared stream, halo callback with overlap, node window, ghost
     bands, barrier + max-over-ranks timing, JSON line) with two ranks on the one card of the test box; gloo stands
