@@ -622,12 +622,18 @@ __device__ __forceinline__ double masked_weight(double e, unsigned bits, int i) 
   return __hiloint2double(__double2hiint(e) & m, __double2loint(e));
 }
 
-// Z^-1, r = sum p l, J = sum p l(x)l - r(x)r  (LME.c:766-832) by rows and planes
+// Z^-1, r = sum p l, J = sum p l(x)l - r(x)r  (LME.c:766-832) by rows and planes.
+// The moments are accumulated in INDEX space: with l_x(i) = a_x - u h, u = i - 2 in {-2..2} (a = l of the
+// centre node) the weights of a row are the small integers u and u^2, so a row costs 8 additions / FMAs on its 5
+// masked factors instead of 4 per member; the conversion to moments of l is a handful of operations at the end:
+//   sum e l_x = a_x M0 - h M1x ,  sum e l_x l_y = a_x a_y M0 - h (a_x M1y + a_y M1x) + h^2 M2xy .
 template <int ND>
 __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
   NLPS_YZ_LOCALS(c);
-  double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
-  // real (not unrolled) plane and row loops: compact code, short live ranges
+  (void)ly5;
+  (void)lz5;
+  double M0 = 0.0, M1x = 0.0, M1y = 0.0, M1z = 0.0, M2xx = 0.0, M2xy = 0.0, M2xz = 0.0, M2yy = 0.0, M2yz = 0.0, M2zz = 0.0;
+  // real (not unrolled) plane loop, unrolled rows: compact code, short live ranges
 #pragma unroll 1
   for (int k = 0; k < Lme<ND>::KN; k++) {
     const unsigned pb = plane_bits<ND>(c, k);
@@ -635,16 +641,15 @@ __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, do
 #pragma unroll NLPS_JUNROLL_MOMENTS
     for (int j = 0; j < 5; j++) {
       const unsigned bits = (pb >> (5 * j)) & 31u;
-      // branch-free: non-members enter with weight 0 (straight-line code, 2 v_cndmask per value)
-      double A0 = 0.0, A1 = 0.0, A2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        const double m0 = masked_weight(c.ex[i], bits, i), m1 = m0 * c.lx[i];
-        A0 += m0;
-        A1 += m1;
-        A2 = fma(m1, c.lx[i], A2);
-      }
-      const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
+      const double m0 = masked_weight(c.ex[0], bits, 0), m1 = masked_weight(c.ex[1], bits, 1),
+                   m2 = masked_weight(c.ex[2], bits, 2), m3 = masked_weight(c.ex[3], bits, 3),
+                   m4 = masked_weight(c.ex[4], bits, 4);
+      const double s13 = m1 + m3, s04 = m0 + m4;
+      const double A0 = m2 + s13 + s04;                  // sum e
+      const double A1 = fma(2.0, m4 - m0, m3 - m1);      // sum e u
+      const double A2 = fma(4.0, s04, s13);              // sum e u^2
+      const double cj = (double)(j - 2);
+      const double y0 = ey5[j], y1 = y0 * cj, y2 = y1 * cj;
       P00 = fma(y0, A0, P00);
       P10 = fma(y0, A1, P10);
       P20 = fma(y0, A2, P20);
@@ -653,44 +658,51 @@ __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, do
       P02 = fma(y2, A0, P02);
     }
     if (ND == 3) {
-      const double z0 = ez5[k], lzk = lz5[k], z1 = z0 * lzk, z2 = z1 * lzk;
-      Z = fma(z0, P00, Z);
-      rx = fma(z0, P10, rx);
-      ry = fma(z0, P01, ry);
-      rz = fma(z1, P00, rz);
-      Jxx = fma(z0, P20, Jxx);
-      Jxy = fma(z0, P11, Jxy);
-      Jxz = fma(z1, P10, Jxz);
-      Jyy = fma(z0, P02, Jyy);
-      Jyz = fma(z1, P01, Jyz);
-      Jzz = fma(z2, P00, Jzz);
+      const double ck = (double)(k - 2);
+      const double z0 = ez5[k], z1 = z0 * ck, z2 = z1 * ck;
+      M0 = fma(z0, P00, M0);
+      M1x = fma(z0, P10, M1x);
+      M1y = fma(z0, P01, M1y);
+      M1z = fma(z1, P00, M1z);
+      M2xx = fma(z0, P20, M2xx);
+      M2xy = fma(z0, P11, M2xy);
+      M2xz = fma(z1, P10, M2xz);
+      M2yy = fma(z0, P02, M2yy);
+      M2yz = fma(z1, P01, M2yz);
+      M2zz = fma(z2, P00, M2zz);
     } else {
-      Z = P00;
-      rx = P10;
-      ry = P01;
-      Jxx = P20;
-      Jxy = P11;
-      Jyy = P02;
+      M0 = P00;
+      M1x = P10;
+      M1y = P01;
+      M2xx = P20;
+      M2xy = P11;
+      M2yy = P02;
     }
   }
-  Zinv = 1.0 / Z;
-  rx *= Zinv;
-  ry *= Zinv;
-  rz *= Zinv;
+  Zinv = 1.0 / M0;
+  // l = a - u h per axis (Lme::geom: lx[i] = x - (o + h (I0 + i - 2)), so a = lx[2] and h = lx[2] - lx[3])
+  const double hx = c.lx[2] - c.lx[3];
+  const double ax = c.lx[2], ay = c.ly[2], az = (ND == 3) ? c.lz[2 % Lme<ND>::KN] : 0.0;
+  const double e1x = M1x * Zinv, e1y = M1y * Zinv, e1z = M1z * Zinv;  // <u>
+  const double rx = ax - hx * e1x, ry = ay - hx * e1y, rz = az - hx * e1z;
   r[0] = rx;
   r[1] = ry;
   if (ND == 3) r[ND - 1] = rz;
+  // J = <l l> - r r = h^2 (<u u> - <u><u>)   (the a-terms cancel identically)
+  const double h2 = hx * hx;
+  const double cxx = M2xx * Zinv - e1x * e1x, cxy = M2xy * Zinv - e1x * e1y, cyy = M2yy * Zinv - e1y * e1y;
   if (ND == 2) {
-    Jm[0] = Jxx * Zinv - rx * rx;
-    Jm[1] = Jm[2] = Jxy * Zinv - rx * ry;
-    Jm[3] = Jyy * Zinv - ry * ry;
+    Jm[0] = h2 * cxx;
+    Jm[1] = Jm[2] = h2 * cxy;
+    Jm[3] = h2 * cyy;
   } else {
-    Jm[0] = Jxx * Zinv - rx * rx;
-    Jm[1] = Jm[3 % (ND * ND)] = Jxy * Zinv - rx * ry;
-    Jm[2] = Jm[6 % (ND * ND)] = Jxz * Zinv - rx * rz;
-    Jm[4 % (ND * ND)] = Jyy * Zinv - ry * ry;
-    Jm[5 % (ND * ND)] = Jm[7 % (ND * ND)] = Jyz * Zinv - ry * rz;
-    Jm[8 % (ND * ND)] = Jzz * Zinv - rz * rz;
+    const double cxz = M2xz * Zinv - e1x * e1z, cyz = M2yz * Zinv - e1y * e1z, czz = M2zz * Zinv - e1z * e1z;
+    Jm[0] = h2 * cxx;
+    Jm[1] = Jm[3 % (ND * ND)] = h2 * cxy;
+    Jm[2] = Jm[6 % (ND * ND)] = h2 * cxz;
+    Jm[4 % (ND * ND)] = h2 * cyy;
+    Jm[5 % (ND * ND)] = Jm[7 % (ND * ND)] = h2 * cyz;
+    Jm[8 % (ND * ND)] = h2 * czz;
   }
 }
 
