@@ -123,19 +123,28 @@ __device__ __forceinline__ int window_base(const int* ijk, const int* w0) {
   return (ijk[0] - w0[0]) + W * (ijk[1] - w0[1]) + (ND == 3 ? PS * (ijk[2] - w0[2]) : 0);
 }
 
-// block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive prefix, *total = sum
+// block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns the exclusive prefix,
+// *total = sum.  Wave-level shuffles + one pass over the 16 wave totals: two barriers instead of twenty.
 __device__ __forceinline__ int block_scan_1024(int v, int* sh, int* total) {
-  __syncthreads();
-  sh[threadIdx.x] = v;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    int t = ((int)threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
-    __syncthreads();
-    sh[threadIdx.x] += t;
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
   }
-  *total = sh[1023];
-  return sh[threadIdx.x] - v;
+  __syncthreads();  // sh[] may still be read from the previous scan
+  if (lane == 63) sh[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const int t = sh[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + incl - v;
 }
 
 // exclusive scan of the per-tile particle counts + the compacted work lists (one 1024-thread block).
