@@ -202,6 +202,9 @@ int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
  * Needs nlps_gpu_active_masks() first.  EXIT_FAILURE if a particle has another law: the spectral tangents of
  * Hencky / Drucker-Prager divide by eigenvalue differences down to 1e-14 and are not reproduced. */
 int nlps_gpu_tangent_assemble(nlps_gpu *h, long long *nnz);
+/* grouped != 0 (default): one workgroup per closest node sums the blocks of the particles sharing it before the
+ * atomics; 0: one wave per particle (kept for comparison, same result up to summation order). */
+int nlps_gpu_tangent_set_grouped(nlps_gpu *h, int grouped);
 /* The assembled matrix as COO triplets (masked dof numbering, every visited pair present even when its value is
  * zero, like MatSetValues ... ADD_VALUES): rows[nnz], cols[nnz], vals[nnz], host or device pointers.
  * lumped_mass (masked [N_A*d], may be NULL): alpha_1 * M is added on the diagonal (:1797-1807).

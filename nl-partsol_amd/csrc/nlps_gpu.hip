@@ -820,9 +820,11 @@ struct nlps_gpu {
   double* kst_d = nullptr;           // [nnodes][S][d*d]
   unsigned char* ktouched_d = nullptr;  // [nnodes][S]
   int *kcnt_d = nullptr, *koffs_d = nullptr;  // visited blocks per row node, exclusive scan
+  int *khead_d = nullptr, *kng_d = nullptr;   // group heads of the I0-sorted particle list, group count
   void* kscan_tmp = nullptr;
   size_t kscan_bytes = 0;
   long long knnz_blocks = -1;
+  bool tangent_grouped = true;  // one workgroup per closest node (false: one wave per particle, kept for comparison)
   int* order_d;
 
   nlps_halo_fn halo;
@@ -1464,7 +1466,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -2099,6 +2101,8 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
     HIPCHK(hipMalloc((void**)&h->ktouched_d, nblk_st));
     HIPCHK(hipMalloc((void**)&h->kcnt_d, (nn + 1) * sizeof(int)));
     HIPCHK(hipMalloc((void**)&h->koffs_d, (nn + 1) * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->khead_d, h->P.npad * sizeof(int)));
+    HIPCHK(hipMalloc((void**)&h->kng_d, sizeof(int)));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, h->kscan_bytes, h->kcnt_d, h->koffs_d, (int)nn + 1, h->stream));
     HIPCHK(hipMalloc(&h->kscan_tmp, h->kscan_bytes + 16));
   }
@@ -2106,7 +2110,22 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
   HIPCHK(hipMemsetAsync(h->ktouched_d, 0, nblk_st, h->stream));
   HIPCHK(hipMemsetAsync(h->kcnt_d, 0, (nn + 1) * sizeof(int), h->stream));
   const int np = h->P.np;
-  if (np > 0) {
+  if (np > 0 && h->tangent_grouped) {
+    // particles grouped by closest node (radix sort of (I0, p) in the re-sort buffers), one workgroup per node
+    hipLaunchKernelGGL(k_tangent_keys, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->skey_d, h->sval_d);
+    size_t bytes = h->cub_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 32,
+                                              h->stream));
+    HIPCHK(hipMemsetAsync(h->kng_d, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_tangent_groups, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->skey2_d, h->khead_d, h->kng_d);
+    const int ngrid = std::min(np, h->g.nnodes);  // upper bound of the number of groups; surplus workgroups exit
+    if (ND == 2)
+      hipLaunchKernelGGL(k_tangent_nh_grouped<2>, dim3(ngrid), dim3(256), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
+                         h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d);
+    else
+      hipLaunchKernelGGL(k_tangent_nh_grouped<3>, dim3(ngrid), dim3(256), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
+                         h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d);
+  } else if (np > 0) {
     if (ND == 2) hipLaunchKernelGGL(k_tangent_nh<2>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
     else hipLaunchKernelGGL(k_tangent_nh<3>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
   }
@@ -2119,6 +2138,11 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
   if (check_status(h, ST_NEWTON | ST_CONSTITUTIVE, "nlps_gpu_tangent_assemble() (Neo-Hookean particles only)")) return 1;
   h->knnz_blocks = total;
   if (nnz) *nnz = (long long)total * ND * ND;
+  return 0;
+}
+
+extern "C" int nlps_gpu_tangent_set_grouped(nlps_gpu* h, int grouped) {
+  h->tangent_grouped = grouped != 0;
   return 0;
 }
 

@@ -127,6 +127,159 @@ __global__ __launch_bounds__(64) void k_tangent_nh(PView P, GridD g, const MatD*
   }
 }
 
+// ---- grouped form: one workgroup per closest node I0.  The particles that share an I0 share their stencil, so
+// the d x d blocks of a node pair are summed over the group in registers and reach memory with one atomic per
+// entry instead of one per particle (the pair space of one particle, 625 / 15 625 blocks, is what made the
+// per-particle form atomic-bound).  The group's member tables live in LDS, indexed by the stencil code
+// s = i + 5 j + 25 k (zeros for non-members); TAN_GROUP particles per pass.
+static constexpr int TAN_GROUP = 8;
+
+// group heads of the I0-sorted particle list: head[g] = first position of group g, ngroups = count
+__global__ void k_tangent_groups(int np, const unsigned long long* __restrict__ keys, int* __restrict__ head,
+                                 int* __restrict__ ngroups) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= np) return;
+  if (s == 0 || keys[s] != keys[s - 1]) head[atomicAdd(ngroups, 1)] = s;
+}
+
+__global__ void k_tangent_keys(PView P, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.np) return;
+  keys[p] = (unsigned long long)P.I0[p];
+  vals[p] = p;
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, const MatD* __restrict__ mats, int np,
+                                                            const unsigned long long* __restrict__ keys,
+                                                            const int* __restrict__ sorted, const int* __restrict__ head,
+                                                            const int* __restrict__ ngroups, double* __restrict__ Kst,
+                                                            unsigned char* __restrict__ touched,
+                                                            int* __restrict__ gstatus) {
+  constexpr int S = TanCfg<ND>::S, MAXM = TanCfg<ND>::MAXM, KN = Lme<ND>::KN;
+  __shared__ double gn[TAN_GROUP][MAXM][ND], g1[TAN_GROUP][MAXM][ND], ub[TAN_GROUP][MAXM][ND];
+  __shared__ double coef[TAN_GROUP][3];  // V0*c0, V0*c1, V0*G of each particle
+  __shared__ u64 mem[TAN_GROUP][2];
+  __shared__ double tab[4][6][5];  // per wave: ex, ey, ez, lx, ly, lz of the particle it is building
+  if ((int)blockIdx.x >= *ngroups) return;
+  const int first = head[blockIdx.x];
+  const unsigned long long key = keys[first];
+  int last = first;
+  while (last + 1 < np && keys[last + 1] == key) last++;  // groups are small (particles per node)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int I0 = (int)key;
+  const int i0 = I0 % g.n[0], j0 = (I0 / g.n[0]) % g.n[1], k0 = I0 / (g.n[0] * g.n[1]);
+  for (int chunk = first; chunk <= last; chunk += TAN_GROUP) {
+    const int nb = min(TAN_GROUP, last + 1 - chunk);
+    __syncthreads();
+    // phase A: wave w builds the tables of particles w, w+4 of the chunk
+    for (int jj = wave; jj < nb; jj += 4) {
+      const int p = sorted[chunk + jj];
+      Lme<ND> c;
+      double lam[ND], beta;
+      const bool ok_lists = load_lme<ND>(P, g, p, c, lam, beta);
+      const MatD m = mats[P.mat[p]];
+      double Zinv = 0.0, r[ND], J[ND * ND], Jm1[ND * ND], DF[ND * ND], DFm1[ND * ND], Fn[ND * ND], bn[ND * ND], zz;
+      bool ok = ok_lists && m.type == NLPS_MAT_NEO_HOOKEAN;
+      if (ok_lists && m.type != NLPS_MAT_NEO_HOOKEAN && lane == 0) {
+        atomicOr(&P.status[p], ST_CONSTITUTIVE);
+        atomicOr(gstatus, ST_CONSTITUTIVE);
+      }
+      if (ok) {
+        lme_moments_h<ND>(c, Zinv, r, J);
+        load_block<ND>(P, F_DF, p, DF, zz);
+        load_block<ND>(P, fFN(P), p, Fn, zz);
+        if (!inverse<ND>(Jm1, J) || !inverse<ND>(DFm1, DF)) {
+          if (lane == 0) {
+            atomicOr(&P.status[p], ST_NEWTON);
+            atomicOr(gstatus, ST_NEWTON);
+          }
+          ok = false;
+        }
+      }
+      if (ok) left_cauchy_green<ND>(bn, Fn);
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+        if (lane == i) {
+          tab[wave][0][i] = c.ex[i];
+          tab[wave][1][i] = c.ey[i];
+          tab[wave][2][i] = (ND == 3) ? c.ez[i % KN] : 1.0;
+          tab[wave][3][i] = c.lx[i];
+          tab[wave][4][i] = c.ly[i];
+          tab[wave][5][i] = (ND == 3) ? c.lz[i % KN] : 0.0;
+        }
+      if (lane == 0) {
+        const double Jp = PF(P, F_JN1, p), sqrJ = Jp * Jp, V0 = ok ? PF(P, F_VOL0, p) : 0.0;
+        coef[jj][0] = V0 * (m.lame * sqrJ);                       // Neo-Hookean.c:107-110
+        coef[jj][1] = V0 * (m.G - 0.5 * m.lame * (sqrJ - 1));
+        coef[jj][2] = V0 * m.G;
+        mem[jj][0] = ok ? c.mlo : 0ull;
+        mem[jj][1] = ok ? c.mhi : 0ull;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      for (int s = lane; s < MAXM; s += 64) {
+        const bool on = ok && c.on(s);
+        const int i = s % 5, j = (s / 5) % 5, k = s / 25;
+        const double l[3] = {tab[wave][3][i], tab[wave][4][j], tab[wave][5][k]};
+        const double pa = on ? tab[wave][0][i] * tab[wave][1][j] * tab[wave][2][k] * Zinv : 0.0;
+        double ga[ND];
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          double v = 0.0;
+#pragma unroll
+          for (int b2 = 0; b2 < ND; b2++) v = fma(on ? Jm1[a * ND + b2] : 0.0, l[b2], v);
+          ga[a] = -pa * v;
+        }
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          double v1 = 0.0, vb = 0.0;
+#pragma unroll
+          for (int b2 = 0; b2 < ND; b2++) {
+            v1 = fma(on ? DFm1[b2 * ND + a] : 0.0, ga[b2], v1);
+            vb = fma(on ? bn[a * ND + b2] : 0.0, ga[b2], vb);
+          }
+          gn[jj][s][a] = on ? ga[a] : 0.0;
+          g1[jj][s][a] = on ? v1 : 0.0;
+          ub[jj][s][a] = on ? vb : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    // phase B: the threads share the (sA, sB) pairs of the stencil; blocks are summed over the chunk
+    for (int q = threadIdx.x; q < MAXM * MAXM; q += 256) {
+      const int sA = q / MAXM, sB = q - sA * MAXM;
+      double acc[ND * ND];
+#pragma unroll
+      for (int e = 0; e < ND * ND; e++) acc[e] = 0.0;
+      bool any = false;
+      for (int jj = 0; jj < nb; jj++) {
+        const bool inA = sA < 64 ? (mem[jj][0] >> sA) & 1ull : (mem[jj][1] >> (sA - 64)) & 1ull;
+        const bool inB = sB < 64 ? (mem[jj][0] >> sB) & 1ull : (mem[jj][1] >> (sB - 64)) & 1ull;
+        if (!(inA && inB)) continue;
+        any = true;
+        double len0 = 0.0;
+#pragma unroll
+        for (int a = 0; a < ND; a++) len0 = fma(gn[jj][sB][a], ub[jj][sA][a], len0);
+        const double k0c = coef[jj][0], k1c = coef[jj][1], kG = coef[jj][2] * len0;
+#pragma unroll
+        for (int i = 0; i < ND; i++)
+#pragma unroll
+          for (int j = 0; j < ND; j++)
+            acc[i * ND + j] += k0c * g1[jj][sA][i] * g1[jj][sB][j] + (i == j ? kG : 0.0) + k1c * g1[jj][sA][j] * g1[jj][sB][i];
+      }
+      if (!any) continue;
+      const int ia = sA % 5, ja = (sA / 5) % 5, ka = sA / 25;
+      const int nodeA = (i0 + ia - 2) + g.n[0] * ((j0 + ja - 2) + (ND == 3 ? g.n[1] * (k0 + ka - 2) : 0));
+      const size_t blk = (size_t)nodeA * S + tangent_offset_index<ND>(sA, sB);
+      double* out = Kst + blk * (ND * ND);
+#pragma unroll
+      for (int e = 0; e < ND * ND; e++) atomic_add_f64(out + e, acc[e]);
+      touched[blk] = 1;
+    }
+  }
+}
+
 // number of structurally visited blocks of every row node (both ends active by construction)
 template <int ND>
 __global__ void k_tangent_count(int nnodes, const unsigned char* __restrict__ touched, int* __restrict__ cnt) {

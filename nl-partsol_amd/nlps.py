@@ -65,7 +65,8 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
            "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
-           "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_coo", "nlps_gpu_sparsity_pattern",
+           "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_set_grouped", "nlps_gpu_tangent_coo",
+           "nlps_gpu_sparsity_pattern",
            "nlps_gpu_migration_select", "nlps_gpu_migration_commit", "nlps_gpu_num_particles",
            "nlps_gpu_set_particle_ids", "nlps_gpu_download_ids",
            "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables"]
@@ -94,6 +95,7 @@ def lib():
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.nlps_gpu_set_ghost_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_tangent_assemble.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        L.nlps_gpu_tangent_set_grouped.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_tangent_coo.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, _ip, _ip, _dp]
         L.nlps_gpu_sparsity_pattern.argtypes = [C.c_void_p, _ip]
         L.nlps_gpu_migration_select.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _ip, C.POINTER(C.c_void_p),

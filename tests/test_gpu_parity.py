@@ -350,6 +350,12 @@ def test_tangent_matrix_neo_hookean(ndim):
         assert np.unique(key).size == key.size
         assert np.array_equal(S.create_sparsity_pattern(), pat_o), "sparsity pattern"
         assert np.array_equal(np.bincount(rows, minlength=ntot), pat_o), "COO rows vs pattern"
+        # the one-wave-per-particle form gives the same matrix
+        S.L.nlps_gpu_tangent_set_grouped(S.h, 0)
+        rows2, cols2, vals2 = S.jacobian_evaluation(alpha_1, mass, dirichlet)
+        S.L.nlps_gpu_tangent_set_grouped(S.h, 1)
+        assert np.array_equal(rows2, rows) and np.array_equal(cols2, cols)
+        assert_close(vals2, vals, 1e-12, "per-particle vs grouped assembly", scale=np.abs(vals).max())
     assert np.abs(K_o - K_o.T).max() <= 1e-12 * np.abs(K_o).max()
     # another law in the cloud is refused, not silently skipped
     case2 = dict(case)

@@ -49,7 +49,7 @@ def run_case(name, ndim, cells, lo, blk, reps):
            "workload": name, "ndim": ndim, "particles": int(np_), "mean_neighbours": float(nn.mean()),
            "pair_blocks": pairs, "nnz": int(rows.size), "assemble_ms": 1e3 * ta,
            "assemble_plus_coo_download_ms": 1e3 * float(np.median(t_all)), "value": pairs / ta,
-           "unit": "blocks/s", "f64_atomics_per_s": pairs * ndim * ndim / ta, "dtype": "f64"}
+           "unit": "blocks/s", "dtype": "f64"}
     S.close()
     return out, case
 
