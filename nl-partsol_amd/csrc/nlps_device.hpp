@@ -73,6 +73,12 @@ struct ParamsD {
 #ifndef NLPS_JUNROLL_SCATTER
 #define NLPS_JUNROLL_SCATTER 5
 #endif
+#ifndef NLPS_K3_WAVES_2D
+#define NLPS_K3_WAVES_2D 2
+#endif
+#ifndef NLPS_K2_WAVES_2D
+#define NLPS_K2_WAVES_2D 3
+#endif
 #ifndef NLPS_JUNROLL_MASK
 #define NLPS_JUNROLL_MASK 1  // neighbourhood-mask rows: unrolling only costs registers (measured)
 #endif

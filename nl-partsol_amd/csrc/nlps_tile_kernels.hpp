@@ -236,7 +236,7 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
 template <int ND, bool P2G>
-__global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
+__global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
   constexpr int KN = Lme<ND>::KN;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(BLK, NLPS_K2_WAVES) void k2_tile(PView P, GridD g, 
 // MODE 2: MODE 0 plus the rate tensors dt_DF = sum dV_A (x) grad N_A and dt_F_n1 = dt_DF F_n + DF dt_F_n
 // (compute-Strains.c:48-72, 176-207) from a second gather window dV.
 template <int ND, int LAW, int MODE>
-__global__ __launch_bounds__(BLK, NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+__global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus,
                                                const double* __restrict__ dVgrid) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
