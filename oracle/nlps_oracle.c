@@ -944,17 +944,23 @@ static int stress_hencky(int ndim, const orc_material *mat, const double *F_n1, 
  * buildable (2-D) reference because LAPACK's 2x2 eigenvector matrix is symmetric.  Restated with
  * the consistent COLUMN convention (SURVEY.md §7 hard part 3).  C_ep (:1088-1198, implicit tangent
  * only) is not produced. */
-static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_params *prm,
-                                 const double *d_phi, const double *b_e_n, double kappa_n,
-                                 double eps_n_in, double *T, double *W, double *b_e, double *kappa_out,
-                                 double *eps_out, double *C_ep) {
-  double eigval[3] = {0, 0, 0}, eigvec[9] = {0}, btr[9] = {0};
-  /* __compute_trial_b_e :617-660 */
+/* __compute_trial_b_e, Plasticity/Drucker-Prager.c:617-633: b_tr = d_phi b_e,n d_phi^T on the d x d block
+ * (the reference's tests/Constitutive/test.py checks this index convention on a fixed pair of matrices) */
+void orc_trial_b_e(double *btr, const double *d_phi, const double *b_e_n, int ndim) {
+  for (int i = 0; i < ndim * ndim; i++) btr[i] = 0.0;
   for (int i = 0; i < ndim; i++)
     for (int j = 0; j < ndim; j++)
       for (int k = 0; k < ndim; k++)
         for (int l = 0; l < ndim; l++)
           btr[i * ndim + j] += d_phi[i * ndim + k] * b_e_n[k * ndim + l] * d_phi[j * ndim + l];
+}
+
+static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_params *prm,
+                                 const double *d_phi, const double *b_e_n, double kappa_n,
+                                 double eps_n_in, double *T, double *W, double *b_e, double *kappa_out,
+                                 double *eps_out, double *C_ep) {
+  double eigval[3] = {0, 0, 0}, eigvec[9] = {0}, btr[9] = {0};
+  orc_trial_b_e(btr, d_phi, b_e_n, ndim);
   if (orc_sym_eigen(eigval, eigvec, btr, ndim)) return 1;
   if (ndim == 2) eigval[2] = b_e_n[4];
 

@@ -343,6 +343,15 @@ def stress_one(ndim, mat, prm, F_n1, DF, J, b_e_n, kappa_n, eps_n):
     return st, stress, W.value, b1, k1.value, e1.value
 
 
+def trial_b_e(d_phi, b_e_n, ndim):
+    out = np.zeros(ndim * ndim)
+    f = lib().orc_trial_b_e
+    f.argtypes = [_dp, _dp, _dp, C.c_int]
+    f.restype = None
+    f(_d(out), _d(np.ascontiguousarray(d_phi, dtype=np.float64)), _d(np.ascontiguousarray(b_e_n, dtype=np.float64)), ndim)
+    return out.reshape(ndim, ndim)
+
+
 def sym_eigen(A):
     A = np.ascontiguousarray(A, dtype=np.float64)
     n = A.shape[0]

@@ -376,3 +376,18 @@ def test_tangent_matrix_is_the_derivative_of_the_internal_forces(ndim):
         assert np.array_equal(Kd[d], row) and np.array_equal(Kd[:, d], row)
     inner = np.ix_(np.arange(1, ntot - 1), np.arange(1, ntot - 1))
     assert np.abs(Kd[inner] - (K + 6.0 * np.eye(ntot))[inner]).max() <= 1e-13 * np.abs(K).max(), "mass diagonal"
+
+
+def test_trial_b_e_against_the_reference_test_vector():
+    """The one fixture the reference's tests hold on this path: tests/Constitutive/test.py checks the index
+    convention of the trial elastic left Cauchy-Green tensor b_tr = d_phi b_e d_phi^T (Drucker-Prager.c:617-633) on
+    d_phi = [10, 20, 60, 40], b_e = [157, 671, 671, 1561] (integers: the product is exact)."""
+    o = orc()
+    d_phi = np.array([10.0, 20.0, 60.0, 40.0])
+    b_e = np.array([157.0, 671.0, 671.0, 1561.0])
+    expected = np.einsum("ik,kl,lj", d_phi.reshape(2, 2), b_e.reshape(2, 2), d_phi.reshape(2, 2).T)
+    assert np.array_equal(o.trial_b_e(d_phi, b_e, 2), expected)
+    # and in 3-D against the same einsum
+    rng = np.random.default_rng(2)
+    F, B = rng.normal(size=(3, 3)), rng.normal(size=(3, 3))
+    assert np.abs(o.trial_b_e(F.ravel(), B.ravel(), 3) - F @ B @ F.T).max() < 1e-13
