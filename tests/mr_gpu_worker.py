@@ -14,14 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-CELLS, MARGIN, NSTEPS = 8, 5, 4
+ND = int(os.environ.get("NLPS_NDIM", "3"))
+CELLS, MARGIN, NSTEPS = (8 if ND == 3 else 24), 5, 4
 
 
 def rank_cloud(synth, rank, world):
-    gc = [CELLS + 2 * MARGIN, CELLS + 2 * MARGIN, CELLS * world + 2 * MARGIN]
-    lo = [MARGIN, MARGIN, MARGIN + CELLS * rank]
-    return gc, synth.make_cloud(3, gc, lo, [CELLS] * 3, h=1.0, jitter=0.05, seed=777 + rank,
-                                velocity=[1.0, 0.5, -10.0])
+    gc = [CELLS + 2 * MARGIN] * (ND - 1) + [CELLS * world + 2 * MARGIN]
+    lo = [MARGIN] * (ND - 1) + [MARGIN + CELLS * rank]
+    return gc, synth.make_cloud(ND, gc, lo, [CELLS] * ND, h=1.0, jitter=0.05, seed=777 + rank,
+                                velocity=[1.0, 0.5, -10.0][3 - ND:])
 
 
 def main():
@@ -37,16 +38,16 @@ def main():
     gc, cloud = rank_cloud(synth, rank, world)
     gn = synth.grid_nodes(gc)
     mats = [util.NH]
-    bc = {"nodes": synth.plane_nodes(gn, 2, MARGIN + 1), "dim": 3, "dir": np.ones((3, NSTEPS), dtype=np.int32),
-          "value": np.zeros((3, NSTEPS))}
+    bc = {"nodes": synth.plane_nodes(gn, ND - 1, MARGIN + 1), "dim": ND, "dir": np.ones((ND, NSTEPS), dtype=np.int32),
+          "value": np.zeros((ND, NSTEPS))}
     dt = 0.4 / 100.0
     work_stream = torch.cuda.Stream()  # as bench.py: library kernels and callback ops share one real stream
     torch.cuda.set_stream(work_stream)
     stream = work_stream.cuda_stream
-    S = nlps.Solver(3, gn, [0.0] * 3, 1.0, cloud, mats, nsteps=NSTEPS, stream=stream)
-    lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[2], reach=3)
-    halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi)
-    nnodes = gn[0] * gn[1] * gn[2]
+    S = nlps.Solver(ND, gn, [0.0] * ND, 1.0, cloud, mats, nsteps=NSTEPS, stream=stream)
+    nnodes = int(np.prod(gn))
+    lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[ND - 1], reach=3)
+    halo = halo_mod.SlabHalo(torch, dist, rank, world, nnodes // gn[ND - 1], gn[ND - 1], lo, hi)
     S.set_halo_exchange(lambda dptr, nfield, elem, kind, phase: halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem,
                                                                                  kind, phase))
     S.set_node_window(lo[rank], hi[rank])
@@ -72,7 +73,7 @@ def main():
         whole = {}
         for k, v in clouds[0].items():
             whole[k] = np.concatenate([c[k] for c in clouds]) if isinstance(v, np.ndarray) else v
-        G = nlps.Solver(3, gn, [0.0] * 3, 1.0, whole, mats, nsteps=NSTEPS)
+        G = nlps.Solver(ND, gn, [0.0] * ND, 1.0, whole, mats, nsteps=NSTEPS)
         G.set_resort_interval(2)
         G.initialise_shapefun()
         for t in range(NSTEPS):
@@ -92,7 +93,7 @@ def main():
             got = np.concatenate([p[k] for p in parts])
             util.assert_close(got, ref[k], 1e-11 if k != "lambda" else 1e-9, "%s partitioned vs whole" % k)
         assert np.abs(ref["Stress"]).max() > 1.0, "the case must deform"
-        print("MULTIRANK_GPU_OK world=%d particles=%d overlap=%s" % (world, ref["x"].shape[0], overlap))
+        print("MULTIRANK_GPU_OK ndim=%d world=%d particles=%d overlap=%s" % (ND, world, ref["x"].shape[0], overlap))
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1

@@ -670,8 +670,8 @@ def test_halo_callback_and_rccl_on_library_memory():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap", [(2, 1), (3, 1), (3, 0)])
-def test_multirank_on_one_gpu(world, overlap):
+@pytest.mark.parametrize("world,overlap,ndim", [(2, 1, 3), (3, 1, 3), (3, 0, 3), (3, 1, 2)])
+def test_multirank_on_one_gpu(world, overlap, ndim):
     """N > 1 rehearsal on the one card of the test box: `world` processes, each with its slab, the halo
     callback (with and without overlapping the exchanges with the interior tiles), the node window and periodic
     re-sorts, against one solver holding the whole cloud
@@ -683,7 +683,7 @@ def test_multirank_on_one_gpu(world, overlap):
     port = 29600 + (os.getpid() + world) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mr_gpu_worker.py")]
-    env = dict(os.environ, NLPS_OVERLAP=str(overlap))
+    env = dict(os.environ, NLPS_OVERLAP=str(overlap), NLPS_NDIM=str(ndim))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
