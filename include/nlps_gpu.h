@@ -192,6 +192,20 @@ int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force
 int nlps_gpu_resort(nlps_gpu *h);
 int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
 
+/* ------------------------------------------------------------------ per-dof updates of the implicit driver (a21)
+ * Vectors of N_A*d doubles in masked numbering, host (VecGetArray) or device pointers.  alpha = the six Newmark
+ * parameters alpha_1..alpha_6 of __compute_Newmark_parameters (U-Newmark-beta.c:497-514). */
+/* __form_initial_guess, :879-957: optional explicit trial dU = dt*Un_dt + dt^2/2*Un_dt2, then the Dirichlet
+ * values of the active boundary dofs at `step` */
+int nlps_gpu_form_initial_guess(nlps_gpu *h, double *dU, const double *Un_dt, const double *Un_dt2, double dt,
+                                int use_explicit_trial, const nlps_bcc *bcc, int nbcc, int step);
+/* __compute_nodal_velocity_increments / __compute_nodal_kinetic_increments, :1834-1906 (either output may be NULL) */
+int nlps_gpu_nodal_kinetic_increments(nlps_gpu *h, double *dU_dt, double *dU_dt2, const double *dU,
+                                      const double *Un_dt, const double *Un_dt2, const double *alpha);
+/* __nodal_inertial_forces, :1519-1557: R += M (alpha_1 dU - alpha_2 Un_dt - alpha_3 Un_dt2 - b) on the free dofs */
+int nlps_gpu_nodal_inertial_forces(nlps_gpu *h, double *R, const double *M, const double *dU, const double *Un_dt,
+                                   const double *Un_dt2, const double *alpha, const double *gravity);
+
 /* ------------------------------------------------------------------ tangent assembly */
 
 /* __jacobian_evaluation (U-Newmark-beta.c:1646-1830) for Neo-Hookean particles

@@ -816,6 +816,8 @@ struct nlps_gpu {
   int band_lo = -(1 << 30), band_hi = 1 << 30;  // ghost bands: layers <= band_lo and >= band_hi are shared with neighbours
   bool overlap = false;     // overlap the halo exchanges with the interior tiles (needs bands + a two-phase callback)
   unsigned long long* phase_d = nullptr;
+  double* vec_d = nullptr;  // scratch pool for host vectors of the a21 per-dof updates
+  size_t vec_cap = 0;
   // tangent assembly, allocated on first use
   double* kst_d = nullptr;           // [nnodes][S][d*d]
   unsigned char* ktouched_d = nullptr;  // [nnodes][S]
@@ -1466,7 +1468,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -2086,6 +2088,143 @@ extern "C" int nlps_gpu_explicit_nodal(nlps_gpu* h, double* mass, double* dU, do
   if (accel && from_grid(h, accel, h->N.accel, ND, ND, 0, 0, 0, nullptr)) return 1;
   if (reaction && from_grid(h, reaction, h->N.reaction, ND, ND, 0, 0, 0, nullptr)) return 1;
   return check_status(h, ST_NEWTON | ST_CONNECT | ST_JACOBIAN | ST_CONSTITUTIVE | ST_HALO, "nlps_gpu_explicit_step()");
+}
+
+// ------------------------------------------------------------------------------------------------
+// a21: the per-dof vector updates of the implicit driver (masked numbering, N_A*d doubles)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_vec_initial_guess(int n, double* __restrict__ dU, const double* __restrict__ v, const double* __restrict__ a,
+                                    double dt, int trial) {  // __form_initial_guess, U-Newmark-beta.c:893-901
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && trial) dU[i] = dt * v[i] + 0.5 * dsqr(dt) * a[i];
+}
+__global__ void k_vec_guess_bc(const int* __restrict__ nodes, int n, int nd, int dim, int dirbits, double v0, double v1,
+                               double v2, const int* __restrict__ n2m, double* __restrict__ dU) {  // :909-950
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int m = n2m[nodes[q]];
+  if (m == -1) return;
+  const double v[3] = {v0, v1, v2};
+  for (int k = 0; k < nd; k++)
+    if (k < dim && ((dirbits >> k) & 1)) dU[m * nd + k] = v[k];
+}
+__global__ void k_vec_increments(int n, double* __restrict__ dV, double* __restrict__ dA, const double* __restrict__ dU,
+                                 const double* __restrict__ v, const double* __restrict__ a, double a1, double a2,
+                                 double a3, double a4, double a5, double a6) {  // :1834-1906
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (dV) dV[i] = a4 * dU[i] + (a5 - 1) * v[i] + a6 * a[i];
+  if (dA) dA[i] = a1 * dU[i] - a2 * v[i] - (a3 + 1) * a[i];
+}
+__global__ void k_vec_inertial(int n, int nd, double* __restrict__ R, const double* __restrict__ M,
+                               const double* __restrict__ dU, const double* __restrict__ v, const double* __restrict__ a,
+                               const int* __restrict__ d2m, double a1, double a2, double a3, double b0, double b1,
+                               double b2) {  // __nodal_inertial_forces, :1519-1557
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || d2m[i] == -1) return;
+  const double b[3] = {b0, b1, b2};
+  R[i] += M[i] * (a1 * dU[i] - a2 * v[i] - a3 * a[i] - b[i % nd]);
+}
+
+// host or device vectors of the caller: inputs are staged into a scratch pool when they live on the host,
+// outputs are written in place (device) or copied back (host)
+struct VecIO {
+  nlps_gpu* h;
+  size_t n;
+  int slot = 0;
+  std::vector<std::pair<double*, double*>> back;  // (host destination, device source)
+  const double* in(const double* p) {
+    if (!p || is_device_ptr(p)) return p;
+    double* d = h->vec_d + (size_t)(slot++) * n;
+    (void)hipMemcpyAsync(d, p, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    return d;
+  }
+  double* out(double* p, bool load) {
+    if (!p || is_device_ptr(p)) return p;
+    double* d = h->vec_d + (size_t)(slot++) * n;
+    if (load) (void)hipMemcpyAsync(d, p, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    back.push_back({p, d});
+    return d;
+  }
+  int finish() {
+    for (auto& b : back)
+      if (hipMemcpyAsync(b.first, b.second, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 1;
+    if (hipGetLastError() != hipSuccess) return 1;
+    if (!back.empty() && hipStreamSynchronize(h->stream) != hipSuccess) return 1;
+    return 0;
+  }
+};
+static int vec_begin(nlps_gpu* h, const char* who, VecIO& io) {
+  if (need_masks(h, who)) return 1;
+  io.h = h;
+  io.n = (size_t)h->nactive * h->nd;
+  if (io.n * 6 > h->vec_cap) {
+    if (h->vec_d) HIPCHK(hipFree(h->vec_d));
+    h->vec_cap = io.n * 6;
+    HIPCHK(hipMalloc((void**)&h->vec_d, h->vec_cap * sizeof(double)));
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_form_initial_guess(nlps_gpu* h, double* dU, const double* Un_dt, const double* Un_dt2, double dt,
+                                           int use_explicit_trial, const nlps_bcc* bcc, int nbcc, int step) {
+  VecIO io;
+  if (vec_begin(h, "nlps_gpu_form_initial_guess", io)) return 1;
+  if (ensure_bcs(h, bcc, nbcc)) return 1;
+  const int n = (int)io.n, ND = h->nd;
+  double* d = io.out(dU, true);
+  const double *v = io.in(Un_dt), *a = io.in(Un_dt2);
+  if (n > 0) hipLaunchKernelGGL(k_vec_initial_guess, dim3(nblk(n)), dim3(BLK), 0, h->stream, n, d, v, a, dt, use_explicit_trial);
+  for (int i = 0; i < nbcc; i++) {
+    if (h->bcs[i].n == 0) continue;
+    double val[3] = {0, 0, 0};
+    for (int k = 0; k < bcc[i].dim && k < 3; k++) val[k] = bcc[i].value[(size_t)k * h->nsteps + step];
+    hipLaunchKernelGGL(k_vec_guess_bc, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, h->stream, h->bcs[i].dnodes, h->bcs[i].n, ND,
+                       bcc[i].dim, dirbits_of(bcc[i], step, h->nsteps), val[0], val[1], val[2], h->n2m_d, d);
+  }
+  if (io.finish()) {
+    h->err = "nlps_gpu_form_initial_guess: HIP error";
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_nodal_kinetic_increments(nlps_gpu* h, double* dU_dt, double* dU_dt2, const double* dU,
+                                                 const double* Un_dt, const double* Un_dt2, const double* alpha) {
+  VecIO io;
+  if (vec_begin(h, "nlps_gpu_nodal_kinetic_increments", io)) return 1;
+  const int n = (int)io.n;
+  double *dV = io.out(dU_dt, false), *dA = io.out(dU_dt2, false);
+  const double *u = io.in(dU), *v = io.in(Un_dt), *a = io.in(Un_dt2);
+  if (n > 0)
+    hipLaunchKernelGGL(k_vec_increments, dim3(nblk(n)), dim3(BLK), 0, h->stream, n, dV, dA, u, v, a, alpha[0], alpha[1], alpha[2],
+                       alpha[3], alpha[4], alpha[5]);
+  if (io.finish()) {
+    h->err = "nlps_gpu_nodal_kinetic_increments: HIP error";
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_nodal_inertial_forces(nlps_gpu* h, double* R, const double* M, const double* dU,
+                                              const double* Un_dt, const double* Un_dt2, const double* alpha,
+                                              const double* gravity) {
+  VecIO io;
+  if (vec_begin(h, "nlps_gpu_nodal_inertial_forces", io)) return 1;
+  const int n = (int)io.n, ND = h->nd;
+  double* r = io.out(R, true);
+  const double *m = io.in(M), *u = io.in(dU), *v = io.in(Un_dt), *a = io.in(Un_dt2);
+  double b[3] = {0, 0, 0};
+  if (gravity)
+    for (int k = 0; k < ND; k++) b[k] = gravity[k];
+  if (n > 0)
+    hipLaunchKernelGGL(k_vec_inertial, dim3(nblk(n)), dim3(BLK), 0, h->stream, n, ND, r, m, u, v, a, h->d2m_d, alpha[0], alpha[1],
+                       alpha[2], b[0], b[1], b[2]);
+  if (io.finish()) {
+    h->err = "nlps_gpu_nodal_inertial_forces: HIP error";
+    return 1;
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

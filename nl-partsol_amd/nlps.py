@@ -65,6 +65,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
            "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
+           "nlps_gpu_form_initial_guess", "nlps_gpu_nodal_kinetic_increments", "nlps_gpu_nodal_inertial_forces",
            "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_set_grouped", "nlps_gpu_tangent_coo",
            "nlps_gpu_sparsity_pattern",
            "nlps_gpu_migration_select", "nlps_gpu_migration_commit", "nlps_gpu_num_particles",
@@ -94,6 +95,10 @@ def lib():
         L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.nlps_gpu_set_ghost_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.nlps_gpu_form_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                                  C.POINTER(Bcc), C.c_int, C.c_int]
+        L.nlps_gpu_nodal_kinetic_increments.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [_dp]
+        L.nlps_gpu_nodal_inertial_forces.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [_dp, _dp]
         L.nlps_gpu_tangent_assemble.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.nlps_gpu_tangent_set_grouped.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_tangent_coo.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, _ip, _ip, _dp]
@@ -390,6 +395,27 @@ class Solver:
         lo, hi = C.c_int(0), C.c_int(0)
         self._chk(self.L.nlps_gpu_touched_layers(self.h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def form_initial_guess(self, Un_dt, Un_dt2, dt, bcs, step, use_explicit_trial=True):  # __form_initial_guess
+        dU = np.zeros(self.nactive * self.ndim)
+        self._chk(self.L.nlps_gpu_form_initial_guess(self.h, _vp(dU), _vp(Un_dt), _vp(Un_dt2), float(dt),
+                                                     1 if use_explicit_trial else 0, bcs.arr, bcs.n, int(step)))
+        return dU
+
+    def compute_nodal_kinetic_increments(self, dU, Un_dt, Un_dt2, alpha):  # __compute_nodal_kinetic_increments
+        n = self.nactive * self.ndim
+        dV, dA = np.zeros(n), np.zeros(n)
+        al = np.ascontiguousarray(alpha, dtype=np.float64)
+        self._chk(self.L.nlps_gpu_nodal_kinetic_increments(self.h, _vp(dV), _vp(dA), _vp(dU), _vp(Un_dt), _vp(Un_dt2),
+                                                           _d(al)))
+        return dV, dA
+
+    def nodal_inertial_forces(self, R, M, dU, Un_dt, Un_dt2, alpha, gravity=None):  # __nodal_inertial_forces
+        al = np.ascontiguousarray(alpha, dtype=np.float64)
+        gv = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float64)
+        self._chk(self.L.nlps_gpu_nodal_inertial_forces(self.h, _vp(R), _vp(M), _vp(dU), _vp(Un_dt), _vp(Un_dt2), _d(al),
+                                                        _d(gv)))
+        return R
 
     def jacobian_evaluation(self, alpha_1=0.0, lumped_mass=None, apply_dirichlet=False):  # __jacobian_evaluation
         """COO triplets (rows, cols, vals) of the tangent matrix in masked dof numbering (Neo-Hookean)."""

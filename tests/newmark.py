@@ -20,23 +20,33 @@ def newmark_step(stage, ndim, bcs_list, step, nsteps, dt, gravity, beta=0.25, ga
     free = d2m != -1
     M = stage.lumped_mass()                                        # :223
     Un_dt, Un_dt2 = stage.nodal_field_n(M)                         # :241
-    dU = dt * Un_dt + 0.5 * dt * dt * Un_dt2                       # __form_initial_guess, explicit trial :893-901
-    for b in bcs_list:                                             # :909-950
-        for node in b["nodes"]:
-            m = n2m[node]
-            if m == -1:
-                continue
-            for k in range(b["dim"]):
-                if b["dir"][k, step] == 1:
-                    dU[m * ndim + k] = b["value"][k, step]
+    alpha = [a["a1"], a["a2"], a["a3"], a["a4"], a["a5"], a["a6"]]
+    if hasattr(stage, "form_initial_guess"):                       # device versions of the per-dof updates (a21)
+        dU = stage.form_initial_guess(Un_dt, Un_dt2, dt, bcs_list, step)
+    else:
+        dU = dt * Un_dt + 0.5 * dt * dt * Un_dt2                   # __form_initial_guess, explicit trial :893-901
+        for b in bcs_list:                                         # :909-950
+            for node in b["nodes"]:
+                m = n2m[node]
+                if m == -1:
+                    continue
+                for k in range(b["dim"]):
+                    if b["dir"][k, step] == 1:
+                        dU[m * ndim + k] = b["value"][k, step]
     bvec = np.tile(np.asarray(gravity, dtype=np.float64), na)
     history = []
     for it in range(max_iter):
-        dU_dt = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2        # :1836-1856
+        if hasattr(stage, "kinetic_increments"):
+            dU_dt, _ = stage.kinetic_increments(dU, Un_dt, Un_dt2, alpha)
+        else:
+            dU_dt = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2    # :1836-1856
         stage.compatibility(dU, dU_dt)                                          # :1026
         stage.constitutive()                                                    # :1031
         R = stage.internal_forces()                                             # :1033 (Dirichlet dofs skipped)
-        R[free] += (M * (a["a1"] * dU - a["a2"] * Un_dt - a["a3"] * Un_dt2 - bvec))[free]   # :1519-1557
+        if hasattr(stage, "inertial_forces"):
+            R = stage.inertial_forces(R, M, dU, Un_dt, Un_dt2, alpha, gravity)
+        else:
+            R[free] += (M * (a["a1"] * dU - a["a2"] * Un_dt - a["a3"] * Un_dt2 - bvec))[free]   # :1519-1557
         res = float(np.linalg.norm(R[free]))
         history.append(res)
         if res <= tol * max(1.0, history[0]):
@@ -45,8 +55,11 @@ def newmark_step(stage, ndim, bcs_list, step, nsteps, dt, gravity, beta=0.25, ga
         rhs = -R
         rhs[~free] = 0.0
         dU = dU + np.linalg.solve(K, rhs)
-    dU_dt = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2             # :1859-1906
-    dU_dt2 = a["a1"] * dU - a["a2"] * Un_dt - (a["a3"] + 1) * Un_dt2
+    if hasattr(stage, "kinetic_increments"):
+        dU_dt, dU_dt2 = stage.kinetic_increments(dU, Un_dt, Un_dt2, alpha)
+    else:
+        dU_dt = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2         # :1859-1906
+        dU_dt2 = a["a1"] * dU - a["a2"] * Un_dt - (a["a3"] + 1) * Un_dt2
     stage.roll()                                                                # :393
     stage.update_kinetics(dU, Un_dt, dU_dt, dU_dt2)                             # :396, alpha_blend = 1 (:148)
     return dU, history

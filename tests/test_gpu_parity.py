@@ -438,6 +438,15 @@ class _DeviceStages:
     def internal_forces(self):
         return self.S.nodal_internal_forces(np.zeros(self.S.nactive * self.ndim))
 
+    def form_initial_guess(self, Un_dt, Un_dt2, dt, bcs, step):
+        return self.S.form_initial_guess(Un_dt, Un_dt2, dt, self.n.BccSet(bcs), step)
+
+    def kinetic_increments(self, dU, Un_dt, Un_dt2, alpha):
+        return self.S.compute_nodal_kinetic_increments(dU, Un_dt, Un_dt2, alpha)
+
+    def inertial_forces(self, R, M, dU, Un_dt, Un_dt2, alpha, gravity):
+        return self.S.nodal_inertial_forces(R, M, dU, Un_dt, Un_dt2, alpha, gravity)
+
     def tangent(self, alpha_1, Mv):
         rows, cols, vals = self.S.jacobian_evaluation(alpha_1, Mv, True)
         ntot = self.S.nactive * self.ndim
@@ -455,7 +464,8 @@ class _DeviceStages:
 @pytest.mark.parametrize("ndim", [2, 3])
 def test_implicit_newmark_steps_with_device_stages(ndim):
     """The maintained driver's time step (U_Newmark_Beta, U-Newmark-beta.c:192-409) composed from the level-B
-    stage calls and the device tangent, three steps with gravity and a fixed floor, against the same host algebra
+    stage calls, the device versions of the per-dof updates (a21: initial guess with Dirichlet values, kinetic
+    increments, inertial forces; the oracle side uses the numpy restatement in tests/newmark.py) and the device tangent, three steps with gravity and a fixed floor, against the same host algebra
     (tests/newmark.py) over the oracle.  The Newton iteration must converge quadratically with the device
     tangent, take the same number of iterations and leave the same particles behind."""
     from newmark import newmark_step
