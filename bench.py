@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--migrate-every", type=int, default=0,
                     help="N > 1: hand particles whose closest node left the rank's slab to the neighbour every k "
                          "steps (0 = never: the default 25 steps move the cloud by 0.25 cells)")
+    ap.add_argument("--workload", choices=["step", "tangent"], default="step",
+                    help="step: the explicit particle step (the headline metric); tangent: the Neo-Hookean tangent "
+                         "assembly of the implicit driver (SURVEY 8f n1), one JSON line per case")
     ap.add_argument("--overlap", type=int, choices=[0, 1], default=1,
                     help="N > 1: run the halo exchanges behind the interior tiles (1) or blocking in place (0)")
     return ap.parse_args()
@@ -99,8 +102,88 @@ def cpu_baseline(cells, budget_s=25.0):
                       "reference's omp-critical nodal accumulation" % (cells, best[2], budget_s)}
 
 
+# ---------------------------------------------------------------------------------------------------
+# --workload tangent: nlps_gpu_tangent_assemble + nlps_gpu_tangent_coo on synthetic Neo-Hookean clouds, with the
+# oracle's dense restatement timed beside it on a bounded sample (the cpu_baseline leg)
+# ---------------------------------------------------------------------------------------------------
+def _nh_case(ndim, cells, lo, blk):
+    synth = importlib.import_module("nl-partsol_amd.synth")
+    cloud = synth.make_cloud(ndim, cells, lo, blk, h=1.0, jitter=0.05, seed=12345, velocity=[0.0] * (ndim - 1) + [-1.0])
+    return {"ndim": ndim, "cells": cells, "grid_n": synth.grid_nodes(cells), "origin": [0.0] * ndim, "h": 1.0,
+            "cloud": cloud, "materials": [{"type": 0, "E": 1.0e7, "nu": 0.3}]}
+
+
+def tangent_cpu_baseline(ndim):
+    from oracle import orc
+    case = _nh_case(2, [16, 16], [4, 4], [8, 8]) if ndim == 2 else _nh_case(3, [9, 9, 9], [3, 3, 3], [3, 3, 3])
+    M = orc.OracleMesh(ndim, case["grid_n"], case["origin"], case["h"])
+    P = orc.OracleParticles(case["cloud"])
+    prm = orc.default_params()
+    mats = orc.make_materials(case["materials"])
+    assert orc.initialize_lme(P, M, prm) == 0
+    n2m, na = orc.active_nodes(M)
+    orc.compatibility(np.zeros(na * ndim), None, P, M, n2m)
+    orc.constitutive(P, mats, prm)
+    t0 = time.perf_counter()
+    K, pat, st = orc.tangent_matrix(P, M, mats, n2m, None, na, with_pattern=False)
+    dt = time.perf_counter() - t0
+    pairs = float((P["nn"].astype(np.int64) ** 2).sum())
+    return {"value": pairs / dt, "unit": "blocks/s", "cores": 1, "kind": "port",
+            "sample": "%d-D, %d particles, dense matrix %d^2 (oracle/nlps_oracle.c, serial like the reference's "
+                      "omp-critical MatSetValues)" % (ndim, P.np, na * ndim)}
+
+
+def bench_tangent(a):
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    nlps = importlib.import_module("nl-partsol_amd.nlps")
+    synth = importlib.import_module("nl-partsol_amd.synth")
+    cases = [("2-D bar 10k particles (BASELINE configs[0] shape)", 2, [60, 60], [5, 5], [50, 50]),
+             ("2-D 250k particles", 2, [260, 260], [5, 5], [250, 250]),
+             ("3-D 27k particles", 3, [25, 25, 25], [5, 5, 5], [15, 15, 15])]
+    cpu = {} if a.no_cpu_baseline else {2: tangent_cpu_baseline(2), 3: tangent_cpu_baseline(3)}
+    for name, ndim, cells, lo, blk in cases:
+        case = _nh_case(ndim, cells, lo, blk)
+        S = nlps.Solver(ndim, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"], nsteps=1)
+        S.initialise_shapefun()
+        nodes = synth.plane_nodes(case["grid_n"], ndim - 1, lo[ndim - 1])
+        gb = nlps.BccSet([{"nodes": nodes, "dim": ndim, "dir": np.ones((ndim, 1), dtype=np.int32),
+                           "value": np.zeros((ndim, 1))}])
+        S.active_masks(gb, 0)
+        rng = np.random.default_rng(0)
+        S.local_compatibility_conditions(1e-3 * rng.normal(size=S.nactive * ndim))
+        S.constitutive_update()
+        Mv = S.compute_nodal_lumped_mass()
+        S.jacobian_evaluation(1.0, Mv, True)  # warm-up (allocates the stencil array)
+        t_asm, t_all = [], []
+        for _ in range(max(3, a.steps // 4)):
+            nnz = C.c_longlong(0)
+            t0 = time.perf_counter()
+            S._chk(S.L.nlps_gpu_tangent_assemble(S.h, C.byref(nnz)))  # synchronises (status check)
+            t_asm.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            rows, cols, vals = S.jacobian_evaluation(1.0, Mv, True)
+            t_all.append(time.perf_counter() - t0)
+        nn, _ = S.download_lists()
+        pairs = float((nn.astype(np.int64) ** 2).sum())
+        ta = float(np.median(t_asm))
+        out = {"metric": "tangent particle-pair blocks/s (assembly kernels, incl. clearing the stencil array)",
+               "workload": name, "ndim": ndim, "particles": int(case["cloud"]["x"].shape[0]),
+               "mean_neighbours": float(nn.mean()), "pair_blocks": pairs, "nnz": int(rows.size),
+               "assemble_ms": 1e3 * ta, "assemble_plus_coo_download_ms": 1e3 * float(np.median(t_all)),
+               "value": pairs / ta, "unit": "blocks/s", "dtype": "f64", "data": "synthetic", "n_gpus": 1}
+        if cpu:
+            out["cpu_baseline"] = cpu[ndim]
+        print(json.dumps(out), flush=True)
+        S.close()
+
+
 def main():
     a = parse()
+    if a.workload == "tangent":
+        return bench_tangent(a)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
