@@ -493,6 +493,52 @@ def test_implicit_newmark_steps_with_device_stages(ndim):
     assert np.abs(A.P["stress"]).max() > 10.0
 
 
+@pytest.mark.parametrize("nexplicit", [1, 2, 3])
+def test_stage_calls_after_explicit_steps(nexplicit):
+    """The explicit step rolls F and b_e by renaming their n/n+1 slots; a level-B stage or a download right after an
+    odd or even number of such steps must still see the reference's copy semantics (n+1 == n after the roll)."""
+    o = orc()
+    n = nlps()
+    case = small_case(3, material=DP, velocity=[0.0, 0.0, -0.2])
+    nsteps = 4
+    bcs_list = [dirichlet_plane(case, 2, 2, nsteps)]
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps, gravity=[0.0, 0.0, -9.81])
+    gb = n.BccSet(bcs_list)
+    dt = 0.1 * case["h"] / np.sqrt(DP["E"] / 1000.0)
+    for t in range(nexplicit):
+        assert stepper.step(t, dt) == 0
+        S.explicit_step(gb, t, dt, 0.5, [0.0, 0.0, -9.81])
+    st = S.download_state()
+    for k in ("F_n", "b_e_n"):
+        assert_close(st[k], P[k], 1e-10, f"{k} after {nexplicit} explicit steps")
+        assert np.array_equal(st[k + "1"], st[k]), f"{k}1 must equal {k} after the roll"
+    # level-B stages on top of that state
+    assert o.local_search(P, M, prm) == 0
+    S.local_search()
+    n2m, d2m, na = masks(S, M, bcs_list, nexplicit, nsteps)
+    rng = np.random.default_rng(5)
+    dU = 2e-3 * rng.normal(size=na * 3)
+    assert o.compatibility(dU, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+    S.local_compatibility_conditions(dU)
+    S.constitutive_update()
+    R_o, s = o.internal_forces(P, M, n2m, d2m, na)
+    R_g = S.nodal_internal_forces(np.zeros(na * 3))
+    assert_close(R_g, R_o, 1e-10, "internal forces after explicit steps")
+    st = S.download_state()
+    for k, ok in (("F_n1", "F_n1"), ("b_e_n1", "b_e_n1"), ("Stress", "stress"), ("F_n", "F_n"), ("b_e_n", "b_e_n")):
+        assert_close(st[k], P[ok], 1e-10, f"{k} after level-B stages on top of {nexplicit} explicit steps")
+    # and the explicit scheme continues from there
+    o.roll_state(P)
+    S.update_particles_internal_variables()
+    assert stepper.step(nexplicit, dt) == 0
+    S.explicit_step(gb, nexplicit, dt, 0.5, [0.0, 0.0, -9.81])
+    st = S.download_state()
+    for k, ok in (("x", "x"), ("F_n", "F_n"), ("b_e_n", "b_e_n"), ("Stress", "stress")):
+        assert_close(st[k], P[ok], 1e-9, f"{k} after continuing explicitly")
+
+
 def test_device_pointer_nodal_vectors():
     """Nodal Vec arrays may live on the device (torch tensors) as well as on the host."""
     import torch
