@@ -306,7 +306,8 @@ def main():
                                    "Neo-Hookean E=1e7 nu=0.3, explicit predictor-corrector step, 1xMI355X per rank; "
                                    "blocks stacked along z for N>1" % (npart, a.cells),
                        "particles_total": npart * world, "grid_nodes": int(np.prod(case["grid_n"])),
-                       "halo": a.halo if world > 1 else "none"},
+                       "halo": a.halo if world > 1 else "none",
+                       "halo_overlap": bool(a.overlap) if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_particle": alg[dom], "kernel_ms": float(kms[dom]),
