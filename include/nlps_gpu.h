@@ -208,13 +208,13 @@ int nlps_gpu_nodal_inertial_forces(nlps_gpu *h, double *R, const double *M, cons
 
 /* ------------------------------------------------------------------ tangent assembly */
 
-/* __jacobian_evaluation (U-Newmark-beta.c:1646-1830) for Neo-Hookean particles
- * (compute_stiffness_density_Neo_Hookean, Hyperelastic/Neo-Hookean.c:89-141): the d x d blocks
- * V0 * stiffness_density(A, B) of every node pair a particle connects are summed on the device, from the state
- * the compatibility + constitutive stages left (DF, F_n, J_n1) and the current lists / lambda.  *nnz = number
- * of COO entries = d*d * (number of structurally visited node pairs, the reference's sparsity pattern).
- * Needs nlps_gpu_active_masks() first.  EXIT_FAILURE if a particle has another law: the spectral tangents of
- * Hencky / Drucker-Prager divide by eigenvalue differences down to 1e-14 and are not reproduced. */
+/* __jacobian_evaluation (U-Newmark-beta.c:1646-1830) with stiffness_density__Constitutive__
+ * (Constitutive.c:262-381): Neo-Hookean (Hyperelastic/Neo-Hookean.c:89-141), Hencky (Hencky.c:98-229) and
+ * Drucker-Prager (Plasticity/Elastoplastic-Tangent-Matrix.c:42-163, with the C_ep of the last constitutive
+ * update).  The d x d blocks V0 * stiffness_density(A, B) of every node pair a particle connects are summed on
+ * the device, from the state the compatibility + constitutive stages left (DF, F_n, F_n1, J_n1, tau, b_e,n+1,
+ * C_ep) and the current lists / lambda.  *nnz = number of COO entries = d*d * (number of structurally visited node
+ * pairs, the reference's sparsity pattern).  Needs nlps_gpu_active_masks() first. */
 int nlps_gpu_tangent_assemble(nlps_gpu *h, long long *nnz);
 /* grouped != 0 (default): one workgroup per closest node sums the blocks of the particles sharing it before the
  * atomics; 0: one wave per particle (kept for comparison, same result up to summation order). */

@@ -158,7 +158,12 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
                                                             int* __restrict__ gstatus) {
   constexpr int S = TanCfg<ND>::S, MAXM = TanCfg<ND>::MAXM, KN = Lme<ND>::KN;
   __shared__ double gn[TAN_GROUP][MAXM][ND], g1[TAN_GROUP][MAXM][ND], ub[TAN_GROUP][MAXM][ND];
-  __shared__ double coef[TAN_GROUP][3];  // V0*c0, V0*c1, V0*G of each particle
+  __shared__ double coef[TAN_GROUP][3];  // V0*c0, V0*c1, V0*G of each particle (Neo-Hookean)
+  // spectral laws (Hencky.c:98-229, Elastoplastic-Tangent-Matrix.c:42-163): eigenvectors (column A) and eigenvalues
+  // of b, eigenvalues of the Kirchhoff block, moduli (AA or C_ep), the Kirchhoff block itself, V0
+  __shared__ double sp_n[TAN_GROUP][ND * ND], sp_lam[TAN_GROUP][ND], sp_tauv[TAN_GROUP][ND], sp_C[TAN_GROUP][ND * ND],
+      sp_tau[TAN_GROUP][ND * ND], sp_V0[TAN_GROUP];
+  __shared__ int law_of[TAN_GROUP];
   __shared__ u64 mem[TAN_GROUP][2];
   __shared__ double tab[4][6][5];  // per wave: ex, ey, ez, lx, ly, lz of the particle it is building
   if ((int)blockIdx.x >= *ngroups) return;
@@ -180,11 +185,9 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
       const bool ok_lists = load_lme<ND>(P, g, p, c, lam, beta);
       const MatD m = mats[P.mat[p]];
       double Zinv = 0.0, r[ND], J[ND * ND], Jm1[ND * ND], DF[ND * ND], DFm1[ND * ND], Fn[ND * ND], bn[ND * ND], zz;
-      bool ok = ok_lists && m.type == NLPS_MAT_NEO_HOOKEAN;
-      if (ok_lists && m.type != NLPS_MAT_NEO_HOOKEAN && lane == 0) {
-        atomicOr(&P.status[p], ST_CONSTITUTIVE);
-        atomicOr(gstatus, ST_CONSTITUTIVE);
-      }
+      bool ok = ok_lists;
+      const bool spectral = m.type != NLPS_MAT_NEO_HOOKEAN;
+      double nv[ND * ND];  // eigenvectors of b (spectral laws)
       if (ok) {
         lme_moments_h<ND>(c, Zinv, r, J);
         load_block<ND>(P, F_DF, p, DF, zz);
@@ -197,7 +200,43 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
           ok = false;
         }
       }
-      if (ok) left_cauchy_green<ND>(bn, Fn);
+      if (ok && !spectral) left_cauchy_green<ND>(bn, Fn);
+      if (ok && spectral) {
+        double bmat[ND * ND], tau[ND * ND], lamb[3] = {0, 0, 0}, tauv[3] = {0, 0, 0}, tv[ND * ND], Cm[ND * ND];
+        load_block<ND>(P, F_TAU, p, tau, zz);
+        if (m.type == NLPS_MAT_HENCKY) {
+          double F1[ND * ND];
+          load_block<ND>(P, fFN1(P), p, F1, zz);
+          left_cauchy_green<ND>(bmat, F1);
+#pragma unroll
+          for (int i = 0; i < ND; i++)
+#pragma unroll
+            for (int j = 0; j < ND; j++) Cm[i * ND + j] = m.lame + (i == j ? 2 * m.G : 0.0);
+        } else {
+          load_block<ND>(P, fBEN1(P), p, bmat, zz);
+#pragma unroll
+          for (int q = 0; q < ND * ND; q++) Cm[q] = PF(P, F_CEP + q, p);
+        }
+        sym_eigen<ND>(lamb, nv, bmat);
+        sym_eigen<ND>(tauv, tv, tau);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < ND * ND; q++) {
+            sp_n[jj][q] = nv[q];
+            sp_C[jj][q] = Cm[q];
+            sp_tau[jj][q] = tau[q];
+          }
+#pragma unroll
+          for (int a = 0; a < ND; a++) {
+            sp_lam[jj][a] = lamb[a];
+            sp_tauv[jj][a] = tauv[a];
+          }
+        }
+      }
+      if (lane == 0) {
+        law_of[jj] = m.type;
+        sp_V0[jj] = ok ? PF(P, F_VOL0, p) : 0.0;
+      }
 #pragma unroll
       for (int i = 0; i < 5; i++)
         if (lane == i) {
@@ -243,6 +282,18 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
           g1[jj][s][a] = on ? v1 : 0.0;
           ub[jj][s][a] = on ? vb : 0.0;
         }
+        if (spectral) {  // gn <- projections of the pushed-forward gradient on the eigenvectors of b
+          double pr[ND];
+#pragma unroll
+          for (int A = 0; A < ND; A++) {
+            double v = 0.0;
+#pragma unroll
+            for (int i2 = 0; i2 < ND; i2++) v = fma(g1[jj][s][i2], ok ? nv[A + i2 * ND] : 0.0, v);
+            pr[A] = v;
+          }
+#pragma unroll
+          for (int A = 0; A < ND; A++) gn[jj][s][A] = on ? pr[A] : 0.0;
+        }
       }
     }
     __syncthreads();
@@ -258,6 +309,52 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
         const bool inB = sB < 64 ? (mem[jj][0] >> sB) & 1ull : (mem[jj][1] >> (sB - 64)) & 1ull;
         if (!(inA && inB)) continue;
         any = true;
+        if (law_of[jj] != NLPS_MAT_NEO_HOOKEAN) {
+          // K = V0 [ sum_AB (W_AB + delta_AB D_A) n_A (x) n_B - (tau g1_B) (x) g1_A ],  a = proj(sA), b = proj(sB):
+          // W_AB = C_AB a_A b_B + [A != B] 1/2 q_AB lam_A b_A a_B ,  D_A = sum_{B != A} 1/2 q_AB lam_B a_B b_B ,
+          // q_AB = (tau_B - tau_A) / (lam_B - lam_A) where |lam_B - lam_A| > 1e-14
+          double a[ND], b[ND], Wm[ND * ND];
+#pragma unroll
+          for (int A = 0; A < ND; A++) {
+            a[A] = gn[jj][sA][A];
+            b[A] = gn[jj][sB][A];
+          }
+#pragma unroll
+          for (int A = 0; A < ND; A++) {
+            double DA = 0.0;
+#pragma unroll
+            for (int B = 0; B < ND; B++) {
+              double w = sp_C[jj][A * ND + B] * a[A] * b[B];
+              if (A != B) {
+                const double dl = sp_lam[jj][B] - sp_lam[jj][A];
+                if (fabs(dl) > 1E-14) {
+                  const double hq = 0.5 * ((sp_tauv[jj][B] - sp_tauv[jj][A]) / dl);
+                  w += hq * sp_lam[jj][A] * b[A] * a[B];
+                  DA += hq * sp_lam[jj][B] * a[B] * b[B];
+                }
+              }
+              Wm[A * ND + B] = w;
+            }
+            Wm[A * ND + A] += DA;
+          }
+          const double V0 = sp_V0[jj];
+#pragma unroll
+          for (int i = 0; i < ND; i++) {
+            double tb = 0.0;  // (tau g1_B)[i]
+#pragma unroll
+            for (int k2 = 0; k2 < ND; k2++) tb = fma(sp_tau[jj][i * ND + k2], g1[jj][sB][k2], tb);
+#pragma unroll
+            for (int j = 0; j < ND; j++) {
+              double v = -tb * g1[jj][sA][j];
+#pragma unroll
+              for (int A = 0; A < ND; A++)
+#pragma unroll
+                for (int B = 0; B < ND; B++) v = fma(Wm[A * ND + B], sp_n[jj][A + i * ND] * sp_n[jj][B + j * ND], v);
+              acc[i * ND + j] = fma(V0, v, acc[i * ND + j]);
+            }
+          }
+          continue;
+        }
         double len0 = 0.0;
 #pragma unroll
         for (int a = 0; a < ND; a++) len0 = fma(gn[jj][sB][a], ub[jj][sA][a], len0);

@@ -1237,12 +1237,61 @@ static void stiffness_density_neo_hookean(double *Kd, int ndim, const double *dN
       Kd[i * ndim + j] = c0 * dNa_n1[i] * dNb_n1[j] + G * lenght_0 * (i == j) + c1 * dNa_n1[j] * dNb_n1[i];
 }
 
+/* Spectral stiffness density shared by compute_stiffness_density_Hencky__Constitutive__ (Hyperelastic/Hencky.c:98-229:
+ * b = F_n1 F_n1^T, moduli AA = [lambda + 2G on the diagonal, lambda elsewhere]) and
+ * compute_stiffness_elastoplastic__Constitutive__ (Plasticity/Elastoplastic-Tangent-Matrix.c:42-163: b = b_e,n+1,
+ * moduli C_ep).  Eigenpairs of b and eigenvalues of the d x d Kirchhoff block by dsyev (ascending; paired by
+ * index, :137-147); eigenvector A = column A.  The quotient (tau_B - tau_A)/(lambda_B - lambda_A) is skipped when
+ * |lambda_B - lambda_A| <= 1e-14 exactly like the reference. */
+static int stiffness_density_spectral(double *Kd, int ndim, const double *dN_alpha_n1, const double *dN_beta_n1,
+                                      const double *b, const double *Cmod, const double *Stress) {
+  double eigval_b[3] = {0, 0, 0}, eigvec_b[9] = {0}, eigval_T[3] = {0, 0, 0}, eigvec_T[9] = {0}, Tblk[9];
+  for (int i = 0; i < ndim * ndim; i++) {
+    Kd[i] = 0.0;
+    Tblk[i] = Stress[i];
+  }
+  if (orc_sym_eigen(eigval_b, eigvec_b, b, ndim)) return 1;
+  if (orc_sym_eigen(eigval_T, eigvec_T, Tblk, ndim)) return 1;
+  double u__o__v[3][3];
+  for (int i = 0; i < ndim; i++)
+    for (int j = 0; j < ndim; j++) u__o__v[i][j] = dN_beta_n1[i] * dN_alpha_n1[j];
+  for (int A = 0; A < ndim; A++) {
+    double u_A = 0.0, v_A = 0.0;
+    for (int i = 0; i < ndim; i++) {
+      u_A += dN_alpha_n1[i] * eigvec_b[A + i * ndim];
+      v_A += dN_beta_n1[i] * eigvec_b[A + i * ndim];
+    }
+    for (int B = 0; B < ndim; B++) {
+      double u_B = 0.0, v_B = 0.0;
+      for (int i = 0; i < ndim; i++) {
+        u_B += dN_alpha_n1[i] * eigvec_b[B + i * ndim];
+        v_B += dN_beta_n1[i] * eigvec_b[B + i * ndim];
+      }
+      double C_ep_AB = Cmod[A * ndim + B];
+      double v_A__dot__u_B = u_B * v_A, u_A__dot__v_B = u_A * v_B, u_B__dot__v_B = u_B * v_B;
+      for (int i = 0; i < ndim; i++)
+        for (int j = 0; j < ndim; j++) {
+          Kd[i * ndim + j] += C_ep_AB * u_A__dot__v_B * eigvec_b[A + i * ndim] * eigvec_b[B + j * ndim];
+          if (A != B && fabs(eigval_b[B] - eigval_b[A]) > 1E-14)
+            Kd[i * ndim + j] += 0.5 * ((eigval_T[B] - eigval_T[A]) / (eigval_b[B] - eigval_b[A])) *
+                                (eigval_b[B] * u_B__dot__v_B * (eigvec_b[A + i * ndim] * eigvec_b[A + j * ndim]) +
+                                 eigval_b[A] * v_A__dot__u_B * (eigvec_b[A + i * ndim] * eigvec_b[B + j * ndim]));
+        }
+    }
+  }
+  for (int i = 0; i < ndim; i++) /* geometric part */
+    for (int j = 0; j < ndim; j++)
+      for (int k = 0; k < ndim; k++) Kd[i * ndim + j] += -Stress[i * ndim + k] * u__o__v[k][j];
+  return 0;
+}
+
 /* __jacobian_evaluation, U-Newmark-beta.c:1646-1830, as a dense matrix K[ntot][ntot] (row-major, masked dof
  * numbering, ntot = nactive*ndim): particle loop with stiffness_density__Constitutive__ (Constitutive.c:262-283)
  * times V0 (:1768-1774), alpha_1 * lumped mass on the diagonal (:1797-1807) and, when dofs2mask is given,
  * MatZeroRowsColumnsIS on the Dirichlet dofs with 1.0 on their diagonal (:1822).  pattern[ntot] (optional) is
  * __create_sparsity_pattern, :1568-1632: the number of structurally visited columns of every row.
- * Neo-Hookean particles only (returns 1 otherwise). */
+ * Laws: Neo-Hookean, Hencky, Drucker-Prager (stiffness_density__Constitutive__, Constitutive.c:262-381); the
+ * Drucker-Prager branch reads the C_ep the constitutive update left in P->C_ep. */
 int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lumped_mass, const orc_particles *P,
                        const orc_mesh *M, const orc_material *mats, const int *nodes2mask, const int *dofs2mask,
                        int nactive) {
@@ -1253,7 +1302,7 @@ int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lu
   memset(K, 0, ntot * ntot * sizeof(double));
   for (int p = 0; p < P->np; p++) {
     const orc_material *mat = &mats[P->matidx[p]];
-    if (mat->type != 0) {
+    if (mat->type == ORC_MAT_DRUCKER_PRAGER && (!P->C_ep || !P->b_e_n1)) {
       STATUS = 1;
       break;
     }
@@ -1276,8 +1325,21 @@ int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lu
       for (int B = 0; B < nn; B++) {
         int Mask_node_B = nodes2mask[conn[B]];
         double Kd[9];
-        stiffness_density_neo_hookean(Kd, ndim, &dN1[A * ndim], &dN1[B * ndim], &dN[A * ndim], &dN[B * ndim],
-                                      &P->F_n[p * T], P->J_n1[p], mat);
+        if (mat->type == ORC_MAT_NEO_HOOKEAN) {
+          stiffness_density_neo_hookean(Kd, ndim, &dN1[A * ndim], &dN1[B * ndim], &dN[A * ndim], &dN[B * ndim],
+                                        &P->F_n[p * T], P->J_n1[p], mat);
+        } else if (mat->type == ORC_MAT_HENCKY) { /* Hencky.c:98-229 */
+          double Lame = mat->E * mat->nu / ((1.0 + mat->nu) * (1.0 - 2.0 * mat->nu));
+          double G = mat->E / (2.0 * (1.0 + mat->nu));
+          double AA[9], b[9];
+          for (int i = 0; i < ndim; i++)
+            for (int j = 0; j < ndim; j++) AA[i * ndim + j] = Lame + (i == j ? 2 * G : 0.0);
+          left_cauchy_green(b, &P->F_n1[p * T], ndim);
+          STATUS |= stiffness_density_spectral(Kd, ndim, &dN1[A * ndim], &dN1[B * ndim], b, AA, &P->stress[p * T]);
+        } else { /* Elastoplastic-Tangent-Matrix.c:42-163 */
+          STATUS |= stiffness_density_spectral(Kd, ndim, &dN1[A * ndim], &dN1[B * ndim], &P->b_e_n1[p * T],
+                                               &P->C_ep[p * ndim * ndim], &P->stress[p * T]);
+        }
         for (int i = 0; i < ndim; i++)
           for (int j = 0; j < ndim; j++) {
             size_t at = ((size_t)Mask_node_A * ndim + i) * ntot + (size_t)Mask_node_B * ndim + j;

@@ -391,3 +391,62 @@ def test_trial_b_e_against_the_reference_test_vector():
     rng = np.random.default_rng(2)
     F, B = rng.normal(size=(3, 3)), rng.normal(size=(3, 3))
     assert np.abs(o.trial_b_e(F.ravel(), B.ravel(), 3) - F @ B @ F.T).max() < 1e-13
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("law", ["hencky", "drucker-prager"])
+def test_spectral_tangent_against_a_second_transcription(ndim, law):
+    """The spectral stiffness density of Hencky (Hencky.c:98-229) and of the elastoplastic laws
+    (Elastoplastic-Tangent-Matrix.c:42-163) has no reference fixture, and calculus cannot pin it either: as written
+    upstream its shear-coupling terms carry a factor 1/2 on the quotient (tau_B - tau_A)/(b_B - b_A), so it is not the
+    derivative of the internal force (measured: 2-8 % off at 2 % strain, and it does not linearise to isotropic
+    elasticity).  A drop-in has to reproduce it as it is.  This test guards the C restatement against indexing
+    slips with a second, independent transcription in numpy (numpy.linalg.eigh = the same LAPACK dsyev) assembled
+    from the oracle's own grad N."""
+    o = orc()
+    mat = HENCKY if law == "hencky" else DP
+    case = (make_case(2, [9, 8], [3, 3], [3, 2], material=mat) if ndim == 2 else
+            make_case(3, [7, 7, 7], [3, 3, 3], [1, 1, 1], material=mat))
+    M, P, prm, mats = oracle_setup(case)
+    n2m, na = o.active_nodes(M)
+    ntot = na * ndim
+    rng = np.random.default_rng(3)
+    dU = (2e-2 if law == "hencky" else 8e-3) * rng.normal(size=ntot)
+    assert o.compatibility(dU, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+    K, _, st = o.tangent_matrix(P, M, mats, n2m, None, na, with_pattern=False)
+    assert st == 0
+    T = P.T
+    K2 = np.zeros((ntot, ntot))
+    E, nu = mat["E"], mat["nu"]
+    lame, G = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    for p in range(P.np):
+        nn = P["nn"][p]
+        conn = n2m[P["list"][p, :nn]]
+        dN = o.compute_dN(P, M, p)[:nn]
+        blk = lambda a: a[p, :ndim * ndim].reshape(ndim, ndim)  # noqa: E731
+        DF, tau = blk(P["DF"]), blk(P["stress"])
+        g1 = dN @ np.linalg.inv(DF)                      # rows: DF^-T grad N_A
+        if law == "hencky":
+            F1 = blk(P["F_n1"])
+            b = F1 @ F1.T
+            Cm = lame * np.ones((ndim, ndim)) + 2 * G * np.eye(ndim)
+        else:
+            b = blk(P["b_e_n1"])
+            Cm = P["C_ep"][p].reshape(ndim, ndim)
+        w, V = np.linalg.eigh(b)
+        tw = np.linalg.eigvalsh(tau)
+        for A in range(nn):
+            for B in range(nn):
+                u, v = g1[A] @ V, g1[B] @ V              # projections of dN_alpha, dN_beta on the eigenvectors
+                Kd = np.zeros((ndim, ndim))
+                for a in range(ndim):
+                    for c in range(ndim):
+                        Kd += Cm[a, c] * u[a] * v[c] * np.outer(V[:, a], V[:, c])
+                        if a != c and abs(w[c] - w[a]) > 1e-14:
+                            q = 0.5 * (tw[c] - tw[a]) / (w[c] - w[a])
+                            Kd += q * (w[c] * u[c] * v[c] * np.outer(V[:, a], V[:, a]) +
+                                       w[a] * v[a] * u[c] * np.outer(V[:, a], V[:, c]))
+                Kd -= tau @ np.outer(g1[B], g1[A])
+                ia, ib = conn[A] * ndim, conn[B] * ndim
+                K2[ia:ia + ndim, ib:ib + ndim] += Kd * P["vol0"][p]
+    assert np.abs(K - K2).max() <= 1e-9 * np.abs(K2).max()
