@@ -1,0 +1,182 @@
+/* nlps_glue.c — the reference-side binding of include/nlps_gpu.h.
+ *
+ * This file is meant to be dropped into nl-partsol/src/Formulations/Displacements/ and compiled WITH the
+ * reference (it includes the reference's own headers; nothing of them is copied here).  It marshals the
+ * reference's Particle / Mesh / Material / Boundaries structures (Types.h:14-797) into the plain-pointer
+ * structures of the C-ABI, so that U-Newmark-beta.c / U-Static.c can replace their static stage functions by
+ * the nlps_gpu_* calls listed in INTEGRATION.md.  It cannot be linked here (the reference needs PETSc and LAPACK);
+ * tests/test_abi.py::test_glue_compiles_against_the_reference_headers type-checks it against Types.h in both
+ * dimensions whenever the reference tree is present.
+ *
+ *   cc -std=gnu99 [-DUSE_PLAINSTRAIN] -I<nl-partsol>/src -I<this repo>/include -c nlps_glue.c
+ */
+#include <math.h>
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "Macros.h"
+#include "Types.h"
+#include "Globals.h"
+
+#include "nlps_gpu.h"
+
+/* law ids of the C-ABI from Material.Type, the strings of Constitutive.c:28-258 */
+static int nlps_glue_law(const Material *M) {
+  if (strcmp(M->Type, "Neo-Hookean-Wriggers") == 0) return NLPS_MAT_NEO_HOOKEAN;
+  if (strcmp(M->Type, "Hencky") == 0) return NLPS_MAT_HENCKY;
+  if (strcmp(M->Type, "Drucker-Prager") == 0) return NLPS_MAT_DRUCKER_PRAGER;
+  return -1;
+}
+
+/* The GramsBox lattice behind FEM_Mesh.Coordinates: nodes per axis and origin (x fastest numbering is checked
+ * by nlps_gpu_create against h_avg / the stencil tables). */
+static int nlps_glue_lattice(const Mesh *FEM_Mesh, nlps_grid *g) {
+  const int Ndim = NumberDimensions;
+  const int N = FEM_Mesh->NumNodesMesh;
+  const double h = FEM_Mesh->DeltaX;
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int i = 0; i < Ndim; i++) lo[i] = hi[i] = FEM_Mesh->Coordinates.nM[0][i];
+  for (int A = 1; A < N; A++)
+    for (int i = 0; i < Ndim; i++) {
+      const double x = FEM_Mesh->Coordinates.nM[A][i];
+      if (x < lo[i]) lo[i] = x;
+      if (x > hi[i]) hi[i] = x;
+    }
+  long total = 1;
+  g->ndim = Ndim;
+  g->h = h;
+  g->h_avg = FEM_Mesh->h_avg;
+  for (int i = 0; i < 3; i++) {
+    g->n[i] = i < Ndim ? (int)floor((hi[i] - lo[i]) / h + 0.5) + 1 : 1;
+    g->origin[i] = i < Ndim ? lo[i] : 0.0;
+    total *= g->n[i];
+  }
+  if (total != N) {
+    fprintf(stderr, "" RED "nlps_glue: the background mesh is not a structured lattice of spacing DeltaX" RESET "\n");
+    return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
+}
+
+/* The particle arrays the reference already owns (Matrix.nV is the contiguous row-major storage,
+ * Matlib/MatrixOp.c:128-181). */
+static nlps_particles nlps_glue_particles(Particle MPM_Mesh) {
+  nlps_particles p;
+  memset(&p, 0, sizeof p);
+  p.np = MPM_Mesh.NumGP;
+  p.x_GC = MPM_Mesh.Phi.x_GC.nV;
+  p.dis = MPM_Mesh.Phi.dis.nV;
+  p.vel = MPM_Mesh.Phi.vel.nV;
+  p.acc = MPM_Mesh.Phi.acc.nV;
+  p.F_n = MPM_Mesh.Phi.F_n.nV;
+  p.F_n1 = MPM_Mesh.Phi.F_n1.nV;
+  p.DF = MPM_Mesh.Phi.DF.nV;
+  p.Stress = MPM_Mesh.Phi.Stress.nV;
+  p.b_e_n = MPM_Mesh.Phi.b_e_n.nV;
+  p.b_e_n1 = MPM_Mesh.Phi.b_e_n1.nV;
+  p.J_n = MPM_Mesh.Phi.J_n.nV;
+  p.J_n1 = MPM_Mesh.Phi.J_n1.nV;
+  p.rho = MPM_Mesh.Phi.rho.nV;
+  p.mass = MPM_Mesh.Phi.mass.nV;
+  p.Vol_0 = MPM_Mesh.Phi.Vol_0.nV;
+  p.W = MPM_Mesh.Phi.W;
+  p.Kappa_n = MPM_Mesh.Phi.Kappa_n;
+  p.Kappa_n1 = MPM_Mesh.Phi.Kappa_n1;
+  p.EPS_n = MPM_Mesh.Phi.EPS_n;
+  p.EPS_n1 = MPM_Mesh.Phi.EPS_n1;
+  p.MatIdx = MPM_Mesh.MatIdx;
+  p.I0 = MPM_Mesh.I0;
+  p.lambda = MPM_Mesh.lambda.nV;
+  p.Beta = MPM_Mesh.Beta.nV;
+  p.dt_F_n = MPM_Mesh.Phi.dt_F_n.nV;
+  p.dt_F_n1 = MPM_Mesh.Phi.dt_F_n1.nV;
+  p.dt_DF = MPM_Mesh.Phi.dt_DF.nV;
+  p.C_ep = MPM_Mesh.Phi.C_ep.nV;
+  return p;
+}
+
+/* after initialise_shapefun__MeshTools__ (driver-nl-partsol.c:344): upload everything once */
+int nlps_glue_create(nlps_gpu **GPU, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Params Parameters_Solver) {
+  nlps_grid g;
+  if (nlps_glue_lattice(&FEM_Mesh, &g) == EXIT_FAILURE) return EXIT_FAILURE;
+  /* snapshot of the globals the level-A functions read implicitly (Globals.h:33-58) */
+  nlps_params prm = {gamma_LME, TOL_zero_LME, TOL_wrapper_LME, max_iter_LME, TOL_Radial_Returning,
+                     Max_Iterations_Radial_Returning};
+  const int Nmat = MPM_Mesh.NumberMaterials;
+  nlps_material *mats = (nlps_material *)calloc((size_t)Nmat, sizeof(nlps_material));
+  if (mats == NULL) return EXIT_FAILURE;
+  for (int m = 0; m < Nmat; m++) {
+    const Material *M = &MPM_Mesh.Mat[m];
+    const int law = nlps_glue_law(M);
+    if (law < 0) {
+      fprintf(stderr, "" RED "nlps_glue: material %s stays on the CPU path" RESET "\n", M->Type);
+      free(mats);
+      return EXIT_FAILURE;
+    }
+    mats[m].type = law;
+    mats[m].E = M->E;
+    mats[m].nu = M->nu;
+    mats[m].phi_deg = M->phi_Frictional;
+    mats[m].psi_deg = M->psi_Frictional;
+    mats[m].kappa_0 = M->kappa_0;
+    mats[m].exponent_ortiz = M->Exponent_Hardening_Ortiz;
+    mats[m].eps_0 = M->Plastic_Strain_0;
+    mats[m].p_ref = M->ReferencePressure;
+  }
+  nlps_particles p = nlps_glue_particles(MPM_Mesh);
+  const int STATUS = nlps_gpu_create(GPU, &g, &prm, mats, Nmat, &p, Parameters_Solver.NumTimeStep, NULL);
+  free(mats);
+  if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", *GPU ? nlps_gpu_last_error(*GPU) : "nlps_gpu_create");
+  return STATUS;
+}
+
+/* FEM_Mesh.Bounds (Types.h:296-351) flattened to the value[k*NumTimeStep + t] layout of nlps_bcc.
+ * The caller frees bcc[i].value and bcc. */
+nlps_bcc *nlps_glue_boundaries(Mesh FEM_Mesh, int NumTimeStep, int *nbcc) {
+  const int NumBounds = FEM_Mesh.Bounds.NumBounds;
+  nlps_bcc *bcc = (nlps_bcc *)calloc((size_t)(NumBounds > 0 ? NumBounds : 1), sizeof(nlps_bcc));
+  if (bcc == NULL) return NULL;
+  for (int i = 0; i < NumBounds; i++) {
+    const Load *L = &FEM_Mesh.Bounds.BCC_i[i];
+    double *value = (double *)calloc((size_t)L->Dim * NumTimeStep, sizeof(double));
+    if (value == NULL) return NULL;
+    for (int k = 0; k < L->Dim; k++)
+      for (int t = 0; t < NumTimeStep && t < L->Value[k].Num; t++) value[(size_t)k * NumTimeStep + t] = L->Value[k].Fx[t];
+    bcc[i].nnodes = L->NumNodes;
+    bcc[i].nodes = L->Nodes;
+    bcc[i].dim = L->Dim;
+    bcc[i].dir = L->Dir; /* Dir[k*NumTimeStep + t], Nodes-Tools.c:130 */
+    bcc[i].value = value;
+  }
+  *nbcc = NumBounds;
+  return bcc;
+}
+
+/* get_active_nodes__MeshTools__ + get_active_dofs__MeshTools__ (U-Newmark-beta.c:205-209): the Mask structures
+ * the host still needs for the PETSc sizes.  Nodes2Mask arrays are malloc'd like the reference's (caller frees). */
+int nlps_glue_masks(nlps_gpu *GPU, Mesh FEM_Mesh, const nlps_bcc *bcc, int nbcc, int TimeStep, Mask *ActiveNodes,
+                    Mask *ActiveDOFs) {
+  const int Ndim = NumberDimensions;
+  int Nactivenodes = 0, Nfree = 0;
+  ActiveNodes->Nodes2Mask = (int *)malloc((size_t)FEM_Mesh.NumNodesMesh * sizeof(int));
+  ActiveDOFs->Nodes2Mask = (int *)malloc((size_t)FEM_Mesh.NumNodesMesh * Ndim * sizeof(int));
+  if (ActiveNodes->Nodes2Mask == NULL || ActiveDOFs->Nodes2Mask == NULL) return EXIT_FAILURE;
+  if (nlps_gpu_active_masks(GPU, bcc, nbcc, TimeStep, &Nactivenodes, &Nfree, ActiveNodes->Nodes2Mask,
+                            ActiveDOFs->Nodes2Mask) != EXIT_SUCCESS) {
+    fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(GPU));
+    return EXIT_FAILURE;
+  }
+  ActiveNodes->Nactivenodes = Nactivenodes;
+  ActiveDOFs->Nactivenodes = Nfree;
+  return EXIT_SUCCESS;
+}
+
+/* before particle_results_vtk__InOutFun__ (U-Newmark-beta.c:409) or any host-side use of MPM_Mesh.Phi */
+int nlps_glue_download(nlps_gpu *GPU, Particle MPM_Mesh) {
+  nlps_particles p = nlps_glue_particles(MPM_Mesh);
+  const int STATUS = nlps_gpu_download_state(GPU, &p);
+  if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(GPU));
+  return STATUS;
+}

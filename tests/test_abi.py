@@ -58,3 +58,22 @@ def test_no_gpu_means_failure_not_fallback():
     case = make_case(2, [8, 8], [2, 2], [3, 3])
     with pytest.raises(n.NlpsError):
         n.Solver(2, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"])
+
+
+def test_glue_compiles_against_the_reference_headers():
+    """integration/nlps_glue.c is the binding a maintainer adds to the reference.  It includes the
+    reference's own Types.h / Globals.h, so wherever the reference tree is present (this container; not the GPU
+    box) it is type-checked against the real Particle / Mesh / Material / Boundaries declarations, in 2-D and 3-D."""
+    import shutil
+    import subprocess
+    import pytest
+    ref = "/root/reference/nl-partsol/src"
+    if not os.path.isdir(ref) or shutil.which("gcc") is None:
+        pytest.skip("reference tree or gcc not available here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dim in (["-DUSE_PLAINSTRAIN"], []):
+        cmd = ["gcc", "-std=gnu99", "-fsyntax-only", "-Werror=implicit-function-declaration",
+               "-Werror=incompatible-pointer-types", "-Werror=int-conversion"] + dim + \
+              ["-I" + ref, "-I" + os.path.join(root, "include"), os.path.join(root, "integration", "nlps_glue.c")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
