@@ -29,6 +29,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: these are its exports */
+#endif
 
 typedef struct nlps_gpu nlps_gpu; /* opaque: device buffers, stream, tables */
 
@@ -290,6 +293,9 @@ int nlps_host_stencil_tables(int ndim, unsigned char *rank1, unsigned char *orde
 int nlps_gpu_set_timing(nlps_gpu *h, int on);
 int nlps_gpu_get_timing(nlps_gpu *h, float ms[8]);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

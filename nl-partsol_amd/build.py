@@ -4,14 +4,17 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "nlps_gpu.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "nlps_device.hpp"), os.path.join(HERE, "csrc", "nlps_tables.hpp"),
-        os.path.join(HERE, "..", "include", "nlps_gpu.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("nlps_device.hpp", "nlps_tables.hpp", "nlps_tile_kernels.hpp",
+                                                         "nlps_tangent_kernels.hpp")] + \
+       [os.path.join(HERE, "..", "include", "nlps_gpu.h")]
 LIB = os.path.join(HERE, "csrc", "libnlps_gpu.so")
 # -ffp-contract=off: index-deciding arithmetic (closest node, cut-off radius) must round exactly like
 # the CPU path; hot loops that may fuse use explicit fma().  -munsafe-fp-atomics: hardware
-# global_atomic_add_f64 instead of a CAS loop.
+# global_atomic_add_f64 instead of a CAS loop.  -fvisibility=hidden: only the C-ABI of include/nlps_gpu.h is exported
+# (the header switches the default back on for its declarations), so the template instantiations of hipcub /
+# rocPRIM inside this library can never be interposed by another copy in the host process (torch, PETSc ...).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
-         "-munsafe-fp-atomics", "-Wall"]
+         "-munsafe-fp-atomics", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall"]
 
 
 def build(force=False):
