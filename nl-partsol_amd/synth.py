@@ -86,3 +86,10 @@ def drucker_prager_material(E=1e4, nu=0.2, kappa_0=40.0, phi_deg=39.0, psi_deg=6
     return {"type": MAT_DRUCKER_PRAGER, "E": E, "nu": nu, "phi_deg": phi_deg, "psi_deg": psi_deg,
             "kappa_0": kappa_0, "exponent_ortiz": m, "eps_0": (kappa_0 / (m * H)) * 1.0 ** (1.0 / m - 1.0),
             "p_ref": p_ref}
+
+
+def von_mises_material():
+    """J2 plasticity with combined linear isotropic / kinematic hardening plus a Voce term (Von-Mises.c:246-253);
+    the numbers are of the order of the reference's tests/Constitutive/Von-Mises.c driver (unit-free)."""
+    return {"type": 3, "E": 1.0e4, "nu": 0.3, "kappa_0": 30.0, "hardening_modulus": 400.0, "theta_voce": 0.6,
+            "K0_voce": 30.0, "Kinf_voce": 45.0, "delta_voce": 12.0}

@@ -1134,9 +1134,104 @@ static int stress_drucker_prager(int ndim, const orc_material *mat, const orc_pa
 }
 
 /* Stress_integration__Constitutive__, Constitutive/Constitutive.c:18-258 (the three laws on the path) */
+/* compute_Kirchhoff_Stress_Von_Mises__Constitutive__, Plasticity/Von-Mises.c:212-392 (helpers :396-757): J2
+ * plasticity in principal Hencky strains with combined isotropic (linear + Voce) / kinematic hardening.  The back
+ * stress (3 principal values) is updated in place like upstream.  Eigenvectors by column everywhere (upstream
+ * indexes them by row in __update_internal_variables_plastic, :673-676; the two agree for dsyev's 2x2 output and
+ * 3-D has no compilable reference). */
+static int stress_von_mises(int ndim, const orc_material *mat, const orc_params *prm, const double *d_phi,
+                            const double *b_e_n, double eps_n_in, double *back, double *T, double *W, double *b_e,
+                            double *eps_out, double *C_ep) {
+  double eigval[3] = {0, 0, 0}, eigvec[9] = {0}, btr[9] = {0};
+  orc_trial_b_e(btr, d_phi, b_e_n, ndim); /* __compute_trial_b_e :396-441 */
+  if (orc_sym_eigen(eigval, eigvec, btr, ndim)) return 1;
+  if (ndim == 2) eigval[2] = b_e_n[4];
+  double Etr[3] = {0.5 * log(eigval[0]), 0.5 * log(eigval[1]), 0.5 * log(eigval[2])};
+  double K = mat->E / (3.0 * (1.0 - 2.0 * mat->nu));
+  double G = mat->E / (2.0 * (1.0 + mat->nu));
+  double sigma_y = mat->kappa_0, H = mat->hardening_modulus, theta = mat->theta_voce;
+  double K_0 = mat->K0_voce, K_inf = mat->Kinf_voce, delta = mat->delta_voce;
+  double n[3] = {0, 0, 0}, dEp[3] = {0, 0, 0}, T_back[3] = {back[0], back[1], back[2]};
+  double kappa_n[2], kappa_k[2], d_kappa_k[2];
+  double PHI, PHI_0, d_PHI, J2, eps_n = eps_n_in, eps_k = eps_n, d_gamma_k = 0.0;
+  double TOL = prm->tol_radial_returning;
+  int MaxIter = prm->max_iter_radial_returning, Iter = 0;
+  double Tp[3], Tvol[3], Tdev[3];
+  *eps_out = eps_n_in;
+  /* __trial_elastic :495-519 */
+  double Evol = (1.0 / 3.0) * (Etr[0] + Etr[1] + Etr[2]);
+  for (int a = 0; a < 3; a++) {
+    Tvol[a] = K * Evol;
+    Tdev[a] = 2 * G * (Etr[a] - Evol) - T_back[a];
+  }
+  J2 = sqrt(Tdev[0] * Tdev[0] + Tdev[1] * Tdev[1] + Tdev[2] * Tdev[2]);
+#define VM_KAPPA(k, e)                                                                          \
+  do {                                                                                          \
+    if ((e) < 0.0) return 1;                                                                    \
+    (k)[0] = sigma_y + theta * H * (e) + (K_inf - K_0) * (1 - exp(-delta * (e))); /* :591-604 */ \
+    (k)[1] = (1 - theta) * H * (e);                                                             \
+  } while (0)
+#define VM_YIELD(kk, dg) (J2 - sqrt(2. / 3.) * ((kk)[0] + (kk)[1] - kappa_n[1]) - 2.0 * G * (dg)) /* :624-633 */
+  VM_KAPPA(kappa_n, eps_n);
+  PHI_0 = VM_YIELD(kappa_n, d_gamma_k);
+  kappa_k[0] = kappa_n[0];
+  kappa_k[1] = kappa_n[1];
+  if (PHI_0 <= 0.0) { /* elastic :283-297 */
+    for (int a = 0; a < 3; a++) Tp[a] = Tvol[a] + Tdev[a];
+    ppal_to_xyz(T, Tp, eigvec, ndim);
+  } else {
+    for (int a = 0; a < 3; a++) n[a] = Tdev[a] / J2; /* :580-587 */
+    PHI = PHI_0;
+    while (fabs(PHI / PHI_0) >= TOL) { /* :312-340 */
+      Iter++;
+      if (Iter == MaxIter) break;
+      if (eps_k < 0.0) return 1;
+      d_kappa_k[0] = theta * H + delta * (K_inf - K_0) * exp(-delta * eps_k); /* :608-620 */
+      d_kappa_k[1] = (1 - theta) * H;
+      d_PHI = -2.0 * G * (1.0 + (d_kappa_k[0] + d_kappa_k[1]) / (3 * G)); /* :637-642 */
+      d_gamma_k += -PHI / d_PHI;
+      eps_k = eps_n + sqrt(2. / 3.) * d_gamma_k;
+      VM_KAPPA(kappa_k, eps_k);
+      PHI = VM_YIELD(kappa_k, d_gamma_k);
+    }
+    double d_K_kin = kappa_k[1] - kappa_n[1];
+    for (int a = 0; a < 3; a++) Tp[a] = Tvol[a] + Tdev[a] + T_back[a] - d_gamma_k * 2 * G * n[a]; /* :646-654 */
+    *eps_out = eps_k; /* __update_internal_variables_plastic :658-713 */
+    for (int a = 0; a < 3; a++) dEp[a] = d_gamma_k * n[a];
+    ppal_to_xyz(T, Tp, eigvec, ndim);
+    for (int a = 0; a < 3; a++) back[a] += sqrt(2. / 3.) * d_K_kin * n[a];
+  }
+#undef VM_KAPPA
+#undef VM_YIELD
+  Etr[0] -= dEp[0];
+  Etr[1] -= dEp[1];
+  Etr[2] -= dEp[2];
+  { /* __corrector_b_e :444-491 */
+    double lam[3] = {exp(2 * Etr[0]), exp(2 * Etr[1]), exp(2 * Etr[2])};
+    int Tn = ndim == 2 ? 5 : 9;
+    for (int i = 0; i < Tn; i++) b_e[i] = 0.0;
+    for (int A = 0; A < ndim; A++)
+      for (int i = 0; i < ndim; i++)
+        for (int j = 0; j < ndim; j++) b_e[i * ndim + j] += lam[A] * eigvec[A + i * ndim] * eigvec[A + j * ndim];
+    if (ndim == 2) b_e[4] = lam[2];
+  }
+  if (C_ep) { /* __tangent_moduli :717-757 */
+    double th = 0.0;
+    if (J2 > TOL_NR) th = 1.0 - 2.0 * G * d_gamma_k / J2;
+    double theta_bar = 1.0 / (1.0 + (kappa_k[0] + kappa_k[1]) / (3.0 * G)) - (1.0 - th);
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++)
+        C_ep[i * ndim + j] = K * 1.0 * 1.0 + 2.0 * G * th * ((i == j ? 1.0 : 0.0) - (1.0 / 3.0) * 1.0 * 1.0) -
+                             2.0 * G * theta_bar * n[i] * n[j];
+  }
+  *W = 0.5 * (Tp[0] * Etr[0] + Tp[1] * Etr[1] + Tp[2] * Etr[2]);
+  return 0;
+}
+
 int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, const double *F_n1,
                    const double *DF, double J, const double *b_e_n, double kappa_n, double eps_n,
-                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep) {
+                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep,
+                   double *back_stress) {
   switch (mat->type) {
   case ORC_MAT_NEO_HOOKEAN:
     return stress_neo_hookean(ndim, mat, F_n1, J, stress, W);
@@ -1145,6 +1240,12 @@ int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, con
   case ORC_MAT_DRUCKER_PRAGER:
     return stress_drucker_prager(ndim, mat, prm, DF, b_e_n, kappa_n, eps_n, stress, W, b_e_n1,
                                  kappa_n1, eps_n1, C_ep);
+  case ORC_MAT_VON_MISES: { /* Constitutive.c:110-143 */
+    double zero_back[3] = {0, 0, 0};
+    *kappa_n1 = kappa_n;
+    return stress_von_mises(ndim, mat, prm, DF, b_e_n, eps_n, back_stress ? back_stress : zero_back, stress, W,
+                            b_e_n1, eps_n1, C_ep);
+  }
   default:
     return 1; /* Constitutive.c:251-256 exit()s */
   }
@@ -1162,7 +1263,8 @@ int orc_constitutive(orc_particles *P, const orc_material *mats, const orc_param
                             P->b_e_n ? &P->b_e_n[p * T] : dummyb, P->kappa_n ? P->kappa_n[p] : 0.0,
                             P->eps_n ? P->eps_n[p] : 0.0, &P->stress[p * T], &P->W[p],
                             P->b_e_n1 ? &P->b_e_n1[p * T] : dummyb, P->kappa_n1 ? &P->kappa_n1[p] : &dk,
-                            P->eps_n1 ? &P->eps_n1[p] : &de, P->C_ep ? &P->C_ep[p * P->ndim * P->ndim] : NULL);
+                            P->eps_n1 ? &P->eps_n1[p] : &de, P->C_ep ? &P->C_ep[p * P->ndim * P->ndim] : NULL,
+                            P->back_stress ? &P->back_stress[p * 3] : NULL);
     if (st) {
       if (P->status) P->status[p] |= 8;
       STATUS |= 1;

@@ -26,7 +26,7 @@ extern "C" {
 
 #define ORC_MAXNB 128 /* >= 5^3 two-ring candidates */
 
-enum { ORC_MAT_NEO_HOOKEAN = 0, ORC_MAT_HENCKY = 1, ORC_MAT_DRUCKER_PRAGER = 2 };
+enum { ORC_MAT_NEO_HOOKEAN = 0, ORC_MAT_HENCKY = 1, ORC_MAT_DRUCKER_PRAGER = 2, ORC_MAT_VON_MISES = 3 };
 
 /* Background mesh: Types.h:631-760 (only the members the path reads). */
 typedef struct {
@@ -58,6 +58,7 @@ typedef struct {
   int *list;                                            /* ListNodes as array [np][ORC_MAXNB], chain order */
   int *status;                                          /* per-particle failure flags (build's addition) */
   double *C_ep;                                         /* [np][ndim*ndim] elastoplastic tangent moduli */
+  double *back_stress;                                  /* [np][3] principal back stress (Von-Mises), in/out */
 } orc_particles;
 
 /* Material: Types.h:359-458 (members the three laws read). */
@@ -69,6 +70,9 @@ typedef struct {
   double exponent_ortiz;        /* Exponent_Hardening_Ortiz */
   double eps_0;                 /* Plastic_Strain_0 */
   double p_ref;                 /* ReferencePressure */
+  /* Von-Mises (Plasticity/Von-Mises.c:246-253): sigma_y = kappa_0 */
+  double hardening_modulus;     /* Hardening_modulus */
+  double theta_voce, K0_voce, Kinf_voce, delta_voce; /* *_Hardening_Voce */
 } orc_material;
 
 /* Globals snapshot: Globals.h:21,33-58; defaults InOutFun/Read_GramsShapeFun.c:100-104 */
@@ -122,7 +126,8 @@ int orc_compatibility(const double *dU, const double *dU_dt, orc_particles *P, c
 int orc_constitutive(orc_particles *P, const orc_material *mats, const orc_params *prm);
 int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, const double *F_n1,
                    const double *DF, double J, const double *b_e_n, double kappa_n, double eps_n,
-                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep);
+                   double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep,
+                   double *back_stress);
 int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
                         const int *dofs2mask);
 /* __compute_trial_b_e, Drucker-Prager.c:617-633 */

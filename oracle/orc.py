@@ -34,13 +34,15 @@ _PFIELDS_D = ["x", "dis", "vel", "acc", "d_dis", "F_n", "F_n1", "DF", "stress", 
 class CParticles(C.Structure):
     _fields_ = ([("np", C.c_int), ("ndim", C.c_int), ("T", C.c_int)] + [(k, _dp) for k in _PFIELDS_D] +
                 [("matidx", _ip), ("I0", _ip), ("lambda_", _dp), ("beta", _dp), ("nn", _ip), ("list", _ip),
-                 ("status", _ip), ("C_ep", _dp)])
+                 ("status", _ip), ("C_ep", _dp), ("back_stress", _dp)])
 
 
 class Material(C.Structure):
     _fields_ = [("type", C.c_int), ("E", C.c_double), ("nu", C.c_double), ("phi_deg", C.c_double),
                 ("psi_deg", C.c_double), ("kappa_0", C.c_double), ("exponent_ortiz", C.c_double),
-                ("eps_0", C.c_double), ("p_ref", C.c_double)]
+                ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
+                ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
+                ("delta_voce", C.c_double)]
 
 
 class Params(C.Structure):
@@ -164,6 +166,9 @@ class OracleParticles:
         a["list"] = np.full((n, MAXNB), -1, dtype=np.int32)
         a["status"] = np.zeros(n, dtype=np.int32)
         a["C_ep"] = np.zeros((n, d * d))
+        a["back_stress"] = np.zeros((n, 3))
+        if cloud.get("back_stress") is not None:
+            a["back_stress"][:] = cloud["back_stress"]
         for k in ("I0", "lambda_", "beta"):
             src = "lambda" if k == "lambda_" else k
             if src in cloud and cloud[src] is not None:
@@ -171,7 +176,7 @@ class OracleParticles:
         self.a = a
         c = CParticles()
         c.np, c.ndim, c.T = n, d, T
-        for k in _PFIELDS_D + ["lambda_", "beta", "C_ep"]:
+        for k in _PFIELDS_D + ["lambda_", "beta", "C_ep", "back_stress"]:
             setattr(c, k, _d(a[k]))
         for k in ["matidx", "I0", "nn", "list", "status"]:
             setattr(c, k, _i(a[k]))
@@ -190,7 +195,9 @@ def make_materials(mats):
         arr[i] = Material(int(m["type"]), float(m["E"]), float(m["nu"]), float(m.get("phi_deg", 0.0)),
                           float(m.get("psi_deg", 0.0)), float(m.get("kappa_0", 0.0)),
                           float(m.get("exponent_ortiz", 1.0)), float(m.get("eps_0", 1.0)),
-                          float(m.get("p_ref", 0.0)))
+                          float(m.get("p_ref", 0.0)), float(m.get("hardening_modulus", 0.0)),
+                          float(m.get("theta_voce", 1.0)), float(m.get("K0_voce", 0.0)),
+                          float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)))
     return arr
 
 
@@ -325,7 +332,8 @@ class ExplicitStepper:
         return self.bufs[k][: na * self.P.ndim]
 
 
-def stress_one(ndim, mat, prm, F_n1, DF, J, b_e_n, kappa_n, eps_n):
+def stress_one(ndim, mat, prm, F_n1, DF, J, b_e_n, kappa_n, eps_n, back_stress=None):
+    """back_stress: optional array of 3 (Von-Mises), updated in place"""
     T = 5 if ndim == 2 else 9
     stress = np.zeros(T)
     b1 = np.zeros(T)
@@ -334,12 +342,13 @@ def stress_one(ndim, mat, prm, F_n1, DF, J, b_e_n, kappa_n, eps_n):
     e1 = C.c_double(0)
     f = lib().orc_stress_one
     f.argtypes = [C.c_int, C.POINTER(Material), C.POINTER(Params), _dp, _dp, C.c_double, _dp, C.c_double,
-                  C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]
+                  C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     F_n1 = np.ascontiguousarray(F_n1, dtype=np.float64)
     DF = np.ascontiguousarray(DF, dtype=np.float64)
     b_e_n = np.ascontiguousarray(b_e_n, dtype=np.float64)
     st = f(ndim, C.byref(mat), C.byref(prm), _d(F_n1), _d(DF), float(J), _d(b_e_n), float(kappa_n),
-           float(eps_n), _d(stress), C.byref(W), _d(b1), C.byref(k1), C.byref(e1), None)
+           float(eps_n), _d(stress), C.byref(W), _d(b1), C.byref(k1), C.byref(e1), None,
+           _d(back_stress) if back_stress is not None else None)
     return st, stress, W.value, b1, k1.value, e1.value
 
 

@@ -450,3 +450,86 @@ def test_spectral_tangent_against_a_second_transcription(ndim, law):
                 ia, ib = conn[A] * ndim, conn[B] * ndim
                 K2[ia:ia + ndim, ib:ib + ndim] += Kd * P["vol0"][p]
     assert np.abs(K - K2).max() <= 1e-9 * np.abs(K2).max()
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_von_mises_restatement(ndim):
+    """Von-Mises.c:212-392 has a driver without expected values upstream (tests/Constitutive/Von-Mises.c); the
+    restatement is pinned by what the algorithm promises: the elastic branch is the closed form in principal Hencky
+    strains (with upstream's volumetric term K*tr(eps)/3, :495-519), a plastic step lands on the yield surface
+    |dev tau - back| = sqrt(2/3) (K_iso + dK_kin), perfect plasticity keeps |dev tau| = sqrt(2/3) sigma_y, the
+    back stress moves along the flow direction, b_e,n+1 carries exactly the elastic strain."""
+    o = orc()
+    rng = np.random.default_rng(0)
+    T = 5 if ndim == 2 else 9
+    base = synth.von_mises_material()
+    prm = o.default_params()
+    K, G = base["E"] / (3 * (1 - 2 * base["nu"])), base["E"] / (2 * (1 + base["nu"]))
+
+    def tensors(scale):
+        A = scale * rng.normal(size=(ndim, ndim))
+        DF = np.eye(ndim) + A
+        be = np.eye(ndim) + 0.2 * scale * (A + A.T)
+        d, b = np.zeros(T), np.zeros(T)
+        d[:ndim * ndim], b[:ndim * ndim] = DF.ravel(), be.ravel()
+        if ndim == 2:  # out-of-plane slots
+            d[4] = 1.0
+            b[4] = 1.01
+        return DF, be, d, b
+
+    def principal(DF, be, bzz):
+        w, V = np.linalg.eigh(DF @ be @ DF.T)
+        eps = 0.5 * np.log(np.append(w, bzz) if ndim == 2 else w)
+        return eps, V
+
+    # elastic
+    mats = o.make_materials([dict(base, kappa_0=1e9)])
+    DF, be, d, b = tensors(0.01)
+    back = np.zeros(3)
+    st, tau, W, b1, k1, e1 = o.stress_one(ndim, mats[0], prm, d, d, 1.0, b, 0.0, 0.0, back)
+    eps, V = principal(DF, be, b[T - 1])
+    tp = K * eps.sum() / 3 + 2 * G * (eps - eps.sum() / 3)
+    ref = (V * tp[:ndim]) @ V.T
+    assert st == 0 and e1 == 0.0 and np.all(back == 0.0)
+    assert np.abs(tau[:ndim * ndim].reshape(ndim, ndim) - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert abs(W - 0.5 * (tp * eps).sum()) <= 1e-12 * abs(W)
+    # plastic, combined hardening
+    mats = o.make_materials([base])
+    for trial in range(20):
+        DF, be, d, b = tensors(0.05)
+        back = 2.0 * rng.normal(size=3)
+        back -= back.mean()
+        back0, eps_n = back.copy(), 0.01 * trial
+        st, tau, W, b1, k1, e1 = o.stress_one(ndim, mats[0], prm, d, d, 1.0, b, 0.0, eps_n, back)
+        assert st == 0
+        eps, V = principal(DF, be, b[T - 1])
+        sdev = 2 * G * (eps - eps.sum() / 3) - back0
+        J2 = np.linalg.norm(sdev)
+
+        def kap(e):
+            return (base["kappa_0"] + base["theta_voce"] * base["hardening_modulus"] * e +
+                    (base["Kinf_voce"] - base["K0_voce"]) * (1 - np.exp(-base["delta_voce"] * e)),
+                    (1 - base["theta_voce"]) * base["hardening_modulus"] * e)
+        kn = kap(eps_n)
+        if J2 - np.sqrt(2 / 3) * kn[0] <= 0:
+            assert e1 == eps_n and np.array_equal(back, back0)
+            continue
+        assert e1 > eps_n
+        kk = kap(e1)
+        dg = (e1 - eps_n) / np.sqrt(2 / 3)
+        assert abs(J2 - np.sqrt(2 / 3) * (kk[0] + kk[1] - kn[1]) - 2 * G * dg) <= 1e-9 * J2  # on the yield surface
+        nflow = sdev / J2
+        assert np.abs(back - back0 - np.sqrt(2 / 3) * (kk[1] - kn[1]) * nflow).max() <= 1e-12 * max(1.0, np.abs(back).max())
+        # b_e,n+1 = exp(2 (eps_tr - dgamma n)) in the trial eigenvectors
+        e_el = eps - dg * nflow
+        bref = (V * np.exp(2 * e_el[:ndim])) @ V.T
+        assert np.abs(b1[:ndim * ndim].reshape(ndim, ndim) - bref).max() <= 1e-12 * np.abs(bref).max()
+    # perfect plasticity: the deviator stays on the cylinder of radius sqrt(2/3) sigma_y
+    mats = o.make_materials([dict(base, hardening_modulus=0.0, Kinf_voce=base["K0_voce"])])
+    DF, be, d, b = tensors(0.08)
+    back = np.zeros(3)
+    st, tau, W, b1, k1, e1 = o.stress_one(ndim, mats[0], prm, d, d, 1.0, b, 0.0, 0.0, back)
+    assert st == 0 and e1 > 0
+    tm = tau[:ndim * ndim].reshape(ndim, ndim)
+    pr = np.append(np.linalg.eigvalsh(tm), tau[4]) if ndim == 2 else np.linalg.eigvalsh(tm)
+    assert abs(np.linalg.norm(pr - pr.mean()) - np.sqrt(2 / 3) * base["kappa_0"]) <= 1e-9 * base["kappa_0"]
