@@ -41,7 +41,8 @@ typedef struct nlps_gpu nlps_gpu; /* opaque: device buffers, stream, tables */
 enum {
   NLPS_MAT_NEO_HOOKEAN = 0,   /* "Neo-Hookean-Wriggers", Hyperelastic/Neo-Hookean.c:38-85 */
   NLPS_MAT_HENCKY = 1,        /* "Hencky",               Hyperelastic/Hencky.c:40-94       */
-  NLPS_MAT_DRUCKER_PRAGER = 2 /* "Drucker-Prager",       Plasticity/Drucker-Prager.c:319-613 */
+  NLPS_MAT_DRUCKER_PRAGER = 2, /* "Drucker-Prager",      Plasticity/Drucker-Prager.c:319-613 */
+  NLPS_MAT_VON_MISES = 3       /* "Von-Mises",           Plasticity/Von-Mises.c:212-392 */
 };
 
 /* Structured background grid (GramsBox mesh, InOutFun/Read_GramsBox.c:54): Q4 / H8 lattice, nodes
@@ -72,6 +73,8 @@ typedef struct {
   double E, nu;
   double phi_deg, psi_deg; /* phi_Frictional, psi_Frictional */
   double kappa_0, exponent_ortiz, eps_0 /* Plastic_Strain_0 */, p_ref /* ReferencePressure */;
+  /* Von-Mises (Von-Mises.c:246-253): sigma_y = kappa_0, Hardening_modulus, theta / K_0 / K_inf / delta _Hardening_Voce */
+  double hardening_modulus, theta_voce, K0_voce, Kinf_voce, delta_voce;
 } nlps_material;
 
 /* Particle fields, Types.h:184-283 / 548-623: HOST pointers to the reference's row-major arrays
@@ -102,7 +105,8 @@ typedef struct {
   double *dt_F_n;       /* [np][T]  optional (0): rate of F, consumed only by the fluid law upstream */
   double *dt_F_n1;      /* [np][T]  optional */
   double *dt_DF;        /* [np][T]  optional */
-  double *C_ep;         /* [np][ndim*ndim] download only: elastoplastic tangent moduli (Drucker-Prager) */
+  double *C_ep;         /* [np][ndim*ndim] download only: elastoplastic tangent moduli (Drucker-Prager, Von-Mises) */
+  double *Back_stress;  /* [np][3] optional (0): principal back stress of Von-Mises (Phi.Back_stress), in/out */
 } nlps_particles;
 
 /* Dirichlet boundary = Load of FEM_Mesh.Bounds (Types.h:296-351), flattened:

@@ -27,6 +27,7 @@ static int nlps_glue_law(const Material *M) {
   if (strcmp(M->Type, "Neo-Hookean-Wriggers") == 0) return NLPS_MAT_NEO_HOOKEAN;
   if (strcmp(M->Type, "Hencky") == 0) return NLPS_MAT_HENCKY;
   if (strcmp(M->Type, "Drucker-Prager") == 0) return NLPS_MAT_DRUCKER_PRAGER;
+  if (strcmp(M->Type, "Von-Mises") == 0) return NLPS_MAT_VON_MISES;
   return -1;
 }
 
@@ -94,6 +95,7 @@ static nlps_particles nlps_glue_particles(Particle MPM_Mesh) {
   p.dt_F_n1 = MPM_Mesh.Phi.dt_F_n1.nV;
   p.dt_DF = MPM_Mesh.Phi.dt_DF.nV;
   p.C_ep = MPM_Mesh.Phi.C_ep.nV;
+  p.Back_stress = MPM_Mesh.Phi.Back_stress.nV;
   return p;
 }
 
@@ -124,6 +126,11 @@ int nlps_glue_create(nlps_gpu **GPU, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_
     mats[m].exponent_ortiz = M->Exponent_Hardening_Ortiz;
     mats[m].eps_0 = M->Plastic_Strain_0;
     mats[m].p_ref = M->ReferencePressure;
+    mats[m].hardening_modulus = M->Hardening_modulus;
+    mats[m].theta_voce = M->theta_Hardening_Voce;
+    mats[m].K0_voce = M->K_0_Hardening_Voce;
+    mats[m].Kinf_voce = M->K_inf_Hardening_Voce;
+    mats[m].delta_voce = M->delta_Hardening_Voce;
   }
   nlps_particles p = nlps_glue_particles(MPM_Mesh);
   const int STATUS = nlps_gpu_create(GPU, &g, &prm, mats, Nmat, &p, Parameters_Solver.NumTimeStep, NULL);

@@ -37,6 +37,7 @@ struct MatD {
   double G, lame, K;                 // shear, Lame, bulk (E/(3(1-2nu)))
   double alpha_F, alpha_Q, beta_dp;  // Drucker-Prager.c:362-375
   double kappa_0, exp_param, eps_0, p_ref;
+  double H, theta, K_0, K_inf, delta;  // Von-Mises.c:246-253 (sigma_y = kappa_0)
 };
 
 struct ParamsD {
@@ -285,6 +286,7 @@ struct StressIO {
   double be_zz;
   double kappa, eps;
   double cep[N * N];  // elastoplastic tangent moduli in principal space (Drucker-Prager.c:1088-1198)
+  double back[3];     // principal back stress (Von-Mises), in/out
   int fail;
 };
 
@@ -324,6 +326,111 @@ __device__ __forceinline__ void law_hencky(const MatD& m, const double* F, Stres
   ppal_to_xyz<N>(o.tau, Tp, v);
   o.tau_zz = Tp[2];
   o.W = 0.5 * (Tp[0] * Eh[0] + Tp[1] * Eh[1] + Tp[2] * Eh[2]);
+  if (isnan(w[0]) || isnan(w[1])) o.fail = 1;
+}
+
+// Von-Mises (J2) plasticity with combined isotropic (linear + Voce) / kinematic hardening in principal Hencky
+// strains, statement order of Von-Mises.c:212-392 (helpers :396-757); eigenvectors by column everywhere.
+template <int N>
+__device__ __forceinline__ void law_von_mises(const MatD& m, const ParamsD& prm, const double* d_phi, const double* b_e_n,
+                                              double b_e_n_zz, double eps_n, StressIO<N>& o) {
+  double btr[N * N], v[N * N], w[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; k++)
+#pragma unroll
+        for (int l = 0; l < N; l++) s += d_phi[i * N + k] * b_e_n[k * N + l] * d_phi[j * N + l];
+      btr[i * N + j] = s;
+    }
+  sym_eigen<N>(w, v, btr);
+  if (N == 2) w[2] = b_e_n_zz;
+  double Etr[3] = {0.5 * log(w[0]), 0.5 * log(w[1]), 0.5 * log(w[2])};
+  const double K = m.K, G = m.G, sigma_y = m.kappa_0, H = m.H, theta = m.theta, K_0 = m.K_0, K_inf = m.K_inf,
+               delta = m.delta;
+  double n[3] = {0, 0, 0}, dEp[3] = {0, 0, 0}, Tp[3], Tvol[3], Tdev[3];
+  double kappa_n[2], kappa_k[2], d_kappa_k[2];
+  double PHI, PHI_0, d_PHI, J2, eps_k = eps_n, d_gamma_k = 0.0;
+  const double TOL = prm.tol_radial;
+  const int MaxIter = prm.max_iter_radial;
+  int Iter = 0;
+  o.eps = eps_n;
+  const double Evol = (1.0 / 3.0) * (Etr[0] + Etr[1] + Etr[2]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    Tvol[a] = K * Evol;
+    Tdev[a] = 2 * G * (Etr[a] - Evol) - o.back[a];
+  }
+  J2 = sqrt(Tdev[0] * Tdev[0] + Tdev[1] * Tdev[1] + Tdev[2] * Tdev[2]);
+#define NLPS_VM_KAPPA(k, e)                                                         \
+  {                                                                                 \
+    if ((e) < 0.0) o.fail = 1;                                                      \
+    (k)[0] = sigma_y + theta * H * (e) + (K_inf - K_0) * (1 - exp(-delta * (e)));   \
+    (k)[1] = (1 - theta) * H * (e);                                                 \
+  }
+#define NLPS_VM_YIELD(kk, dg) (J2 - sqrt(2. / 3.) * ((kk)[0] + (kk)[1] - kappa_n[1]) - 2.0 * G * (dg))
+  NLPS_VM_KAPPA(kappa_n, eps_n);
+  PHI_0 = NLPS_VM_YIELD(kappa_n, d_gamma_k);
+  kappa_k[0] = kappa_n[0];
+  kappa_k[1] = kappa_n[1];
+  if (PHI_0 <= 0.0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) Tp[a] = Tvol[a] + Tdev[a];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; a++) n[a] = Tdev[a] / J2;
+    PHI = PHI_0;
+    while (fabs(PHI / PHI_0) >= TOL) {
+      Iter++;
+      if (Iter == MaxIter) break;
+      if (eps_k < 0.0) {
+        o.fail = 1;
+        break;
+      }
+      d_kappa_k[0] = theta * H + delta * (K_inf - K_0) * exp(-delta * eps_k);
+      d_kappa_k[1] = (1 - theta) * H;
+      d_PHI = -2.0 * G * (1.0 + (d_kappa_k[0] + d_kappa_k[1]) / (3 * G));
+      d_gamma_k += -PHI / d_PHI;
+      eps_k = eps_n + sqrt(2. / 3.) * d_gamma_k;
+      NLPS_VM_KAPPA(kappa_k, eps_k);
+      if (o.fail) break;
+      PHI = NLPS_VM_YIELD(kappa_k, d_gamma_k);
+    }
+    const double d_K_kin = kappa_k[1] - kappa_n[1];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      Tp[a] = Tvol[a] + Tdev[a] + o.back[a] - d_gamma_k * 2 * G * n[a];
+      dEp[a] = d_gamma_k * n[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) o.back[a] += sqrt(2. / 3.) * d_K_kin * n[a];
+    o.eps = eps_k;
+  }
+#undef NLPS_VM_KAPPA
+#undef NLPS_VM_YIELD
+  ppal_to_xyz<N>(o.tau, Tp, v);
+  o.tau_zz = Tp[2];
+  Etr[0] -= dEp[0];
+  Etr[1] -= dEp[1];
+  Etr[2] -= dEp[2];
+  const double lam[3] = {exp(2 * Etr[0]), exp(2 * Etr[1]), exp(2 * Etr[2])};
+  ppal_to_xyz<N>(o.be, lam, v);
+  o.be_zz = lam[2];
+  {  // __tangent_moduli :717-757
+    double th = 0.0;
+    if (J2 > NLPS_TOL_NR) th = 1.0 - 2.0 * G * d_gamma_k / J2;
+    const double theta_bar = 1.0 / (1.0 + (kappa_k[0] + kappa_k[1]) / (3.0 * G)) - (1.0 - th);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        o.cep[i * N + j] = K * 1.0 * 1.0 + 2.0 * G * th * ((i == j ? 1.0 : 0.0) - (1.0 / 3.0) * 1.0 * 1.0) -
+                           2.0 * G * theta_bar * n[i] * n[j];
+  }
+  o.W = 0.5 * (Tp[0] * Etr[0] + Tp[1] * Etr[1] + Tp[2] * Etr[2]);
   if (isnan(w[0]) || isnan(w[1])) o.fail = 1;
 }
 

@@ -46,9 +46,10 @@ enum {
   F_JN = 69, F_JN1 = 70, F_RHO = 71, F_MASS = 72, F_VOL0 = 73, F_W = 74,
   F_KN = 75, F_KN1 = 76, F_EN = 77, F_EN1 = 78, F_LAM = 79, F_BETA = 82,
   F_LAMP = 83,  // lambda of the previous step (Newton start extrapolation)
-  F_CEP = 86,   // C_ep[ndim*ndim] (Drucker-Prager tangent moduli, implicit driver only)
-  F_DTFN = 95, F_DTFN1 = 104, F_DTDF = 113,  // rate tensors (level-B compatibility with dU_dt)
-  NFD = 122
+  F_BACK = 86,  // principal back stress (Von-Mises), 3 components
+  F_CEP = 89,   // C_ep[ndim*ndim] (Drucker-Prager / Von-Mises tangent moduli, implicit driver only)
+  F_DTFN = 98, F_DTFN1 = 107, F_DTDF = 116,  // rate tensors (level-B compatibility with dU_dt)
+  NFD = 125
 };
 
 struct PView {
@@ -384,7 +385,16 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
   } else {
     double be[ND * ND], bzz;
     load_block<ND>(P, fBEN(P), p, be, bzz);
-    law_drucker_prager<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
+    if (law == NLPS_MAT_VON_MISES) {
+      o.kappa = PF(P, F_KN, p);
+#pragma unroll
+      for (int a = 0; a < 3; a++) o.back[a] = PF(P, F_BACK + a, p);
+      law_von_mises<ND>(m, prm, DF, be, bzz, PF(P, F_EN, p), o);
+#pragma unroll
+      for (int a = 0; a < 3; a++) PF(P, F_BACK + a, p) = o.back[a];  // in place, like upstream (Constitutive.c:116)
+    } else {
+      law_drucker_prager<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
+    }
     store_block<ND>(P, fBEN1(P), p, o.be, o.be_zz, true);
     PF(P, F_KN1, p) = o.kappa;
     PF(P, F_EN1, p) = o.eps;
@@ -888,6 +898,11 @@ static MatD make_mat(const nlps_material& m, int nd) {
   d.exp_param = m.exponent_ortiz;
   d.eps_0 = m.eps_0;
   d.p_ref = m.p_ref;
+  d.H = m.hardening_modulus;
+  d.theta = m.theta_voce;
+  d.K_0 = m.K0_voce;
+  d.K_inf = m.Kinf_voce;
+  d.delta = m.delta_voce;
   return d;
 }
 
@@ -1267,6 +1282,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     if (upload_field(h, F_LAM, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_BETA, 1, host->Beta, 1, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_LAMP, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_BACK, 3, host->Back_stress, 3, tmp, nullptr, 0.0)) return 1;
     if (host->dt_F_n || host->dt_F_n1 || host->dt_DF) h->level_b_fields = true;
     if (host->dt_F_n && upload_field(h, F_DTFN, T, host->dt_F_n, T, tmp, nullptr, 0.0)) return 1;
     if (host->dt_F_n1 && upload_field(h, F_DTFN1, T, host->dt_F_n1, T, tmp, nullptr, 0.0)) return 1;
@@ -1524,6 +1540,7 @@ extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
   if (download_field(h, F_DTFN1, T, o->dt_F_n1, T, tmp)) return 1;
   if (download_field(h, F_DTDF, T, o->dt_DF, T, tmp)) return 1;
   if (download_field(h, F_CEP, ND * ND, o->C_ep, ND * ND, tmp)) return 1;
+  if (download_field(h, F_BACK, 3, o->Back_stress, 3, tmp)) return 1;
   if (o->I0) {
     std::vector<int> it(np);
     HIPCHK(hipMemcpy(it.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
@@ -1989,11 +2006,13 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       if (law == 0) NLPS_K3(2, 0);
       else if (law == 1) NLPS_K3(2, 1);
       else if (law == 2) NLPS_K3(2, 2);
+      else if (law == 3) NLPS_K3(2, 3);
       else NLPS_K3(2, -1);
     } else {
       if (law == 0) NLPS_K3(3, 0);
       else if (law == 1) NLPS_K3(3, 1);
       else if (law == 2) NLPS_K3(3, 2);
+      else if (law == 3) NLPS_K3(3, 3);
       else NLPS_K3(3, -1);
     }
 #undef NLPS_K3

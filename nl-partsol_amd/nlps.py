@@ -36,7 +36,9 @@ class Params(C.Structure):
 class Material(C.Structure):
     _fields_ = [("type", C.c_int), ("E", C.c_double), ("nu", C.c_double), ("phi_deg", C.c_double),
                 ("psi_deg", C.c_double), ("kappa_0", C.c_double), ("exponent_ortiz", C.c_double),
-                ("eps_0", C.c_double), ("p_ref", C.c_double)]
+                ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
+                ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
+                ("delta_voce", C.c_double)]
 
 
 _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e_n1", "J_n", "J_n1", "rho",
@@ -46,7 +48,7 @@ _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e
 class Particles(C.Structure):
     _fields_ = ([("np", C.c_int)] + [(k, _dp) for k in _PD] +
                 [("MatIdx", _ip), ("I0", _ip), ("lambda_", _dp), ("Beta", _dp), ("dt_F_n", _dp), ("dt_F_n1", _dp),
-                 ("dt_DF", _dp), ("C_ep", _dp)])
+                 ("dt_DF", _dp), ("C_ep", _dp), ("Back_stress", _dp)])
 
 
 class Bcc(C.Structure):
@@ -213,13 +215,16 @@ class Solver:
             mats[k] = Material(int(m["type"]), float(m["E"]), float(m["nu"]), float(m.get("phi_deg", 0.0)),
                                float(m.get("psi_deg", 0.0)), float(m.get("kappa_0", 0.0)),
                                float(m.get("exponent_ortiz", 1.0)), float(m.get("eps_0", 1.0)),
-                               float(m.get("p_ref", 0.0)))
+                               float(m.get("p_ref", 0.0)), float(m.get("hardening_modulus", 0.0)),
+                               float(m.get("theta_voce", 1.0)), float(m.get("K0_voce", 0.0)),
+                               float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)))
         self._host = {}
         hp = Particles()
         hp.np = self.np
         keymap = {"x_GC": "x", "dis": "dis", "vel": "vel", "acc": "acc", "F_n": "F_n", "b_e_n": "b_e_n",
                   "J_n": "J_n", "rho": "rho", "mass": "mass", "Vol_0": "vol0", "Kappa_n": "kappa_n",
-                  "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta", "dt_F_n": "dt_F_n"}
+                  "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta", "dt_F_n": "dt_F_n",
+                  "Back_stress": "back_stress"}
         for ck, k in keymap.items():
             if k in cloud and cloud[k] is not None:
                 a = np.ascontiguousarray(cloud[k], dtype=np.float64)
@@ -330,7 +335,8 @@ class Solver:
              "rho": np.zeros(n), "mass": np.zeros(n), "Vol_0": np.zeros(n), "W": np.zeros(n),
              "Kappa_n": np.zeros(n), "Kappa_n1": np.zeros(n), "EPS_n": np.zeros(n), "EPS_n1": np.zeros(n),
              "lambda_": np.zeros((n, d)), "Beta": np.zeros(n), "dt_F_n": np.zeros((n, T)),
-             "dt_F_n1": np.zeros((n, T)), "dt_DF": np.zeros((n, T)), "C_ep": np.zeros((n, d * d))}
+             "dt_F_n1": np.zeros((n, T)), "dt_DF": np.zeros((n, T)), "C_ep": np.zeros((n, d * d)),
+             "Back_stress": np.zeros((n, 3))}
         i0 = np.zeros(n, dtype=np.int32)
         hp = Particles()
         hp.np = n

@@ -24,6 +24,7 @@ def orc():
 NH = {"type": 0, "E": 1.0e7, "nu": 0.3}
 HENCKY = {"type": 1, "E": 1.0e7, "nu": 0.3}
 DP = synth.drucker_prager_material()
+VM = synth.von_mises_material()
 
 
 def make_case(ndim, cells, lo, blk, material=NH, velocity=None, jitter=0.05, ppc=None, seed=12345, h=1.0,
