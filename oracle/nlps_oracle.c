@@ -1,7 +1,9 @@
 /*
  * nlps_oracle.c — CPU ORACLE (test infrastructure only; see nlps_oracle.h header note).
  * PARITY UNPINNED: plain-C restatement of the reference algorithm, pinned by no reference-run
- * output (the reference needs <lapacke.h>/LAPACK, absent here) — see DESIGN.md.
+ * output (the reference needs <lapacke.h>/LAPACK, absent here) — see DESIGN.md.  The two exceptions are single
+ * functions: the trial b_e (tests/Constitutive/test.py) and the spectral stiffness density, checked against the
+ * reference's own numpy script (tests/golden/ref_etm2d.npz).
  *
  * Every function cites the reference file:line (relative to /root/reference/nl-partsol/src) it
  * follows.  Loop orders, operand orders and comparison operators follow the reference so that
@@ -1385,6 +1387,13 @@ static int stiffness_density_spectral(double *Kd, int ndim, const double *dN_alp
     for (int j = 0; j < ndim; j++)
       for (int k = 0; k < ndim; k++) Kd[i * ndim + j] += -Stress[i * ndim + k] * u__o__v[k][j];
   return 0;
+}
+
+/* exported for tests/test_oracle.py: the reference's own numpy check of this density
+ * (tests/Constitutive/Elastoplastic-Tangent-Matrix.py) is held as tests/golden/ref_etm2d.npz */
+int orc_stiffness_density_spectral(double *Kd, int ndim, const double *dN_alpha_n1, const double *dN_beta_n1,
+                                   const double *b, const double *Cmod, const double *Stress) {
+  return stiffness_density_spectral(Kd, ndim, dN_alpha_n1, dN_beta_n1, b, Cmod, Stress);
 }
 
 /* __jacobian_evaluation, U-Newmark-beta.c:1646-1830, as a dense matrix K[ntot][ntot] (row-major, masked dof

@@ -361,6 +361,18 @@ def trial_b_e(d_phi, b_e_n, ndim):
     return out.reshape(ndim, ndim)
 
 
+def stiffness_density_spectral(dN_alpha_n1, dN_beta_n1, b, Cmod, stress, ndim):
+    """Elastoplastic-Tangent-Matrix.c:42-163 for one pair of nodes (row-major d x d)."""
+    out = np.zeros(ndim * ndim)
+    f = lib().orc_stiffness_density_spectral
+    f.argtypes = [_dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    f.restype = C.c_int
+    a = [np.ascontiguousarray(x, dtype=np.float64).ravel() for x in (dN_alpha_n1, dN_beta_n1, b, Cmod, stress)]
+    st = f(_d(out), ndim, *[_d(x) for x in a])
+    assert st == 0
+    return out.reshape(ndim, ndim)
+
+
 def sym_eigen(A):
     A = np.ascontiguousarray(A, dtype=np.float64)
     n = A.shape[0]

@@ -2,6 +2,8 @@
 arithmetic it restates — cross-checked against scipy's LAPACK, the same routines the reference calls
 (dsyev: nl-partsol/src/Matlib/TensorLib.c:208, Constitutive/Plasticity/Drucker-Prager.c:635;
 dgetrf/dgetri: Matlib/MatrixOp.c:341,359).  The reference itself cannot be built here."""
+import os
+
 import numpy as np
 import pytest
 from scipy.linalg import lapack
@@ -391,6 +393,26 @@ def test_trial_b_e_against_the_reference_test_vector():
     rng = np.random.default_rng(2)
     F, B = rng.normal(size=(3, 3)), rng.normal(size=(3, 3))
     assert np.abs(o.trial_b_e(F.ravel(), B.ravel(), 3) - F @ B @ F.T).max() < 1e-13
+
+
+def test_spectral_tangent_against_the_reference_python_check():
+    """tests/golden/ref_etm2d.npz holds the inputs and the A_ep of the reference's own numpy check of its
+    elastoplastic tangent (tests/Constitutive/Elastoplastic-Tangent-Matrix.py, run unmodified by
+    tests/golden/make_ref_fixtures.py; the C driver beside it, :85-175, carries the same numbers).  That check
+    covers the material part: moduli a_ep in the eigenbasis of b_e plus the (tau_B - tau_A)/(lambda_B - lambda_A)
+    terms, with v = D_phi^-T dN_alpha (the pushed-forward gradient) and u = dN_beta.  The maintained routine
+    (src/Constitutive/Plasticity/Elastoplastic-Tangent-Matrix.c:42-163) is the same sum written with the scalar
+    projections u_A, v_B, followed by the geometric term -tau (dN_beta x dN_alpha): take that term off and the
+    oracle must return the reference's matrix."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_etm2d.npz"))
+    o = orc()
+    Kd = o.stiffness_density_spectral(g["v"], g["u"], g["b_e"], g["a_ep"], g["tau"], 2)
+    geometric = -g["tau"] @ np.outer(g["u"], g["v"])
+    got = Kd - geometric
+    assert np.abs(got - g["A_ep"]).max() <= 1e-12 * np.abs(g["A_ep"]).max()
+    # the inputs of the C driver of the same test (Elastoplastic-Tangent-Matrix.c:89-98)
+    assert np.allclose(g["v"], np.linalg.inv(g["D_phi"]).T @ g["dN_alpha"], rtol=0, atol=1e-15)
+    assert np.array_equal(g["u"], g["dN_beta"])
 
 
 @pytest.mark.parametrize("ndim", [2, 3])
