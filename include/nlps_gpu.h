@@ -289,6 +289,35 @@ int nlps_gpu_download_ids(nlps_gpu *h, int *ids);
 int nlps_host_stencil_tables(int ndim, unsigned char *rank1, unsigned char *order2, unsigned char *count2,
                              double *h_avg1);
 
+/* ---- input formats: what stands on the input side of the path in the reference.
+ * GiD ASCII meshes exactly as Nodes/Read-GID-Mesh.c:225-430 reads them: line 0 "MESH dimension d ElemType T Nnode n",
+ * a Coordinates ... End Coordinates block of 4-word lines "id x y z" (also in 2-D), an Elements ... End Elements
+ * block of "id n1 .. nN" lines, 1-based.  All four return 0 or 1; nlps_host_io_last_error() holds the reason. */
+typedef struct nlps_gid_info {
+  int ndim, nnodes, nelem, nodes_per_elem;
+  char elem_type[32]; /* Triangle | Quadrilateral | Tetrahedra | Hexahedra */
+} nlps_gid_info;
+const char *nlps_host_io_last_error(void);
+/* Read_Mesh_Information, Read-GID-Mesh.c:225-300 (stricter: a malformed line inside a block is an error, where the
+ * reference would count it and leave the node unread) */
+int nlps_host_gid_mesh_info(const char *path, nlps_gid_info *info);
+/* Fill_Coordinates :304-352 and Fill_Linear_Conectivity :356-408.  coords[nnodes][ndim]; conn[nelem][nodes_per_elem]
+ * 0-based and in the order the reference's chains hold the nodes, which is the REVERSE of the file order
+ * (push__SetLib__ prepends, ChainOp.c:163-182). */
+int nlps_host_gid_mesh_read(const char *path, const nlps_gid_info *info, double *coords, int *conn);
+/* The structured lattice behind a background mesh (the GramsBox of configs 1-5): spacing, nodes per axis, origin,
+ * and canon[file node] = lattice id (x fastest), the numbering every node-indexed array of this library uses.
+ * Replaces the O(N_nodes x N_elem) neighbour construction of Read_GramsBox.c:293-456 and the element search of
+ * LME.c:63-115 by the closed-form tables of nlps_host_stencil_tables.  Fails if the nodes are not such a lattice. */
+int nlps_host_lattice_from_nodes(int ndim, int nnodes, const double *coords, double *h, int n[3], double origin[3],
+                                 int *canon);
+/* Particles of a body mesh: initial_position__Particles__ (Particles-Tools.c:8-28; Q4.c:342-452 with 1, 4, 5 or 9
+ * and H8.c:389-575 with 1, 8 or 27 particles per element) and the volumes of initialise_particles
+ * (Generate-One-Phase-Analysis.c:569-625: element volume by 2^d-point quadrature / particles per element; thickness
+ * is Thickness_Plain_Stress of the 2-D build).  x[nelem * gp][ndim], vol0[nelem * gp], particle p = e * gp + j. */
+int nlps_host_particles_from_mesh(const nlps_gid_info *info, const double *coords, const int *conn, int gp_per_elem,
+                                  double thickness, double *x, double *vol0);
+
 /* ------------------------------------------------------------------ measurement */
 
 /* Time (ms, HIP events on the handle's stream) of the kernels of the last explicit step:

@@ -4,7 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "nlps_gpu.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("nlps_device.hpp", "nlps_tables.hpp", "nlps_tile_kernels.hpp",
+IO_SRC = os.path.join(HERE, "csrc", "nlps_io.cpp")  # host-only input formats (GiD meshes, lattice, particles)
+DEPS = [SRC, IO_SRC] + [os.path.join(HERE, "csrc", f) for f in ("nlps_device.hpp", "nlps_tables.hpp", "nlps_tile_kernels.hpp",
                                                          "nlps_tangent_kernels.hpp")] + \
        [os.path.join(HERE, "..", "include", "nlps_gpu.h")]
 LIB = os.path.join(HERE, "csrc", "libnlps_gpu.so")
@@ -22,7 +23,7 @@ def build(force=False):
             os.path.getmtime(LIB) >= os.path.getmtime(d) for d in DEPS if os.path.exists(d)):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc] + FLAGS + ["-o", LIB, SRC])
+    subprocess.check_call([hipcc] + FLAGS + ["-o", LIB, SRC, IO_SRC])
     return LIB
 
 

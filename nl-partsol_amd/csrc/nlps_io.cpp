@@ -1,0 +1,315 @@
+// nlps_io.cpp — input side of the path, host only: the GiD ASCII meshes the reference reads
+// (Nodes/Read-GID-Mesh.c), the recognition of the structured GramsBox lattice behind a background mesh (what the
+// library needs instead of GramsBox's O(N_nodes x N_elem) neighbour construction, InOutFun/Read_GramsBox.c:293-456,
+// and of initialize__LME__'s element search, Nodes/LME.c:63-115), and the particles a body mesh generates
+// (InOutFun/Analysis/Generate-One-Phase-Analysis.c:569-625, Particles/Particles-Tools.c:8-28, Nodes/Q4.c:342-452,
+// Nodes/H8.c:389-575).  No GPU, no torch; entry points declared in include/nlps_gpu.h.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nlps_gpu.h"
+
+namespace {
+
+thread_local std::string io_error;
+
+int fail(const std::string& msg) {
+  io_error = msg;
+  return 1;
+}
+
+// parse(), InOutFun/Parser.c:6-40: strtok on the delimiter set of Read-GID-Mesh.c:21-31 (the _WIN32 set, a superset
+// of the __linux__ one, so that files with CR LF line ends read the same).
+int split(char* line, std::vector<char*>& words) {
+  words.clear();
+  for (char* p = strtok(line, " \r\n\t"); p; p = strtok(nullptr, " \r\n\t")) words.push_back(p);
+  return (int)words.size();
+}
+
+struct LineReader {
+  FILE* f;
+  std::vector<char> buf;
+  explicit LineReader(const char* path) : f(fopen(path, "r")), buf(1 << 16) {}
+  ~LineReader() {
+    if (f) fclose(f);
+  }
+  bool next() { return f && fgets(buf.data(), (int)buf.size(), f) != nullptr; }
+};
+
+enum Block { NONE, COORDS, ELEMS };
+
+// Block tracking shared by the three passes of the reference (Read_Mesh_Information :225-300,
+// Fill_Coordinates :304-352, Fill_Linear_Conectivity :356-408).
+Block track(Block cur, const std::vector<char*>& w) {
+  if (w.size() == 1 && !strcmp(w[0], "Coordinates")) return COORDS;
+  if (w.size() == 1 && !strcmp(w[0], "Elements")) return ELEMS;
+  if (w.size() == 2 && !strcmp(w[0], "End") && (!strcmp(w[1], "Coordinates") || !strcmp(w[1], "Elements"))) return NONE;
+  return cur;
+}
+
+// ---- reference elements -------------------------------------------------------------------------------------
+
+// N__Q4__, Nodes/Q4.c:112-124
+void shape_q4(const double* xi, double* N) {
+  N[0] = 0.25 * (1 - xi[0]) * (1 - xi[1]);
+  N[1] = 0.25 * (1 + xi[0]) * (1 - xi[1]);
+  N[2] = 0.25 * (1 + xi[0]) * (1 + xi[1]);
+  N[3] = 0.25 * (1 - xi[0]) * (1 + xi[1]);
+}
+// dN_Ref__Q4__, Nodes/Q4.c:129-155
+void dshape_q4(const double* xi, double (*dN)[3]) {
+  dN[0][0] = -0.25 * (1 - xi[1]);
+  dN[0][1] = -0.25 * (1 - xi[0]);
+  dN[1][0] = +0.25 * (1 - xi[1]);
+  dN[1][1] = -0.25 * (1 + xi[0]);
+  dN[2][0] = +0.25 * (1 + xi[1]);
+  dN[2][1] = +0.25 * (1 + xi[0]);
+  dN[3][0] = -0.25 * (1 + xi[1]);
+  dN[3][1] = +0.25 * (1 - xi[0]);
+}
+double clamp(double hi, double v) { return std::fmin(hi, std::fmax(0.0, v)); }
+// N__H8__, Nodes/H8.c:97-128 (with its DMIN/DMAX clamps)
+void shape_h8(const double* x, double* N) {
+  static const int s[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+  for (int a = 0; a < 8; a++) N[a] = 0.125 * clamp(8, (1. + s[a][0] * x[0]) * (1. + s[a][1] * x[1]) * (1. + s[a][2] * x[2]));
+}
+// dN_Ref__H8__, Nodes/H8.c:133-198
+void dshape_h8(const double* x, double (*dN)[3]) {
+  static const int s[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+  for (int a = 0; a < 8; a++) {
+    dN[a][0] = s[a][0] * 0.125 * clamp(4, (1. + s[a][1] * x[1]) * (1. + s[a][2] * x[2]));
+    dN[a][1] = s[a][1] * 0.125 * clamp(4, (1. + s[a][0] * x[0]) * (1. + s[a][2] * x[2]));
+    dN[a][2] = s[a][2] * 0.125 * clamp(4, (1. + s[a][0] * x[0]) * (1. + s[a][1] * x[1]));
+  }
+}
+
+// I3__MatrixLib__, Matlib/MatrixOp.c:290-300
+double det(const double F[3][3], int nd) {
+  if (nd == 2) return F[0][0] * F[1][1] - F[0][1] * F[1][0];
+  return F[0][0] * F[1][1] * F[2][2] - F[0][0] * F[1][2] * F[2][1] + F[0][1] * F[1][2] * F[2][0] -
+         F[0][1] * F[1][0] * F[2][2] + F[0][2] * F[1][0] * F[2][1] - F[0][2] * F[1][1] * F[2][0];
+}
+
+// volume__Q4__ (Nodes/Q4.c:493-530) / volume__H8__ (Nodes/H8.c:643-690): sum of |det F_ref| over the 2^d
+// Gauss points 0.5773502692 (the reference's 10-digit constant), unit weights; F_ref = sum_I x_I (x) dN_I
+// (F_Ref__Q4__, Q4.c:160-208).
+double element_volume(int nd, int npe, const double (*X)[3]) {
+  const double g = 0.577350269200000;
+  double vol = 0.0;
+  for (int q = 0; q < (1 << nd); q++) {
+    double xi[3] = {(q & 1) ? g : -g, (q & 2) ? g : -g, (q & 4) ? g : -g};
+    double dN[8][3];
+    if (nd == 2) dshape_q4(xi, dN);
+    else dshape_h8(xi, dN);
+    double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int I = 0; I < npe; I++)
+      for (int i = 0; i < nd; i++)
+        for (int j = 0; j < nd; j++) F[i][j] += X[I][i] * dN[I][j];
+    vol += std::fabs(det(F, nd)) * 1.0;
+  }
+  return vol;
+}
+
+// natural coordinates of the particles of one element: element_to_particles__Q4__ (Q4.c:353-416: 1, 4, 5, 9) and
+// element_to_particles__H8__ (H8.c:399-548: 1, 8, 27), with the reference's truncated constants
+bool particle_sites(int nd, int gp, std::vector<double>& xi) {
+  xi.assign((size_t)gp * 3, 0.0);
+  auto set = [&](int j, double a, double b, double c) {
+    xi[3 * j] = a;
+    xi[3 * j + 1] = b;
+    xi[3 * j + 2] = c;
+  };
+  if (nd == 2) {
+    const double s = 1. / std::sqrt(3.0), t = 0.6666666666666;
+    switch (gp) {
+      case 1: return true;
+      case 4: set(0, s, s, 0), set(1, s, -s, 0), set(2, -s, s, 0), set(3, -s, -s, 0); return true;
+      case 5: set(0, .5, .5, 0), set(1, .5, -.5, 0), set(2, -.5, .5, 0), set(3, -.5, -.5, 0), set(4, 0, 0, 0); return true;
+      case 9:
+        set(0, 0, 0, 0), set(1, t, 0, 0), set(2, t, t, 0), set(3, 0, t, 0), set(4, -t, t, 0), set(5, -t, 0, 0);
+        set(6, -t, -t, 0), set(7, 0, -t, 0), set(8, t, -t, 0);
+        return true;
+      default: return false;
+    }
+  }
+  const double t = 0.66666666666;
+  switch (gp) {
+    case 1: return true;
+    case 8:
+      set(0, -.5, -.5, .5), set(1, .5, -.5, .5), set(2, .5, .5, .5), set(3, -.5, .5, .5);
+      set(4, -.5, -.5, -.5), set(5, .5, -.5, -.5), set(6, .5, .5, -.5), set(7, -.5, .5, -.5);
+      return true;
+    case 27: {
+      static const int ring[9][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}, {-1, 1}, {-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+      static const int level[3] = {0, 1, -1};
+      for (int l = 0; l < 3; l++)
+        for (int r = 0; r < 9; r++) set(9 * l + r, ring[r][0] * t, ring[r][1] * t, level[l] * t);
+      return true;
+    }
+    default: return false;
+  }
+}
+
+}  // namespace
+
+extern "C" const char* nlps_host_io_last_error(void) { return io_error.c_str(); }
+
+extern "C" int nlps_host_gid_mesh_info(const char* path, nlps_gid_info* info) {
+  if (!path || !info) return fail("null argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  memset(info, 0, sizeof(*info));
+  std::vector<char*> w;
+  Block blk = NONE;
+  long line_no = 0;
+  while (in.next()) {
+    const int nw = split(in.buf.data(), w);
+    if (line_no == 0) {  // Read-GID-Mesh.c:254-268: exactly "MESH dimension d ElemType T Nnode n"
+      if (!(nw == 7 && !strcmp(w[0], "MESH") && !strcmp(w[1], "dimension") && !strcmp(w[3], "ElemType") &&
+            !strcmp(w[5], "Nnode")))
+        return fail("The header of a GID has a non-suported structure");
+      info->ndim = atoi(w[2]);
+      snprintf(info->elem_type, sizeof(info->elem_type), "%s", w[4]);
+      info->nodes_per_elem = atoi(w[6]);
+      if (info->ndim != 2 && info->ndim != 3) return fail("mesh dimension must be 2 or 3");
+      if (info->nodes_per_elem < 1 || info->nodes_per_elem > 27) return fail("Nnode out of range");
+    } else {
+      const Block nb = track(blk, w);
+      if (nb == blk && blk == COORDS) {
+        // the reference counts every line of the block (:272-283) but only reads those with 4 words (:334-340):
+        // anything else would leave it with uninitialised nodes, so it is refused here
+        if (nw != 4) return fail("line " + std::to_string(line_no + 1) + ": a Coordinates line needs 4 words (id x y z)");
+        info->nnodes++;
+      } else if (nb == blk && blk == ELEMS) {
+        if (nw != info->nodes_per_elem + 1)
+          return fail("line " + std::to_string(line_no + 1) + ": an Elements line needs Nnode + 1 words");
+        info->nelem++;
+      }
+      blk = nb;
+    }
+    line_no++;
+  }
+  if (line_no == 0) return fail("empty mesh file");
+  if (blk != NONE) return fail("unterminated Coordinates / Elements block");
+  return 0;
+}
+
+extern "C" int nlps_host_gid_mesh_read(const char* path, const nlps_gid_info* info, double* coords, int* conn) {
+  if (!path || !info || !coords || !conn) return fail("null argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  std::vector<char*> w;
+  Block blk = NONE;
+  int node = 0, elem = 0;
+  const int nd = info->ndim, npe = info->nodes_per_elem;
+  long line_no = 0;
+  while (in.next()) {
+    const int nw = split(in.buf.data(), w);
+    if (line_no++ == 0) continue;
+    const Block nb = track(blk, w);
+    if (nb == blk && blk == COORDS && nw == 4) {  // Fill_Coordinates :334-340: words 1..d, the id is not used
+      if (node >= info->nnodes) return fail("more nodes than nlps_host_gid_mesh_info counted");
+      for (int j = 0; j < nd; j++) coords[(size_t)node * nd + j] = atof(w[j + 1]);
+      node++;
+    } else if (nb == blk && blk == ELEMS && nw == npe + 1) {
+      // Fill_Linear_Conectivity :392-398 pushes (prepends, ChainOp.c:163-182) the nodes in file order: the chain,
+      // and with it every later walk over the element, runs in REVERSED file order
+      if (elem >= info->nelem) return fail("more elements than nlps_host_gid_mesh_info counted");
+      for (int j = 0; j < npe; j++) {
+        const int id = atoi(w[j + 1]) - 1;
+        if (id < 0 || id >= info->nnodes) return fail("element " + std::to_string(elem) + ": node id out of range");
+        conn[(size_t)elem * npe + (npe - 1 - j)] = id;
+      }
+      elem++;
+    }
+    blk = nb;
+  }
+  if (node != info->nnodes || elem != info->nelem) return fail("the file changed between info and read");
+  return 0;
+}
+
+extern "C" int nlps_host_lattice_from_nodes(int ndim, int nnodes, const double* coords, double* h_out, int n[3],
+                                            double origin[3], int* canon) {
+  if ((ndim != 2 && ndim != 3) || nnodes < (1 << ndim) || !coords || !h_out || !n || !origin)
+    return fail("bad argument");
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int a = 0; a < ndim; a++) lo[a] = hi[a] = coords[a];
+  for (int i = 1; i < nnodes; i++)
+    for (int a = 0; a < ndim; a++) {
+      const double v = coords[(size_t)i * ndim + a];
+      lo[a] = std::fmin(lo[a], v);
+      hi[a] = std::fmax(hi[a], v);
+    }
+  // spacing: distance from node 0 to its nearest node
+  double h2 = INFINITY;
+  for (int i = 1; i < nnodes; i++) {
+    double d2 = 0.0;
+    for (int a = 0; a < ndim; a++) {
+      const double d = coords[(size_t)i * ndim + a] - coords[a];
+      d2 += d * d;
+    }
+    if (d2 > 0.0 && d2 < h2) h2 = d2;
+  }
+  if (!(h2 < INFINITY)) return fail("coincident nodes");
+  const double h = std::sqrt(h2);
+  long long total = 1;
+  n[0] = n[1] = n[2] = 1;
+  origin[0] = origin[1] = origin[2] = 0.0;
+  for (int a = 0; a < ndim; a++) {
+    n[a] = (int)std::llround((hi[a] - lo[a]) / h) + 1;
+    origin[a] = lo[a];
+    total *= n[a];
+  }
+  if (total != nnodes) return fail("the background mesh is not a structured lattice of one spacing (node count)");
+  std::vector<unsigned char> seen((size_t)nnodes, 0);
+  for (int i = 0; i < nnodes; i++) {
+    long long id = 0, stride = 1;
+    for (int a = 0; a < ndim; a++) {
+      const double t = (coords[(size_t)i * ndim + a] - lo[a]) / h;
+      const long long k = std::llround(t);
+      if (std::fabs(t - (double)k) > 1e-6 || k < 0 || k >= n[a])
+        return fail("node " + std::to_string(i) + " is off the lattice");
+      id += stride * k;
+      stride *= n[a];
+    }
+    if (seen[(size_t)id]) return fail("two nodes on one lattice site");
+    seen[(size_t)id] = 1;
+    if (canon) canon[i] = (int)id;
+  }
+  *h_out = h;
+  return 0;
+}
+
+extern "C" int nlps_host_particles_from_mesh(const nlps_gid_info* info, const double* coords, const int* conn,
+                                             int gp_per_elem, double thickness, double* x, double* vol0) {
+  if (!info || !coords || !conn || !x || !vol0) return fail("null argument");
+  const int nd = info->ndim, npe = info->nodes_per_elem;
+  const bool q4 = nd == 2 && npe == 4 && !strcmp(info->elem_type, "Quadrilateral");
+  const bool h8 = nd == 3 && npe == 8 && !strcmp(info->elem_type, "Hexahedra");
+  if (!q4 && !h8) return fail("particles are generated from Quadrilateral (4) or Hexahedra (8) body meshes only");
+  std::vector<double> xi;
+  if (!particle_sites(nd, gp_per_elem, xi)) return fail("Wrong number of particles per element");
+  for (int e = 0; e < info->nelem; e++) {
+    double X[8][3];
+    for (int k = 0; k < npe; k++)
+      for (int l = 0; l < 3; l++) X[k][l] = l < nd ? coords[(size_t)conn[(size_t)e * npe + k] * nd + l] : 0.0;
+    double vol = element_volume(nd, npe, X);
+    if (nd == 2) vol *= thickness;  // Thickness_Plain_Stress, Q4.c:524
+    if (vol <= 0.0) return fail("Element with negative volume");  // Generate-One-Phase-Analysis.c:591-595
+    for (int j = 0; j < gp_per_elem; j++) {
+      double N[8];
+      if (q4) shape_q4(&xi[3 * j], N);
+      else shape_h8(&xi[3 * j], N);
+      const size_t p = (size_t)e * gp_per_elem + j;
+      for (int l = 0; l < nd; l++) x[p * nd + l] = 0.0;
+      for (int k = 0; k < npe; k++)  // Q4.c:433-442 / H8.c:560-569
+        for (int l = 0; l < nd; l++) x[p * nd + l] += N[k] * X[k][l];
+      vol0[p] = vol / gp_per_elem;  // Generate-One-Phase-Analysis.c:607-612
+    }
+  }
+  return 0;
+}

@@ -389,6 +389,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
 #pragma unroll NLPS_JUNROLL_SCATTER
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
+        if (!wave_row_used(bits)) continue;
         const double w = wz * ey5[j];
 #pragma unroll
         for (int i = 0; i < 5; i++)
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
 #pragma unroll NLPS_JUNROLL_K3
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
+        if (!wave_row_used(bits)) continue;
         double A0 = 0.0, A1 = 0.0, A2 = 0.0, R0[ND], R1[ND], V0r[ND], V1r[ND];
 #pragma unroll
         for (int a = 0; a < ND; a++) R0[a] = R1[a] = V0r[a] = V1r[a] = 0.0;
@@ -684,6 +686,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
 #pragma unroll NLPS_JUNROLL_SCATTER
         for (int j = 0; j < 5; j++) {
           const unsigned bits = (pb >> (5 * j)) & 31u;
+          if (!wave_row_used(bits)) continue;
           const double w = wz * ey5[j];
           double cr[ND];
 #pragma unroll
@@ -768,6 +771,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
 #pragma unroll NLPS_JUNROLL_K5
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
+        if (!wave_row_used(bits)) continue;
         double A0 = 0.0, R[ND];
 #pragma unroll
         for (int a = 0; a < ND; a++) R[a] = 0.0;

@@ -1,0 +1,86 @@
+"""Input side of the path: GiD meshes -> lattice + particles, through the C-ABI host helpers of
+csrc/nlps_io.cpp (no GPU needed).
+
+Mirrors what the reference does before its first step: `GramsBox (Type=GID,File=...)` reads the background mesh
+(Nodes/Read-GID-Mesh.c), `GramsSolid2D/3D (File=..., GPxElement=n)` turns every element of a body mesh into n
+particles (InOutFun/Analysis/Generate-One-Phase-Analysis.c:142-250, 569-625)."""
+import ctypes as C
+
+import numpy as np
+
+from . import nlps as _nlps
+
+
+class GidInfo(C.Structure):
+    _fields_ = [("ndim", C.c_int), ("nnodes", C.c_int), ("nelem", C.c_int), ("nodes_per_elem", C.c_int),
+                ("elem_type", C.c_char * 32)]
+
+
+def _check(st, what):
+    if st:
+        f = _nlps.lib().nlps_host_io_last_error
+        f.restype = C.c_char_p
+        raise _nlps.NlpsError("%s: %s" % (what, f().decode()))
+
+
+def read_gid_mesh(path):
+    """-> dict(ndim, elem_type, coords[nnodes][ndim], conn[nelem][npe]); conn is 0-based and in the reference's chain
+    order (the reverse of the file order, see include/nlps_gpu.h)."""
+    L = _nlps.lib()
+    info = GidInfo()
+    L.nlps_host_gid_mesh_info.argtypes = [C.c_char_p, C.POINTER(GidInfo)]
+    _check(L.nlps_host_gid_mesh_info(str(path).encode(), C.byref(info)), "nlps_host_gid_mesh_info")
+    coords = np.zeros((info.nnodes, info.ndim))
+    conn = np.zeros((info.nelem, info.nodes_per_elem), dtype=np.int32)
+    L.nlps_host_gid_mesh_read.argtypes = [C.c_char_p, C.POINTER(GidInfo), C.c_void_p, C.c_void_p]
+    _check(L.nlps_host_gid_mesh_read(str(path).encode(), C.byref(info), coords.ctypes.data_as(C.c_void_p),
+                                     conn.ctypes.data_as(C.c_void_p)), "nlps_host_gid_mesh_read")
+    return {"ndim": info.ndim, "elem_type": info.elem_type.decode(), "coords": coords, "conn": conn, "_info": info}
+
+
+def lattice_from_nodes(coords):
+    """-> (h, n[ndim], origin[ndim], canon[nnodes]): the GramsBox lattice behind the nodes; canon maps a file node
+    to the lattice numbering (x fastest) the library's node-indexed arrays use."""
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    nn, nd = coords.shape
+    h = C.c_double()
+    n = (C.c_int * 3)()
+    o = (C.c_double * 3)()
+    canon = np.zeros(nn, dtype=np.int32)
+    f = _nlps.lib().nlps_host_lattice_from_nodes
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int * 3, C.c_double * 3, C.c_void_p]
+    _check(f(nd, nn, coords.ctypes.data_as(C.c_void_p), C.byref(h), n, o, canon.ctypes.data_as(C.c_void_p)),
+           "nlps_host_lattice_from_nodes")
+    return h.value, list(n)[:nd], list(o)[:nd], canon
+
+
+def particles_from_mesh(mesh, gp_per_elem, thickness=1.0):
+    """-> (x[nelem * gp][ndim], vol0[nelem * gp]) of a Quadrilateral / Hexahedra body mesh."""
+    info = mesh["_info"]
+    npart = info.nelem * int(gp_per_elem)
+    x = np.zeros((npart, info.ndim))
+    vol0 = np.zeros(npart)
+    coords = np.ascontiguousarray(mesh["coords"], dtype=np.float64)
+    conn = np.ascontiguousarray(mesh["conn"], dtype=np.int32)
+    f = _nlps.lib().nlps_host_particles_from_mesh
+    f.argtypes = [C.POINTER(GidInfo), C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    _check(f(C.byref(info), coords.ctypes.data_as(C.c_void_p), conn.ctypes.data_as(C.c_void_p), int(gp_per_elem),
+             float(thickness), x.ctypes.data_as(C.c_void_p), vol0.ctypes.data_as(C.c_void_p)),
+           "nlps_host_particles_from_mesh")
+    return x, vol0
+
+
+def cloud_from_mesh(mesh, gp_per_elem, rho, thickness=1.0, velocity=None, matidx=0, kappa_0=0.0):
+    """The particle arrays nlps.Solver takes (the dict of synth.make_cloud) from a body mesh: positions and volumes
+    as above, mass = V rho and kappa_n = kappa_0 (Generate-One-Phase-Analysis.c:607-622), the rest at the values of
+    U-Analisys.c:33-105 (F = b_e = I, J = 1, zero fields)."""
+    from . import synth
+    x, vol0 = particles_from_mesh(mesh, gp_per_elem, thickness)
+    n, nd = x.shape
+    vel = np.zeros((n, nd))
+    if velocity is not None:
+        vel[:] = np.asarray(velocity, dtype=np.float64)
+    return {"ndim": nd, "x": x, "dis": np.zeros((n, nd)), "vel": vel, "acc": np.zeros((n, nd)),
+            "F_n": synth.identity_rows(n, nd), "b_e_n": synth.identity_rows(n, nd), "J_n": np.ones(n),
+            "rho": np.full(n, float(rho)), "mass": vol0 * float(rho), "vol0": vol0,
+            "kappa_n": np.full(n, float(kappa_0)), "eps_n": np.zeros(n), "matidx": np.full(n, int(matidx), dtype=np.int32)}

@@ -1,0 +1,197 @@
+"""Input formats: the GiD mesh reader, the lattice recognition and the particle generation of
+csrc/nlps_io.cpp against a numpy restatement of the reference's readers written here from the same file:line
+(Nodes/Read-GID-Mesh.c:225-408, Nodes/Q4.c:112-155,342-452,493-530, Nodes/H8.c:97-198,389-575,643-690,
+InOutFun/Analysis/Generate-One-Phase-Analysis.c:569-625).  Host only: runs without a GPU."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from util import nlps
+
+gid = importlib.import_module("nl-partsol_amd.gid")
+synth = importlib.import_module("nl-partsol_amd.synth")
+
+
+# ---- writer of the file format (what GiD exports with the reference's .bas template) --------------------------------
+def write_gid(path, ndim, elem_type, coords, conn, crlf=False, ids=None):
+    nl = "\r\n" if crlf else "\n"
+    with open(path, "w", newline="") as f:
+        f.write("MESH dimension %d ElemType %s Nnode %d%s" % (ndim, elem_type, conn.shape[1], nl))
+        f.write("Coordinates" + nl)
+        for i, c in enumerate(coords):
+            xyz = list(c) + [0.0] * (3 - len(c))
+            f.write("%d %.17g %.17g %.17g%s" % ((ids[i] if ids is not None else i + 1), xyz[0], xyz[1], xyz[2], nl))
+        f.write("End Coordinates" + nl + nl + "Elements" + nl)
+        for e, row in enumerate(conn):
+            f.write("%d %s%s" % (e + 1, " ".join(str(int(v) + 1) for v in row), nl))
+        f.write("End Elements" + nl)
+
+
+def lattice_mesh(ndim, cells, h=0.5, origin=None, perm=None):
+    """Nodes of a lattice (optionally renumbered by perm: file id -> lattice id) and its Q4 / H8 elements with GiD's
+    counter-clockwise (bottom face first) node order."""
+    origin = np.zeros(ndim) if origin is None else np.asarray(origin, dtype=np.float64)
+    n = [c + 1 for c in cells]
+    nn = int(np.prod(n))
+    I = np.arange(nn)
+    ijk = np.stack([I % n[0], (I // n[0]) % n[1]] + ([I // (n[0] * n[1])] if ndim == 3 else []), axis=1)
+    xyz = origin + h * ijk
+    lat2file = np.arange(nn) if perm is None else np.argsort(perm)
+    coords = np.zeros_like(xyz)
+    coords[lat2file] = xyz
+    nid = lambda *a: lat2file[a[0] + n[0] * (a[1] + (n[1] * a[2] if ndim == 3 else 0))]  # noqa: E731
+    conn = []
+    if ndim == 2:
+        for j in range(cells[1]):
+            for i in range(cells[0]):
+                conn.append([nid(i, j), nid(i + 1, j), nid(i + 1, j + 1), nid(i, j + 1)])
+    else:
+        for k in range(cells[2]):
+            for j in range(cells[1]):
+                for i in range(cells[0]):
+                    conn.append([nid(i, j, k), nid(i + 1, j, k), nid(i + 1, j + 1, k), nid(i, j + 1, k),
+                                 nid(i, j, k + 1), nid(i + 1, j, k + 1), nid(i + 1, j + 1, k + 1), nid(i, j + 1, k + 1)])
+    return coords, np.asarray(conn, dtype=np.int64), n
+
+
+# ---- numpy restatement of the reference's particle generation -------------------------------------------------------
+SIGN_H8 = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]])
+SIGN_Q4 = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]])
+
+
+def shape(xi, nd):
+    s = SIGN_Q4 if nd == 2 else SIGN_H8
+    return np.prod(1.0 + s * xi[None, :], axis=1) / (4.0 if nd == 2 else 8.0)
+
+
+def dshape(xi, nd):
+    s = SIGN_Q4 if nd == 2 else SIGN_H8
+    out = np.zeros((len(s), nd))
+    for a in range(nd):
+        others = [b for b in range(nd) if b != a]
+        out[:, a] = s[:, a] * np.prod(1.0 + s[:, others] * xi[None, others], axis=1) / (4.0 if nd == 2 else 8.0)
+    return out
+
+
+def sites(nd, gp):
+    if nd == 2:
+        s, t = 1.0 / np.sqrt(3.0), 0.6666666666666
+        return {1: [[0, 0]], 4: [[s, s], [s, -s], [-s, s], [-s, -s]],
+                5: [[.5, .5], [.5, -.5], [-.5, .5], [-.5, -.5], [0, 0]],
+                9: [[0, 0], [t, 0], [t, t], [0, t], [-t, t], [-t, 0], [-t, -t], [0, -t], [t, -t]]}[gp]
+    t = 0.66666666666
+    ring = [[0, 0], [1, 0], [1, 1], [0, 1], [-1, 1], [-1, 0], [-1, -1], [0, -1], [1, -1]]
+    return {1: [[0, 0, 0]],
+            8: [[-.5, -.5, .5], [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5], [-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5],
+                [-.5, .5, -.5]],
+            27: [[r[0] * t, r[1] * t, l * t] for l in (0, 1, -1) for r in ring]}[gp]
+
+
+def particles_numpy(coords, conn_file_order, nd, gp, thickness=1.0):
+    g = 0.577350269200000
+    x, vol = [], []
+    for row in conn_file_order:
+        X = coords[row[::-1]]  # the chain holds the nodes in reversed file order (ChainOp.c:163-182)
+        v = 0.0
+        for q in range(2 ** nd):
+            xi = np.array([g if (q >> a) & 1 else -g for a in range(nd)])
+            v += abs(np.linalg.det(X.T @ dshape(xi, nd)))
+        v *= thickness if nd == 2 else 1.0
+        for xi in sites(nd, gp):
+            x.append(shape(np.asarray(xi, dtype=np.float64), nd) @ X)
+            vol.append(v / gp)
+    return np.asarray(x), np.asarray(vol)
+
+
+# ---- tests ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ndim,cells,etype", [(2, [5, 4], "Quadrilateral"), (3, [3, 4, 2], "Hexahedra")])
+@pytest.mark.parametrize("crlf", [False, True])
+def test_reader_returns_the_file_with_reversed_element_chains(tmp_path, ndim, cells, etype, crlf):
+    coords, conn, _ = lattice_mesh(ndim, cells, h=0.25, origin=[1.0, -2.0, 0.5][:ndim])
+    path = tmp_path / "mesh.msh"
+    write_gid(path, ndim, etype, coords, conn, crlf=crlf, ids=np.arange(len(coords))[::-1] + 7)  # the id column is ignored
+    m = gid.read_gid_mesh(path)
+    assert (m["ndim"], m["elem_type"]) == (ndim, etype)
+    assert np.array_equal(m["coords"], coords)
+    assert np.array_equal(m["conn"], conn[:, ::-1])
+
+
+@pytest.mark.parametrize("ndim,cells", [(2, [6, 3]), (3, [3, 2, 4])])
+def test_lattice_recognition_and_canonical_numbering(tmp_path, ndim, cells):
+    rng = np.random.default_rng(5)
+    nn = int(np.prod([c + 1 for c in cells]))
+    perm = rng.permutation(nn)  # file node f sits on lattice site perm[f]
+    coords, conn, n = lattice_mesh(ndim, cells, h=0.125, origin=[-3.0, 2.0, 10.0][:ndim], perm=perm)
+    h, gn, origin, canon = gid.lattice_from_nodes(coords)
+    assert h == 0.125 and gn == n and origin == [-3.0, 2.0, 10.0][:ndim]
+    assert np.array_equal(canon, perm)
+    # node-indexed input in file numbering -> library numbering: a Dirichlet plane keeps its geometry
+    plane_file = np.nonzero(coords[:, ndim - 1] == origin[ndim - 1])[0]
+    assert np.array_equal(np.sort(canon[plane_file]), synth.plane_nodes(gn, ndim - 1, 0))
+
+
+def test_lattice_recognition_refuses_other_meshes():
+    coords, _, _ = lattice_mesh(2, [4, 4])
+    bent = coords.copy()
+    bent[7, 0] += 0.1
+    with pytest.raises(nlps().NlpsError, match="off the lattice"):
+        gid.lattice_from_nodes(bent)
+    with pytest.raises(nlps().NlpsError, match="node count"):
+        gid.lattice_from_nodes(coords[:-1])
+    with pytest.raises(nlps().NlpsError, match="one lattice site"):
+        gid.lattice_from_nodes(np.vstack([coords[:-1], coords[3] + 1e-9]))
+
+
+@pytest.mark.parametrize("ndim,cells,etype,gps", [(2, [4, 3], "Quadrilateral", [1, 4, 5, 9]), (3, [2, 3, 2], "Hexahedra", [1, 8, 27])])
+def test_particles_of_a_body_mesh(tmp_path, ndim, cells, etype, gps):
+    coords, conn, _ = lattice_mesh(ndim, cells, h=0.5, origin=[0.25, 1.0, -1.0][:ndim])
+    rng = np.random.default_rng(11)
+    coords = coords + rng.uniform(-0.05, 0.05, size=coords.shape)  # body meshes are not lattices: distort it
+    path = tmp_path / "body.msh"
+    write_gid(path, ndim, etype, coords, conn)
+    m = gid.read_gid_mesh(path)
+    for gp in gps:
+        x, vol0 = gid.particles_from_mesh(m, gp, thickness=2.0)
+        xr, vr = particles_numpy(m["coords"], conn, ndim, gp, thickness=2.0)
+        assert x.shape == (len(conn) * gp, ndim)
+        assert np.abs(x - xr).max() <= 4e-16 * np.abs(xr).max()
+        assert np.abs(vol0 - vr).max() <= 1e-14 * vr.max()
+    with pytest.raises(nlps().NlpsError, match="Wrong number of particles per element"):
+        gid.particles_from_mesh(m, 3)
+
+
+def test_undistorted_body_matches_the_synthetic_clouds(tmp_path):
+    """The clouds of bench.py / the parity tests (synth.make_cloud, jitter 0) are the particles the reference's
+    generator makes from a lattice-aligned body mesh: same sites, same volumes (order apart)."""
+    for ndim, cells, etype, gp in ((2, [4, 3], "Quadrilateral", 4), (3, [3, 2, 2], "Hexahedra", 8)):
+        coords, conn, _ = lattice_mesh(ndim, cells, h=0.5)
+        path = tmp_path / ("b%d.msh" % ndim)
+        write_gid(path, ndim, etype, coords, conn)
+        cloud = gid.cloud_from_mesh(gid.read_gid_mesh(path), gp, rho=1000.0)
+        ref = synth.make_cloud(ndim, cells, [0] * ndim, cells, h=0.5, jitter=0.0, ppc=gp)
+        key = lambda x: np.lexsort(np.round(x, 9).T)  # noqa: E731
+        assert np.abs(cloud["x"][key(cloud["x"])] - ref["x"][key(ref["x"])]).max() < 1e-15
+        assert np.abs(cloud["vol0"] - ref["vol0"]).max() < 1e-9 * ref["vol0"].max()  # 0.5773502692^2 vs 1/3
+        assert set(cloud) == set(ref)
+
+
+def test_reader_errors(tmp_path):
+    E = nlps().NlpsError
+    p = tmp_path / "bad.msh"
+    p.write_text("MESH dimension 2 ElemType Quadrilateral\nCoordinates\nEnd Coordinates\n")
+    with pytest.raises(E, match="non-suported structure"):
+        gid.read_gid_mesh(p)
+    p.write_text("MESH dimension 2 ElemType Quadrilateral Nnode 4\nCoordinates\n1 0.0 0.0\nEnd Coordinates\n")
+    with pytest.raises(E, match="4 words"):
+        gid.read_gid_mesh(p)
+    p.write_text("MESH dimension 2 ElemType Quadrilateral Nnode 4\nCoordinates\n1 0 0 0\nEnd Coordinates\nElements\n1 1 1 1 9\nEnd Elements\n")
+    with pytest.raises(E, match="node id out of range"):
+        gid.read_gid_mesh(p)
+    with pytest.raises(E, match="cannot open"):
+        gid.read_gid_mesh(tmp_path / "missing.msh")
+    coords, conn, _ = lattice_mesh(2, [2, 2])
+    write_gid(p, 2, "Triangle", coords, conn[:, :3])
+    with pytest.raises(E, match="Quadrilateral"):
+        gid.particles_from_mesh(gid.read_gid_mesh(p), 1)

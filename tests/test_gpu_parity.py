@@ -1176,3 +1176,52 @@ def test_maximum_size_8m_particles():
     assert S.status_flags() == 0
     nn, _ = S.download_lists()
     assert nn.min() >= 4 and nn.max() <= 125
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_run_from_gid_mesh_files(tmp_path, ndim):
+    """Input side: a background mesh file with shuffled node numbers and a distorted body mesh, read
+    by the host helpers of csrc/nlps_io.cpp, drive the HIP path; the oracle runs the same arrays.  The Dirichlet
+    nodes are given in FILE numbering and travel through the canon map of nlps_host_lattice_from_nodes."""
+    import importlib
+    import test_gid_io as tg
+    gid = importlib.import_module("nl-partsol_amd.gid")
+    o = orc()
+    n = nlps()
+    rng = np.random.default_rng(21)
+    cells = [12, 11] if ndim == 2 else [9, 9, 8]
+    nn = int(np.prod([c + 1 for c in cells]))
+    perm = rng.permutation(nn)
+    bg_coords, bg_conn, _ = tg.lattice_mesh(ndim, cells, h=1.0, perm=perm)
+    etype = "Quadrilateral" if ndim == 2 else "Hexahedra"
+    tg.write_gid(tmp_path / "box.msh", ndim, etype, bg_coords, bg_conn)
+    body_cells = [6, 5] if ndim == 2 else [3, 3, 2]
+    bc_, bconn, _ = tg.lattice_mesh(ndim, body_cells, h=1.0, origin=[3.0] * ndim)
+    bc_ = bc_ + rng.uniform(-0.08, 0.08, size=bc_.shape)
+    tg.write_gid(tmp_path / "body.msh", ndim, etype, bc_, bconn)
+
+    box = gid.read_gid_mesh(tmp_path / "box.msh")
+    h, gn, origin, canon = gid.lattice_from_nodes(box["coords"])
+    cloud = gid.cloud_from_mesh(gid.read_gid_mesh(tmp_path / "body.msh"), 4 if ndim == 2 else 8, rho=1000.0,
+                                velocity=[0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0])
+    case = {"ndim": ndim, "cells": cells, "grid_n": gn, "origin": origin, "h": h, "cloud": cloud, "materials": [NH]}
+    nsteps = 4
+    plane_file = np.nonzero(box["coords"][:, ndim - 1] == 2.0)[0]  # file numbering
+    bcs = [{"nodes": np.sort(canon[plane_file]).astype(np.int32), "dim": ndim,
+            "dir": np.ones((ndim, nsteps), dtype=np.int32), "value": np.zeros((ndim, nsteps))}]
+    assert np.array_equal(bcs[0]["nodes"], dirichlet_plane(case, ndim - 1, 2, nsteps)["nodes"])
+    dt = 0.1 * h / np.sqrt(NH["E"] / 1000.0)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs), nsteps)
+    gb = n.BccSet(bcs)
+    for t in range(nsteps):
+        assert stepper.step(t, dt) == 0
+        S.explicit_step(gb, t, dt)
+    assert S.status_flags() == 0
+    st = S.download_state()
+    nnb, lst = S.download_lists()
+    assert np.array_equal(st["I0"], P["I0"]) and np.array_equal(nnb, P["nn"]) and lists_equal(nnb, lst, P["list"])
+    for k, ok in (("x", "x"), ("vel", "vel"), ("F_n", "F_n"), ("Stress", "stress"), ("lambda", "lambda")):
+        assert_close(st[k], P[ok], 1e-9, k)
+    assert np.abs(st["Stress"]).max() > 1.0
