@@ -318,6 +318,24 @@ int nlps_host_lattice_from_nodes(int ndim, int nnodes, const double *coords, dou
 int nlps_host_particles_from_mesh(const nlps_gid_info *info, const double *coords, const int *conn, int gp_per_elem,
                                   double thickness, double *x, double *vol0);
 
+/* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
+ * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in
+ * the layout of nlps_gpu_download_state ([np][ndim], tensors [np][5 | 9]); a NULL array leaves its block out, like
+ * the reference's Out_* switches.  flags add the blocks that derive from shared arrays. */
+typedef struct nlps_vtk_fields {
+  const double *x;            /* POINTS (required); X_GC with NLPS_VTK_X_GC */
+  const double *mass, *rho;   /* MASS, DENSITY */
+  const int *I0, *matidx;     /* ELEM_i, MatIdx */
+  const double *vel, *acc, *dis; /* VELOCITY, ACCELERATION, DISPLACEMENT */
+  const double *stress;       /* STRESS (2-D: zz from slot 4); P with NLPS_VTK_P */
+  const double *F_n;          /* DEFORMATION-GRADIENT */
+  const double *W;            /* Energy-Potential + Energy-Kinetic with NLPS_VTK_ENERGY (needs vel, mass) */
+  const double *eps;          /* EPS */
+} nlps_vtk_fields;
+enum { NLPS_VTK_X_GC = 1, NLPS_VTK_P = 2, NLPS_VTK_ENERGY = 4 };
+int nlps_host_write_particles_vtk(const char *path, int results_time_step, int ndim, int np,
+                                  const nlps_vtk_fields *fields, int flags);
+
 /* ------------------------------------------------------------------ measurement */
 
 /* Time (ms, HIP events on the handle's stream) of the kernels of the last explicit step:

@@ -313,3 +313,102 @@ extern "C" int nlps_host_particles_from_mesh(const nlps_gid_info* info, const do
   }
   return 0;
 }
+
+// ---- output side: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266), legacy
+// ASCII VTK with every number as %.20g, one vertex cell per particle.  Blocks appear in the reference's order; a block
+// whose array is NULL (or whose flag is off) is left out, as with the reference's Out_* switches.
+namespace {
+void vtk_vectors(FILE* f, const char* name, const double* v, int np, int nd) {  // vtk_Out_vel & co., :516-566
+  fprintf(f, "VECTORS %s double \n", name);
+  for (int i = 0; i < np; i++) {
+    for (int j = 0; j < 3; j++) fprintf(f, "%.20g ", j < nd ? v[(size_t)i * nd + j] : 0.0);
+    fprintf(f, "\n");
+  }
+}
+void vtk_scalars(FILE* f, const char* name, const double* v, int np) {  // vtk_Out_mass & co., :466-481
+  fprintf(f, "SCALARS %s double \n", name);
+  fprintf(f, "LOOKUP_TABLE default \n");
+  for (int i = 0; i < np; i++) fprintf(f, "%.20g \n", v[i]);
+}
+void vtk_integers(FILE* f, const char* name, const int* v, int np) {  // vtk_Out_nodal_idx, :496-512
+  fprintf(f, "SCALARS %s integer \n", name);
+  fprintf(f, "LOOKUP_TABLE default \n");
+  for (int i = 0; i < np; i++) fprintf(f, "%i \n", v[i]);
+}
+// vtk_Out_Stress (:570-590, the 2-D build puts the out-of-plane component, slot 4, at zz) and
+// vtk_Out_Deformation_Gradient (:662-680, zeros outside the d x d block)
+void vtk_tensors(FILE* f, const char* name, const double* t, int np, int nd, bool zz_from_slot4) {
+  const int T = nd == 2 ? 5 : 9;
+  fprintf(f, "TENSORS %s double \n", name);
+  for (int i = 0; i < np; i++) {
+    for (int j = 0; j < 3; j++) {
+      for (int k = 0; k < 3; k++) {
+        double v = 0.0;
+        if (j < nd && k < nd) v = t[(size_t)i * T + j * nd + k];
+        else if (zz_from_slot4 && j == 2 && k == 2) v = t[(size_t)i * T + 4];
+        fprintf(f, "%.20g ", v);
+      }
+      fprintf(f, "\n");
+    }
+    fprintf(f, "\n");
+  }
+}
+}  // namespace
+
+extern "C" int nlps_host_write_particles_vtk(const char* path, int results_time_step, int ndim, int np,
+                                             const nlps_vtk_fields* a, int flags) {
+  if (!path || !a || !a->x || (ndim != 2 && ndim != 3) || np < 0) return fail("bad argument");
+  FILE* f = fopen(path, "w");
+  if (!f) return fail(std::string("cannot open ") + path);
+  fprintf(f, "# vtk DataFile Version 3.0 \n");
+  fprintf(f, "Results time step %i \n", results_time_step);
+  fprintf(f, "ASCII \n");
+  fprintf(f, "DATASET UNSTRUCTURED_GRID \n");
+  fprintf(f, "POINTS %i double \n", np);
+  for (int i = 0; i < np; i++) {
+    for (int j = 0; j < 3; j++) fprintf(f, "%.20g ", j < ndim ? a->x[(size_t)i * ndim + j] : 0.0);
+    fprintf(f, "\n");
+  }
+  fprintf(f, "CELLS %i %i \n", np, 2 * np);
+  for (int i = 0; i < np; i++) fprintf(f, "%i %i \n", 1, i);
+  fprintf(f, "CELL_TYPES %i \n", np);
+  for (int i = 0; i < np; i++) fprintf(f, "%i \n", 1);
+  fprintf(f, "POINT_DATA %i \n", np);
+  if (flags & NLPS_VTK_X_GC) vtk_vectors(f, "X_GC", a->x, np, ndim);
+  fprintf(f, "CELL_DATA %i \n", np);
+  if (a->mass) vtk_scalars(f, "MASS", a->mass, np);
+  if (a->rho) vtk_scalars(f, "DENSITY", a->rho, np);
+  if (a->I0) vtk_integers(f, "ELEM_i", a->I0, np);
+  if (a->matidx) vtk_integers(f, "MatIdx", a->matidx, np);
+  if (a->vel) vtk_vectors(f, "VELOCITY", a->vel, np, ndim);
+  if (a->acc) vtk_vectors(f, "ACCELERATION", a->acc, np, ndim);
+  if (a->dis) vtk_vectors(f, "DISPLACEMENT", a->dis, np, ndim);
+  if (a->stress) vtk_tensors(f, "STRESS", a->stress, np, ndim, true);
+  if (a->stress && (flags & NLPS_VTK_P)) {  // vtk_Out_Stress_P, :594-612
+    const int T = ndim == 2 ? 5 : 9;
+    fprintf(f, "SCALARS P double \n");
+    fprintf(f, "LOOKUP_TABLE default \n");
+    for (int i = 0; i < np; i++) {
+      const double* s = a->stress + (size_t)i * T;
+      const double p = ndim == 2 ? (1.0 / 3.0) * (s[0] + s[3] + s[4]) : (1.0 / 3.0) * (s[0] + s[4] + s[8]);
+      fprintf(f, "%.20g \n", p);
+    }
+  }
+  if (a->F_n) vtk_tensors(f, "DEFORMATION-GRADIENT", a->F_n, np, ndim, false);
+  if ((flags & NLPS_VTK_ENERGY) && a->W && a->vel && a->mass) {  // :816-843
+    vtk_scalars(f, "Energy-Potential", a->W, np);
+    fprintf(f, "SCALARS Energy-Kinetic double \n");
+    fprintf(f, "LOOKUP_TABLE default \n");
+    for (int i = 0; i < np; i++) {
+      double K = 0;
+      for (int j = 0; j < ndim; j++) {
+        const double v = a->vel[(size_t)i * ndim + j];
+        K += (v == 0.0 ? 0.0 : v * v);  // DSQR, Macros.h:49-50
+      }
+      fprintf(f, "%.20g \n", 0.5 * K * a->mass[i]);
+    }
+  }
+  if (a->eps) vtk_scalars(f, "EPS", a->eps, np);
+  if (fclose(f)) return fail(std::string("write error on ") + path);
+  return 0;
+}

@@ -84,3 +84,35 @@ def cloud_from_mesh(mesh, gp_per_elem, rho, thickness=1.0, velocity=None, matidx
             "F_n": synth.identity_rows(n, nd), "b_e_n": synth.identity_rows(n, nd), "J_n": np.ones(n),
             "rho": np.full(n, float(rho)), "mass": vol0 * float(rho), "vol0": vol0,
             "kappa_n": np.full(n, float(kappa_0)), "eps_n": np.zeros(n), "matidx": np.full(n, int(matidx), dtype=np.int32)}
+
+
+class VtkFields(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x", "mass", "rho", "I0", "matidx", "vel", "acc", "dis", "stress", "F_n", "W",
+                                          "eps")]
+
+
+VTK_X_GC, VTK_P, VTK_ENERGY = 1, 2, 4
+
+
+def write_particles_vtk(path, results_time_step, state, flags=0):
+    """The particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266) from a dict in the
+    layout of Solver.download_state(): keys x (required), mass, rho, I0, matidx, vel, acc, dis, Stress, F_n, W, EPS_n;
+    missing keys leave their block out."""
+    x = np.ascontiguousarray(state["x"], dtype=np.float64)
+    npart, nd = x.shape
+    keep = [x]
+    f = VtkFields()
+    f.x = x.ctypes.data
+    for field, key, dt in (("mass", "mass", np.float64), ("rho", "rho", np.float64), ("I0", "I0", np.int32),
+                           ("matidx", "matidx", np.int32), ("vel", "vel", np.float64), ("acc", "acc", np.float64),
+                           ("dis", "dis", np.float64), ("stress", "Stress", np.float64), ("F_n", "F_n", np.float64),
+                           ("W", "W", np.float64), ("eps", "EPS_n", np.float64)):
+        if state.get(key) is not None:
+            a = np.ascontiguousarray(state[key], dtype=dt)
+            assert a.shape[0] == npart, key
+            keep.append(a)
+            setattr(f, field, a.ctypes.data)
+    fn = _nlps.lib().nlps_host_write_particles_vtk
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(VtkFields), C.c_int]
+    _check(fn(str(path).encode(), int(results_time_step), nd, npart, C.byref(f), int(flags)),
+           "nlps_host_write_particles_vtk")

@@ -195,3 +195,82 @@ def test_reader_errors(tmp_path):
     write_gid(p, 2, "Triangle", coords, conn[:, :3])
     with pytest.raises(E, match="Quadrilateral"):
         gid.particles_from_mesh(gid.read_gid_mesh(p), 1)
+
+
+# ---- output side: the particle VTK file ---------------------------------------------------------------------------
+def vtk_text(step, st, nd, flags):
+    """The file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266, field writers :430-860)
+    written out again from its format strings."""
+    n = len(st["x"])
+    T = 5 if nd == 2 else 9
+    g = lambda v: "%.20g" % v  # noqa: E731
+    vec = lambda name, a: ["VECTORS %s double " % name] + [  # noqa: E731
+        "".join(g(r[j] if j < nd else 0.0) + " " for j in range(3)) for r in a]
+    sca = lambda name, a: ["SCALARS %s double " % name, "LOOKUP_TABLE default "] + [g(v) + " " for v in a]  # noqa: E731
+    integ = lambda name, a: ["SCALARS %s integer " % name, "LOOKUP_TABLE default "] + ["%i " % v for v in a]  # noqa: E731
+
+    def ten(name, a, zz):
+        out = ["TENSORS %s double " % name]
+        for r in a:
+            for j in range(3):
+                row = ""
+                for k in range(3):
+                    v = r[j * nd + k] if (j < nd and k < nd) else (r[4] if (zz and j == 2 and k == 2) else 0.0)
+                    row += g(v) + " "
+                out.append(row)
+            out.append("")
+        return out
+
+    L = ["# vtk DataFile Version 3.0 ", "Results time step %i " % step, "ASCII ", "DATASET UNSTRUCTURED_GRID ",
+         "POINTS %i double " % n]
+    L += ["".join(g(r[j] if j < nd else 0.0) + " " for j in range(3)) for r in st["x"]]
+    L += ["CELLS %i %i " % (n, 2 * n)] + ["1 %i " % i for i in range(n)]
+    L += ["CELL_TYPES %i " % n] + ["1 "] * n
+    L += ["POINT_DATA %i " % n]
+    if flags & 1:
+        L += vec("X_GC", st["x"])
+    L += ["CELL_DATA %i " % n]
+    L += sca("MASS", st["mass"]) + sca("DENSITY", st["rho"]) + integ("ELEM_i", st["I0"]) + integ("MatIdx", st["matidx"])
+    L += vec("VELOCITY", st["vel"]) + vec("ACCELERATION", st["acc"]) + vec("DISPLACEMENT", st["dis"])
+    L += ten("STRESS", st["Stress"], True)
+    if flags & 2:
+        tr = st["Stress"][:, [0, 3, 4]] if nd == 2 else st["Stress"][:, [0, 4, 8]]
+        L += sca("P", [(1.0 / 3.0) * ((r[0] + r[1]) + r[2]) for r in tr])
+    L += ten("DEFORMATION-GRADIENT", st["F_n"], False)
+    if flags & 4:
+        L += sca("Energy-Potential", st["W"])
+        ke = []
+        for v, m in zip(st["vel"], st["mass"]):
+            K = 0.0
+            for j in range(nd):
+                K += v[j] * v[j]
+            ke.append(0.5 * K * m)
+        L += sca("Energy-Kinetic", ke)
+    L += sca("EPS", st["EPS_n"])
+    assert T == st["Stress"].shape[1]
+    return "\n".join(L) + "\n"
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_particle_vtk_file_is_byte_identical_to_the_reference_format(tmp_path, ndim):
+    rng = np.random.default_rng(3)
+    n, T = 7, (5 if ndim == 2 else 9)
+    st = {"x": rng.normal(size=(n, ndim)), "mass": rng.uniform(1, 2, n), "rho": rng.uniform(900, 1100, n),
+          "I0": rng.integers(0, 99, n).astype(np.int32), "matidx": np.zeros(n, dtype=np.int32),
+          "vel": rng.normal(size=(n, ndim)), "acc": rng.normal(size=(n, ndim)), "dis": rng.normal(size=(n, ndim)) * 1e-3,
+          "Stress": rng.normal(size=(n, T)) * 1e5, "F_n": rng.normal(size=(n, T)), "W": rng.uniform(0, 1, n),
+          "EPS_n": rng.uniform(0, 1e-3, n)}
+    st["vel"][2] = 0.0  # DSQR's zero branch
+    for flags in (0, 7):
+        p = tmp_path / ("particles_%d.vtk" % flags)
+        gid.write_particles_vtk(p, 40, st, flags)
+        assert p.read_text() == vtk_text(40, st, ndim, flags)
+    # numbers survive the round trip exactly (%.20g)
+    body = (tmp_path / "particles_7.vtk").read_text().split("\n")
+    at = body.index("POINTS %d double " % n)
+    back = np.array([[float(v) for v in body[at + 1 + i].split()] for i in range(n)])
+    assert np.array_equal(back[:, :ndim], st["x"])
+    # a partial state writes a valid, shorter file
+    gid.write_particles_vtk(tmp_path / "min.vtk", 0, {"x": st["x"], "vel": st["vel"]})
+    txt = (tmp_path / "min.vtk").read_text()
+    assert "VECTORS VELOCITY double" in txt and "STRESS" not in txt
