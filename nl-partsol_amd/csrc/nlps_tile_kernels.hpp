@@ -452,11 +452,11 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
     int node = window_node<ND>(g, w0, idx, in);
     duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
     duxy[2 * idx + 1] = in ? N.dU[(size_t)node * ND + 1] : 0.0;
-    if (ND == 3) duz[idx % ((ND == 3) ? NW : 1)] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
+    if (ND == 3) duz[(ND == 3) ? idx : 0] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
     if (RATES) {
-      dvxy[(2 * idx) % (RATES ? 2 * NW : 2)] = in ? dVgrid[(size_t)node * ND + 0] : 0.0;
-      dvxy[(2 * idx + 1) % (RATES ? 2 * NW : 2)] = in ? dVgrid[(size_t)node * ND + 1] : 0.0;
-      if (ND == 3) dvz[idx % ((RATES && ND == 3) ? NW : 1)] = in ? dVgrid[(size_t)node * ND + (2 % ND)] : 0.0;
+      dvxy[RATES ? 2 * idx : 0] = in ? dVgrid[(size_t)node * ND + 0] : 0.0;
+      dvxy[RATES ? 2 * idx + 1 : 1] = in ? dVgrid[(size_t)node * ND + 1] : 0.0;
+      if (ND == 3) dvz[(RATES && ND == 3) ? idx : 0] = in ? dVgrid[(size_t)node * ND + (2 % ND)] : 0.0;
     }
 #pragma unroll
     for (int a = 0; a < ND; a++) fac[a * NW + idx] = 0.0;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
           A1 += m1;
           A2 = fma(m1, c.lx[i], A2);
           const double2 u01 = du2[li];
-          const double u2 = (ND == 3) ? duz[li % ((ND == 3) ? NW : 1)] : 0.0;
+          const double u2 = (ND == 3) ? duz[(ND == 3) ? li : 0] : 0.0;
           const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
           for (int a = 0; a < ND; a++) {
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
             R1[a] = fma(m1, uu[a], R1[a]);
           }
           if (RATES) {
-            const double2 v01 = dv2[li % (RATES ? NW : 1)];
-            const double v2 = (ND == 3) ? dvz[li % ((RATES && ND == 3) ? NW : 1)] : 0.0;
+            const double2 v01 = dv2[RATES ? li : 0];
+            const double v2 = (ND == 3) ? dvz[(RATES && ND == 3) ? li : 0] : 0.0;
             const double vv[3] = {v01.x, v01.y, v2};
 #pragma unroll
             for (int a = 0; a < ND; a++) {
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
     int node = window_node<ND>(g, w0, idx, in);
     axy[2 * idx] = in ? N.accel[(size_t)node * ND + 0] : 0.0;
     axy[2 * idx + 1] = in ? N.accel[(size_t)node * ND + 1] : 0.0;
-    if (ND == 3) az[idx % ((ND == 3) ? NW : 1)] = in ? N.accel[(size_t)node * ND + (2 % ND)] : 0.0;
+    if (ND == 3) az[(ND == 3) ? idx : 0] = in ? N.accel[(size_t)node * ND + (2 % ND)] : 0.0;
   }
   __syncthreads();
   const double2* a2 = reinterpret_cast<const double2*>(axy);
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
           const double2 v01 = a2[li];
           R[0] = fma(m0, v01.x, R[0]);
           R[1] = fma(m0, v01.y, R[1]);
-          if (ND == 3) R[2 % ND] = fma(m0, az[li % ((ND == 3) ? NW : 1)], R[2 % ND]);
+          if (ND == 3) R[2 % ND] = fma(m0, az[(ND == 3) ? li : 0], R[2 % ND]);
         }
         const double w = ey5[j] * z0;
         Z = fma(w, A0, Z);
