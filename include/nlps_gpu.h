@@ -340,7 +340,8 @@ int nlps_host_write_particles_vtk(const char *path, int results_time_step, int n
 
 /* Time (ms, HIP events on the handle's stream) of the kernels of the last explicit step:
  * [0] search+activate, [1] lists+Newton+P2G mass/momentum, [2] G2P grad+F+stress+P2G force,
- * [3] G2P kinematics+roll, [4] nodal/mask kernels.  Enabled with nlps_gpu_set_timing(h,1). */
+ * [3] G2P kinematics+roll, [4] nodal/mask kernels, [5] a calibration bracket around a kernel of K3's grid that
+ * does nothing (the part of a one-kernel bracket that is not kernel time).  Enabled with nlps_gpu_set_timing(h,1). */
 int nlps_gpu_set_timing(nlps_gpu *h, int on);
 int nlps_gpu_get_timing(nlps_gpu *h, float ms[8]);
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarises the SQ counter passes of a bench.py run (rocprofv3 --kernel-trace --pmc <three counters>, one directory
+per pass under gpurun_out/prof_sq) into profiles/<tag>_sq_counters.md:  tools/summarize_sq.py gpurun_out/prof_sq r01"""
+import csv
+import glob
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = ["k_search", "k2_tile", "k3_tile", "k5_tile"]
+WAVES = 1000000 / 64.0  # particle-waves of the bench workload
+val, dur = {}, {}
+for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        for k in KERNELS:
+            if r["Kernel_Name"].startswith("void %s<3" % k) and "false" not in r["Kernel_Name"]:
+                # the last launch of every kernel wins (rows are in dispatch order)
+                val[(k, r["Counter_Name"])] = float(r["Counter_Value"])
+                dur[(k, r["Counter_Name"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+rows = []
+for k in KERNELS:
+    g = lambda c: val.get((k, c), float("nan"))  # noqa: E731
+    busy = g("SQ_ACTIVE_INST_VALU") / (1024 * dur[(k, "SQ_ACTIVE_INST_VALU")] * 2.4 / 4.0)
+    conf = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else 0.0
+    rows.append("| %s | %.0f | %.0f | %.0f | %.0f %% | %.0f %% |" % (k, g("SQ_INSTS_VALU") / WAVES, g("SQ_INSTS_LDS") / WAVES,
+                                                                 g("SQ_INSTS_SALU") / WAVES, 100 * busy, 100 * conf))
+text = """# SQ counters per launch (%s), bench.py at 1 M particles, Neo-Hookean
+
+Separate `rocprofv3 --kernel-trace --pmc ...` passes (three counters each), last launch of every kernel.  `VALU busy` =
+SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x kernel duration x 2.4 GHz / 4); instructions per particle-wave =
+counter / 15 625 waves of 64 particles (one wave instruction serves 64 particles).  Made by tools/summarize_sq.py.
+
+| kernel | VALU instr / particle-wave | LDS instr | SALU instr | VALU busy | LDS bank-conflict / active cycles |
+|---|---|---|---|---|---|
+%s
+""" % (tag, "\n".join(rows))
+open(os.path.join(ROOT, "profiles", "%s_sq_counters.md" % tag), "w").write(text)
+print(text)
