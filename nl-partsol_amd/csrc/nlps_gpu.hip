@@ -742,6 +742,17 @@ __global__ void k_copy(T* __restrict__ out, const T* __restrict__ in, int n) {
   if (i < n) out[i] = in[i];
 }
 
+// all particle fields of the re-sort in one launch: thread = new slot, blockIdx.y = group of GATHER_FIELDS fields
+static constexpr int GATHER_FIELDS = 8;
+__global__ void k_gather_fields(double* __restrict__ out, const double* __restrict__ in, const int* __restrict__ idx,
+                                int n, size_t npad, int nf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t j = (size_t)idx[i];
+  const int f0 = blockIdx.y * GATHER_FIELDS, f1 = min(nf, f0 + GATHER_FIELDS);
+  for (int f = f0; f < f1; f++) out[(size_t)f * npad + i] = in[(size_t)f * npad + j];
+}
+
 template <class T>
 __global__ void k_gather(T* __restrict__ out, const T* __restrict__ in, const int* __restrict__ idx, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -815,7 +826,8 @@ struct nlps_gpu {
   int *sval_d, *sval2_d;
   void* cub_tmp;
   size_t cub_tmp_bytes;
-  double* gather_tmp;     // [npad] scratch for the field-by-field gather
+  double* gather_tmp;     // [npad] scratch for the gather of the integer arrays
+  double* Pd_alt = nullptr;  // twin of P.d, target of the re-sort (allocated at the first one)
 
   // per-step tile binning
   int nt[3], ntiles;
@@ -1334,11 +1346,15 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr) {
   const int* idx = h->sval2_d;  // new slot -> old slot
   const size_t npad = h->P.npad;
   const int nf = h->level_b_fields ? (int)NFD : (int)F_CEP;  // C_ep and the rate tensors only exist for level B
-  for (int f = 0; f < nf; f++) {
-    double* fld = h->P.d + (size_t)f * npad;
-    hipLaunchKernelGGL(k_gather<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->gather_tmp, fld, idx, np);
-    hipLaunchKernelGGL(k_copy<double>, dim3(nblk(np)), dim3(BLK), 0, h->stream, fld, (const double*)h->gather_tmp, np);
+  // the field block moves into its twin in one launch and the two swap roles (no copy back; the twin costs a second
+  // NFD x npad block of HBM, allocated at the first re-sort)
+  if (!h->Pd_alt) {
+    HIPCHK(hipMalloc((void**)&h->Pd_alt, (size_t)NFD * npad * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->Pd_alt, 0, (size_t)NFD * npad * sizeof(double), h->stream));
   }
+  hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (nf + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
+                     h->Pd_alt, (const double*)h->P.d, idx, np, npad, nf);
+  std::swap(h->P.d, h->Pd_alt);
   int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
   for (int* a : iarr) {
     hipLaunchKernelGGL(k_gather<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (int*)h->gather_tmp, a, idx, np);
@@ -1480,7 +1496,7 @@ extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
 extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   if (!h) return 0;
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->P.d, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
+  void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
