@@ -335,6 +335,12 @@ typedef struct nlps_vtk_fields {
 enum { NLPS_VTK_X_GC = 1, NLPS_VTK_P = 2, NLPS_VTK_ENERGY = 4 };
 int nlps_host_write_particles_vtk(const char *path, int results_time_step, int ndim, int np,
                                   const nlps_vtk_fields *fields, int flags);
+/* The nodal file of nodal_results_vtk__InOutFun__ (WriteVtk.c:269-405): the background mesh in file numbering (info,
+ * coords, conn as read by nlps_host_gid_mesh_read), the active-node mask and the reactions.  active[nnodes] and
+ * reactions[nnodes][ndim] are the library's lattice-numbered arrays (nlps_gpu_download_active,
+ * nlps_gpu_explicit_nodal); canon[file node] = lattice node, NULL = identity. */
+int nlps_host_write_nodes_vtk(const char *path, const nlps_gid_info *info, const double *coords, const int *conn,
+                              const int *canon, const unsigned char *active, const double *reactions);
 
 /* ------------------------------------------------------------------ measurement */
 

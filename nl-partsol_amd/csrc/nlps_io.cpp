@@ -412,3 +412,50 @@ extern "C" int nlps_host_write_particles_vtk(const char* path, int results_time_
   if (fclose(f)) return fail(std::string("write error on ") + path);
   return 0;
 }
+
+// The nodal file of nodal_results_vtk__InOutFun__ (WriteVtk.c:269-405): mesh in FILE numbering (coordinates as %f,
+// cells with their chains, cell types only for triangles (5) and quadrilaterals (9) as in the reference), the
+// active-node mask and the reactions (%.20g; an inactive node writes "0 0 0 " with the reference's trailing blank).
+// active / reactions are the library's lattice-numbered arrays (nlps_gpu_download_active, nlps_gpu_explicit_nodal);
+// canon[file node] = lattice node (nlps_host_lattice_from_nodes), NULL = identity.
+extern "C" int nlps_host_write_nodes_vtk(const char* path, const nlps_gid_info* info, const double* coords,
+                                         const int* conn, const int* canon, const unsigned char* active,
+                                         const double* reactions) {
+  if (!path || !info || !coords || !conn || !active || !reactions) return fail("null argument");
+  FILE* f = fopen(path, "w");
+  if (!f) return fail(std::string("cannot open ") + path);
+  const int nd = info->ndim, nn = info->nnodes, ne = info->nelem, npe = info->nodes_per_elem;
+  fprintf(f, "# vtk DataFile Version 3.0 \n");
+  fprintf(f, "vtk output \n");
+  fprintf(f, "ASCII \n");
+  fprintf(f, "DATASET UNSTRUCTURED_GRID \n");
+  fprintf(f, "POINTS %i float \n", nn);
+  for (int i = 0; i < nn; i++)
+    fprintf(f, "%f %f %f\n", coords[(size_t)i * nd], coords[(size_t)i * nd + 1], nd == 3 ? coords[(size_t)i * nd + 2] : 0.0);
+  fprintf(f, "\n");
+  fprintf(f, "CELLS %i %i \n", ne, ne + ne * npe);
+  for (int e = 0; e < ne; e++) {
+    fprintf(f, "%i", npe);
+    for (int k = 0; k < npe; k++) fprintf(f, " %i", conn[(size_t)e * npe + k]);
+    fprintf(f, "\n");
+  }
+  fprintf(f, "\n");
+  fprintf(f, "CELL_TYPES %i \n", ne);
+  const int type = (!strcmp(info->elem_type, "Triangle") && npe == 3) ? 5
+                   : (!strcmp(info->elem_type, "Quadrilateral") && npe == 4) ? 9 : 0;
+  if (type)
+    for (int e = 0; e < ne; e++) fprintf(f, "%i \n", type);
+  fprintf(f, "\n");
+  fprintf(f, "POINT_DATA %i \n", nn);
+  fprintf(f, "SCALARS Mask int \n");
+  fprintf(f, "LOOKUP_TABLE default \n");
+  for (int i = 0; i < nn; i++) fprintf(f, "%i\n", active[canon ? canon[i] : i] ? 1 : 0);
+  fprintf(f, "VECTORS %s float \n", "REACTIONS");
+  for (int i = 0; i < nn; i++) {
+    const size_t a = (size_t)(canon ? canon[i] : i);
+    if (active[a]) fprintf(f, "%.20g %.20g %.20g\n", reactions[a * nd], reactions[a * nd + 1], nd == 3 ? reactions[a * nd + 2] : 0.0);
+    else fprintf(f, "%.20g %.20g %.20g \n", 0.0, 0.0, 0.0);
+  }
+  if (fclose(f)) return fail(std::string("write error on ") + path);
+  return 0;
+}

@@ -116,3 +116,19 @@ def write_particles_vtk(path, results_time_step, state, flags=0):
     fn.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(VtkFields), C.c_int]
     _check(fn(str(path).encode(), int(results_time_step), nd, npart, C.byref(f), int(flags)),
            "nlps_host_write_particles_vtk")
+
+
+def write_nodes_vtk(path, mesh, canon, active, reactions):
+    """The nodal file of nodal_results_vtk__InOutFun__ (WriteVtk.c:269-405): mesh (read_gid_mesh) in file numbering,
+    active[nnodes] / reactions[nnodes][ndim] in the library's lattice numbering, canon from lattice_from_nodes (or None)."""
+    info = mesh["_info"]
+    coords = np.ascontiguousarray(mesh["coords"], dtype=np.float64)
+    conn = np.ascontiguousarray(mesh["conn"], dtype=np.int32)
+    act = np.ascontiguousarray(active, dtype=np.uint8)
+    rea = np.ascontiguousarray(reactions, dtype=np.float64)
+    assert act.shape[0] == info.nnodes and rea.shape == (info.nnodes, info.ndim)
+    cn = None if canon is None else np.ascontiguousarray(canon, dtype=np.int32)
+    f = _nlps.lib().nlps_host_write_nodes_vtk
+    f.argtypes = [C.c_char_p, C.POINTER(GidInfo)] + [C.c_void_p] * 5
+    _check(f(str(path).encode(), C.byref(info), coords.ctypes.data, conn.ctypes.data, None if cn is None else cn.ctypes.data,
+             act.ctypes.data, rea.ctypes.data), "nlps_host_write_nodes_vtk")

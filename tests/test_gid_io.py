@@ -274,3 +274,34 @@ def test_particle_vtk_file_is_byte_identical_to_the_reference_format(tmp_path, n
     gid.write_particles_vtk(tmp_path / "min.vtk", 0, {"x": st["x"], "vel": st["vel"]})
     txt = (tmp_path / "min.vtk").read_text()
     assert "VECTORS VELOCITY double" in txt and "STRESS" not in txt
+
+
+@pytest.mark.parametrize("ndim,cells,etype", [(2, [3, 2], "Quadrilateral"), (3, [2, 2, 2], "Hexahedra")])
+def test_nodal_vtk_file(tmp_path, ndim, cells, etype):
+    """nodal_results_vtk__InOutFun__ (WriteVtk.c:269-405) from its format strings: %f coordinates, the cells as their
+    chains, cell types for quadrilaterals only (hexahedra get none in the reference), Mask, REACTIONS with the trailing
+    blank on inactive nodes; node-indexed arrays travel from lattice to file numbering through canon."""
+    rng = np.random.default_rng(8)
+    nn = int(np.prod([c + 1 for c in cells]))
+    perm = rng.permutation(nn)
+    coords, conn, _ = lattice_mesh(ndim, cells, h=0.5, perm=perm)
+    write_gid(tmp_path / "box.msh", ndim, etype, coords, conn)
+    m = gid.read_gid_mesh(tmp_path / "box.msh")
+    _, _, _, canon = gid.lattice_from_nodes(m["coords"])
+    active = (rng.uniform(size=nn) < 0.6).astype(np.uint8)  # lattice numbering
+    rea = rng.normal(size=(nn, ndim)) * 1e3
+    gid.write_nodes_vtk(tmp_path / "nodes.vtk", m, canon, active, rea)
+    L = ["# vtk DataFile Version 3.0 ", "vtk output ", "ASCII ", "DATASET UNSTRUCTURED_GRID ", "POINTS %i float " % nn]
+    L += ["%f %f %f" % (c[0], c[1], c[2] if ndim == 3 else 0.0) for c in m["coords"]] + [""]
+    npe = conn.shape[1]
+    L += ["CELLS %i %i " % (len(conn), len(conn) * (npe + 1))]
+    L += ["%i " % npe + " ".join("%i" % v for v in row) for row in m["conn"]] + [""]
+    L += ["CELL_TYPES %i " % len(conn)] + (["9 "] * len(conn) if ndim == 2 else []) + [""]
+    L += ["POINT_DATA %i " % nn, "SCALARS Mask int ", "LOOKUP_TABLE default "]
+    L += ["%i" % active[canon[i]] for i in range(nn)]
+    L += ["VECTORS REACTIONS float "]
+    for i in range(nn):
+        a = canon[i]
+        r = list(rea[a]) + [0.0] * (3 - ndim)
+        L.append(("%.20g %.20g %.20g" % tuple(r)) if active[a] else "0 0 0 ")
+    assert (tmp_path / "nodes.vtk").read_text() == "\n".join(L) + "\n"
