@@ -26,7 +26,8 @@ int fail(const std::string& msg) {
 // of the __linux__ one, so that files with CR LF line ends read the same).
 int split(char* line, std::vector<char*>& words) {
   words.clear();
-  for (char* p = strtok(line, " \r\n\t"); p; p = strtok(nullptr, " \r\n\t")) words.push_back(p);
+  char* save = nullptr;  // strtok_r: the error string is per thread, the tokenizer state has to be as well
+  for (char* p = strtok_r(line, " \r\n\t", &save); p; p = strtok_r(nullptr, " \r\n\t", &save)) words.push_back(p);
   return (int)words.size();
 }
 
