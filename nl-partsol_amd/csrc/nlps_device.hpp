@@ -80,6 +80,26 @@ struct ParamsD {
 #ifndef NLPS_K2_WAVES_2D
 #define NLPS_K2_WAVES_2D 3
 #endif
+// plane loops (k): 1 = real loop (compact code; ez5[k], lz5[k] and the plane bits are selected at run time),
+// 5 = unrolled
+#ifndef NLPS_KUNROLL_MASK
+#define NLPS_KUNROLL_MASK 5  // K2 -2 %; the others measured: K2 scatter / K3 scatter +-1 %, K5 +14 %, K3 gather and the moments spill
+#endif
+#ifndef NLPS_KUNROLL_K2S
+#define NLPS_KUNROLL_K2S 1
+#endif
+#ifndef NLPS_KUNROLL_K3G
+#define NLPS_KUNROLL_K3G 1
+#endif
+#ifndef NLPS_KUNROLL_K3S
+#define NLPS_KUNROLL_K3S 1
+#endif
+#ifndef NLPS_KUNROLL_K5
+#define NLPS_KUNROLL_K5 1
+#endif
+#ifndef NLPS_KUNROLL_MOM
+#define NLPS_KUNROLL_MOM 1
+#endif
 #ifndef NLPS_JUNROLL_MASK
 #define NLPS_JUNROLL_MASK 5  // neighbourhood-mask rows unrolled: no run-time index into ly2[] (8 selects per row); K2 0.294 -> 0.282 ms
 #endif
@@ -765,7 +785,7 @@ __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, do
   (void)lz5;
   double M0 = 0.0, M1x = 0.0, M1y = 0.0, M1z = 0.0, M2xx = 0.0, M2xy = 0.0, M2xz = 0.0, M2yy = 0.0, M2yz = 0.0, M2zz = 0.0;
   // real (not unrolled) plane loop, unrolled rows: compact code, short live ranges
-#pragma unroll 1
+#pragma unroll NLPS_KUNROLL_MOM
   for (int k = 0; k < Lme<ND>::KN; k++) {
     const unsigned pb = plane_bits<ND>(c, k);
     double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;

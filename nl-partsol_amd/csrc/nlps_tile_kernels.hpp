@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
       if (ND == 3) lz2[i] = c.lz[i % KN] * c.lz[i % KN];
     }
     u64 mlo = 0ull, mhi = 0ull;
-#pragma unroll 1
+#pragma unroll NLPS_KUNROLL_MASK
     for (int k = 0; k < KN; k++) {
       const double lz2k = (ND == 3) ? lz2[k] : 0.0;
       unsigned pbits = 0u;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
     }
     const double mz = PF(P, F_MASS, p) * Zinv;
     NLPS_YZ_LOCALS(c);
-#pragma unroll 1
+#pragma unroll NLPS_KUNROLL_K2S
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const double wz = mz * ez5[k];
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
     for (int a = 0; a < ND * ND; a++) G[a] = 0.0;
 #pragma unroll
     for (int a = 0; a < (RATES ? ND * ND : 1); a++) Gv[a] = 0.0;
-#pragma unroll 1
+#pragma unroll NLPS_KUNROLL_K3G
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
     PH(11)
     if (fo_ok) {
       // pass 2: -f_A = p_A * (B l_A), B l = B[.][x] lx_i + (B[.][y] ly_j + B[.][z] lz_k)
-#pragma unroll 1
+#pragma unroll NLPS_KUNROLL_K3S
       for (int k = 0; k < KN; k++) {
         const unsigned pb = plane_bits<ND>(c, k);
         const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
     double Z = 0.0, sv[ND];
 #pragma unroll
     for (int a = 0; a < ND; a++) sv[a] = 0.0;
-#pragma unroll 1
+#pragma unroll NLPS_KUNROLL_K5
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
