@@ -478,8 +478,11 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
     double Z = 0.0, rx = 0.0, ry = 0.0, rz = 0.0, Jxx = 0.0, Jxy = 0.0, Jxz = 0.0, Jyy = 0.0, Jyz = 0.0, Jzz = 0.0;
     double G[ND * ND], Gv[RATES ? ND * ND : 1];
     double U[ND];  // sum e dU: the value gather of U-Verlet.c:962-1010, by-product of the gradient rows
+    double Uv[RATES ? ND : 1];
 #pragma unroll
     for (int a = 0; a < ND; a++) U[a] = 0.0;
+#pragma unroll
+    for (int a = 0; a < (RATES ? ND : 1); a++) Uv[a] = 0.0;
 #pragma unroll
     for (int a = 0; a < ND * ND; a++) G[a] = 0.0;
 #pragma unroll
@@ -497,23 +500,25 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
         if (!wave_row_used(bits)) continue;
-        double A0 = 0.0, A1 = 0.0, A2 = 0.0, R0[ND], R1[ND], V0r[ND], V1r[ND];
+        // INDEX space (as lme_moments_h): with l_x(i) = a_x - h (i - 2) the row weights are the integers
+        // u = i - 2 in {-2..2}: no l arrays live in the loop, u = 0 terms vanish, +-1 are sign modifiers.
+        double m[5], R0[ND], R1[ND], V0r[ND], V1r[ND];
 #pragma unroll
         for (int a = 0; a < ND; a++) R0[a] = R1[a] = V0r[a] = V1r[a] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
+        for (int i = 0; i < 5; i++) m[i] = masked_weight(c.ex[i], bits, i);  // non-members weigh 0
+        const double w0 = -2.0 * m[0], w4 = 2.0 * m[4];
+        const double mu[5] = {w0, -m[1], 0.0, m[3], w4};  // u_i m_i
+#pragma unroll
+        for (int i = 0; i < 5; i++) {  // branch-free (the window slot of a non-member exists)
           const int li = basek + (i - 2) + W * (j - 2);
-          const double m0 = masked_weight(c.ex[i], bits, i), m1 = m0 * c.lx[i];
-          A0 += m0;
-          A1 += m1;
-          A2 = fma(m1, c.lx[i], A2);
           const double2 u01 = du2[li];
           const double u2 = (ND == 3) ? duz[(ND == 3) ? li : 0] : 0.0;
           const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
           for (int a = 0; a < ND; a++) {
-            R0[a] = fma(m0, uu[a], R0[a]);
-            R1[a] = fma(m1, uu[a], R1[a]);
+            R0[a] = fma(m[i], uu[a], R0[a]);
+            if (i != 2) R1[a] = fma(mu[i], uu[a], R1[a]);
           }
           if (RATES) {
             const double2 v01 = dv2[RATES ? li : 0];
@@ -521,12 +526,17 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
             const double vv[3] = {v01.x, v01.y, v2};
 #pragma unroll
             for (int a = 0; a < ND; a++) {
-              V0r[a] = fma(m0, vv[a], V0r[a]);
-              V1r[a] = fma(m1, vv[a], V1r[a]);
+              V0r[a] = fma(m[i], vv[a], V0r[a]);
+              if (i != 2) V1r[a] = fma(mu[i], vv[a], V1r[a]);
             }
           }
         }
-        const double y0 = ey5[j], y1 = y0 * ly5[j], y2 = y1 * ly5[j];
+        const double s13 = m[1] + m[3], s04 = m[0] + m[4];
+        const double A0 = m[2] + s13 + s04;                    // sum e
+        const double A1 = (m[3] - m[1]) + (w4 + w0);           // sum e u
+        const double A2 = fma(4.0, s04, s13);                  // sum e u^2
+        const double cj = (double)(j - 2);
+        const double y0 = ey5[j], y1 = y0 * cj, y2 = y1 * cj;
         P00 = fma(y0, A0, P00);
         P10 = fma(y0, A1, P10);
         P20 = fma(y0, A2, P20);
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
         }
       }
       if (ND == 3) {
-        const double z0 = ez5[k], lzk = lz5[k], z1 = z0 * lzk, z2 = z1 * lzk;
+        const double z0 = ez5[k], ck = (double)(k - 2), z1 = z0 * ck, z2 = z1 * ck;
         Z = fma(z0, P00, Z);
         rx = fma(z0, P10, rx);
         ry = fma(z0, P01, ry);
@@ -562,7 +572,8 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
           G[a * ND + 0] = fma(z0, Gx[a], G[a * ND + 0]);
           G[a * ND + 1] = fma(z0, Gy[a], G[a * ND + 1]);
           G[a * ND + (2 % ND)] = fma(z1, Gz[a], G[a * ND + (2 % ND)]);
-          if (MODE == 1) U[a] = fma(z0, Gz[a], U[a]);
+          U[a] = fma(z0, Gz[a], U[a]);
+          if (RATES) Uv[a % (RATES ? ND : 1)] = fma(z0, Hz[a], Uv[a % (RATES ? ND : 1)]);
           if (RATES) {
             Gv[(a * ND + 0) % (RATES ? ND * ND : 1)] = fma(z0, Hx[a], Gv[(a * ND + 0) % (RATES ? ND * ND : 1)]);
             Gv[(a * ND + 1) % (RATES ? ND * ND : 1)] = fma(z0, Hy[a], Gv[(a * ND + 1) % (RATES ? ND * ND : 1)]);
@@ -580,7 +591,8 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
         for (int a = 0; a < ND; a++) {
           G[a * ND + 0] = Gx[a];
           G[a * ND + 1] = Gy[a];
-          if (MODE == 1) U[a] = Gz[a];
+          U[a] = Gz[a];
+          if (RATES) Uv[a % (RATES ? ND : 1)] = Hz[a];
           if (RATES) {
             Gv[(a * ND + 0) % (RATES ? ND * ND : 1)] = Hx[a];
             Gv[(a * ND + 1) % (RATES ? ND * ND : 1)] = Hy[a];
@@ -590,22 +602,36 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
     }
     PH(10)
     const double Zinv = 1.0 / Z;
+    // index moments -> moments of l = a - h u (a = l of the centre node): J = h^2 (<u u> - <u><u>), the a-terms cancel;
+    // G[a][m] = sum e dU_a l_m = a_m sum e dU_a - h sum e dU_a u_m
+    const double hx = c.lx[2] - c.lx[3];
+    const double al[3] = {c.lx[2], c.ly[2], (ND == 3) ? c.lz[2 % KN] : 0.0};
     rx *= Zinv;
     ry *= Zinv;
     rz *= Zinv;
     double J[ND * ND], Jm1[ND * ND];
+    const double h2 = hx * hx;
     if (ND == 2) {
-      J[0] = Jxx * Zinv - rx * rx;
-      J[1] = J[2] = Jxy * Zinv - rx * ry;
-      J[3] = Jyy * Zinv - ry * ry;
+      J[0] = h2 * (Jxx * Zinv - rx * rx);
+      J[1] = J[2] = h2 * (Jxy * Zinv - rx * ry);
+      J[3] = h2 * (Jyy * Zinv - ry * ry);
     } else {
-      J[0] = Jxx * Zinv - rx * rx;
-      J[1] = J[3 % (ND * ND)] = Jxy * Zinv - rx * ry;
-      J[2] = J[6 % (ND * ND)] = Jxz * Zinv - rx * rz;
-      J[4 % (ND * ND)] = Jyy * Zinv - ry * ry;
-      J[5 % (ND * ND)] = J[7 % (ND * ND)] = Jyz * Zinv - ry * rz;
-      J[8 % (ND * ND)] = Jzz * Zinv - rz * rz;
+      J[0] = h2 * (Jxx * Zinv - rx * rx);
+      J[1] = J[3 % (ND * ND)] = h2 * (Jxy * Zinv - rx * ry);
+      J[2] = J[6 % (ND * ND)] = h2 * (Jxz * Zinv - rx * rz);
+      J[4 % (ND * ND)] = h2 * (Jyy * Zinv - ry * ry);
+      J[5 % (ND * ND)] = J[7 % (ND * ND)] = h2 * (Jyz * Zinv - ry * rz);
+      J[8 % (ND * ND)] = h2 * (Jzz * Zinv - rz * rz);
     }
+#pragma unroll
+    for (int a = 0; a < ND; a++)
+#pragma unroll
+      for (int mm = 0; mm < ND; mm++) {
+        G[a * ND + mm] = fma(al[mm], U[a], -hx * G[a * ND + mm]);
+        if (RATES)
+          Gv[(a * ND + mm) % (RATES ? ND * ND : 1)] =
+              fma(al[mm], Uv[a % (RATES ? ND : 1)], -hx * Gv[(a * ND + mm) % (RATES ? ND * ND : 1)]);
+      }
     int st = 0;
     if (!inverse<ND>(Jm1, J)) st |= ST_NEWTON;
     // DF = I + sum_A dU_A (x) grad N_A = I - (G/Z) J^-T            (compute-Strains.c:20-44)
@@ -676,13 +702,27 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0);
     PH(11)
     if (fo_ok) {
-      // pass 2: -f_A = p_A * (B l_A), B l = B[.][x] lx_i + (B[.][y] ly_j + B[.][z] lz_k)
+      // pass 2: -f_A = p_A * (B l_A) with l = a - h u:  B l = B a - h (B[.][x] u_i + B[.][y] v_j + B[.][z] w_k)
+      double Ba[ND], hB[ND * ND];
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        double v = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < ND; mm++) {
+          v = fma(B[a * ND + mm], al[mm], v);
+          hB[a * ND + mm] = -hx * B[a * ND + mm];
+        }
+        Ba[a] = v;
+      }
 #pragma unroll NLPS_KUNROLL_K3S
       for (int k = 0; k < KN; k++) {
         const unsigned pb = plane_bits<ND>(c, k);
         const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
         const double wz = Zinv * ez5[k];
-        const double lzk = lz5[k];
+        const double ck = (double)(k - 2);
+        double cz[ND];
+#pragma unroll
+        for (int a = 0; a < ND; a++) cz[a] = (ND == 3) ? fma(hB[a * ND + (2 % ND)], ck, Ba[a]) : Ba[a];
 #pragma unroll NLPS_JUNROLL_SCATTER
         for (int j = 0; j < 5; j++) {
           const unsigned bits = (pb >> (5 * j)) & 31u;
@@ -690,15 +730,14 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
           const double w = wz * ey5[j];
           double cr[ND];
 #pragma unroll
-          for (int a = 0; a < ND; a++)
-            cr[a] = (ND == 3) ? fma(B[a * ND + 1], ly5[j], B[a * ND + (2 % ND)] * lzk) : B[a * ND + 1] * ly5[j];
+          for (int a = 0; a < ND; a++) cr[a] = fma(hB[a * ND + 1], (double)(j - 2), cz[a]);
 #pragma unroll
           for (int i = 0; i < 5; i++)
             if ((bits >> i) & 1u) {
               const int li = basek + (i - 2) + W * (j - 2);
               const double we = w * c.ex[i];
 #pragma unroll
-              for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * fma(B[a * ND + 0], c.lx[i], cr[a]));
+              for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
             }
         }
       }
