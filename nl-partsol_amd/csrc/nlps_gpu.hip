@@ -1907,7 +1907,7 @@ extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const doubl
   if (dU_dt && to_grid(h, h->gridB, dU_dt, h->nd)) return 1;
   if (dU_dt) h->level_b_fields = true;
   TileD td = tile_view(h);
-  const dim3 grid(h->ntw * K3_SPLIT), blk(BLK);
+  const dim3 grid(h->ntw * K3_SPLIT), blk(K3_BLK);
   const double* dV = dU_dt ? h->gridB : nullptr;
   if (h->nd == 2) {
     if (dV) hipLaunchKernelGGL((k3_tile<2, 0, 2>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, dV);
@@ -2017,7 +2017,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   auto launch_k3 = [&](int cls) {
     TileD td = tile_view(h, cls);
 #define NLPS_K3(NDv, LAWv)                                                                                      \
-  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d, (const double*)nullptr)
     const int law = h->uniform_law;
     if (ND == 2) {
@@ -2038,7 +2038,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   auto launch_k5 = [&](int cls) {
     TileD td = tile_view(h, cls);
 #define NLPS_K5(NDv, LAWv) \
-  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
+  hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g, h->N, td, dt, gamma_nm)
     const int law = h->uniform_law;
     if (ND == 2) {
       if (law == 0 || law == 1) NLPS_K5(2, 0);

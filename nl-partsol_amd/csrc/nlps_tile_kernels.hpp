@@ -32,6 +32,15 @@ struct TileCfg<2> {
 #ifndef NLPS_K2_SPLIT
 #define NLPS_K2_SPLIT 2
 #endif
+// workgroup sizes of the tile kernels (K2 keeps BLK: its work list splits tiles at BLK particles).  Measured at 1 M
+// particles: K3 with 64 / 128 / 256 / 512 threads 0.402 / 0.327 / 0.312 / 0.338 ms, K5 with 128 / 256 / 512 0.097 / 0.100 / 0.111 ms.
+#ifndef NLPS_K3_BLK
+#define NLPS_K3_BLK 256
+#endif
+#ifndef NLPS_K5_BLK
+#define NLPS_K5_BLK 256
+#endif
+static constexpr int K3_BLK = NLPS_K3_BLK, K5_BLK = NLPS_K5_BLK;
 #ifndef NLPS_K3_SPLIT
 #define NLPS_K3_SPLIT 1
 #endif
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
 // MODE 2: MODE 0 plus the rate tensors dt_DF = sum dV_A (x) grad N_A and dt_F_n1 = dt_DF F_n + DF dt_F_n
 // (compute-Strains.c:48-72, 176-207) from a second gather window dV.
 template <int ND, int LAW, int MODE>
-__global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+__global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus,
                                                const double* __restrict__ dVgrid) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
   PH_INIT
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int idx = threadIdx.x; idx < NW; idx += BLK) {
+  for (int idx = threadIdx.x; idx < NW; idx += K3_BLK) {
     bool in;
     int node = window_node<ND>(g, w0, idx, in);
     duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
   const double2* dv2 = reinterpret_cast<const double2*>(dvxy);
   const int start = td.start[tile];
   PH(8)
-  for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K3_SPLIT) {
+  for (int s = part * K3_BLK + threadIdx.x; s < cnt; s += K3_BLK * K3_SPLIT) {
     const int p = td.order[start + s];
     Lme<ND> c;
     double lam[ND], beta;
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
   if (MODE != 1) return;
   __syncthreads();
   PH(13)
-  for (int qq = threadIdx.x; qq < NW * ND; qq += BLK) {
+  for (int qq = threadIdx.x; qq < NW * ND; qq += K3_BLK) {
     int f = qq % ND, idx = qq / ND;
     double v = fac[f * NW + idx];
     if (v != 0.0) {
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) vo
 // is conflict-free for the tile's 64 I0 positions (see K3).
 // ------------------------------------------------------------------------------------------------
 template <int ND, int LAW>
-__global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
+__global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ __attribute__((aligned(16))) double axy[2 * NW];
   __shared__ double az[(ND == 3) ? NW : 1];
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
   const int cnt = td.count[tile];
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int idx = threadIdx.x; idx < NW; idx += BLK) {
+  for (int idx = threadIdx.x; idx < NW; idx += K5_BLK) {
     bool in;
     int node = window_node<ND>(g, w0, idx, in);
     axy[2 * idx] = in ? N.accel[(size_t)node * ND + 0] : 0.0;
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(BLK) void k5_tile(PView P, GridD g, NView N, TileD 
   __syncthreads();
   const double2* a2 = reinterpret_cast<const double2*>(axy);
   const int start = td.start[tile];
-  for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K5_SPLIT) {
+  for (int s = part * K5_BLK + threadIdx.x; s < cnt; s += K5_BLK * K5_SPLIT) {
     const int p = td.order[start + s];
     Lme<ND> c;
     double lam[ND], beta;
