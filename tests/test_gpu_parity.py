@@ -394,6 +394,21 @@ def test_tangent_matrix_spectral_laws(ndim, law):
     np.add.at(K_g, (rows, cols), vals)
     assert_close(K_g, K_o, 1e-8, f"{law} tangent matrix")
     assert np.array_equal(S.create_sparsity_pattern(), pat_o)
+    # a physical re-sort (all particle fields gathered into the twin block, level-B ones included) followed by the
+    # local search it asks for: the level-B state (C_ep, b_e, stress) has to come through
+    S.resort()
+    S.local_search()
+    assert o.local_search(P, M, prm) == 0
+    n2m, d2m, na2 = masks(S, M, bcs_list, 1, nsteps)
+    assert na2 == na
+    K_o2, _, st2 = o.tangent_matrix(P, M, mats, n2m, d2m, na, 2.0e3, Mv)
+    assert st2 == 0
+    rows2, cols2, vals2 = S.jacobian_evaluation(2.0e3, Mv, True)
+    K_r = np.zeros((ntot, ntot))
+    np.add.at(K_r, (rows2, cols2), vals2)
+    assert_close(K_r, K_o2, 1e-8, f"{law} tangent matrix after a re-sort")
+    if law != "hencky":
+        assert_close(S.download_state()["C_ep"], P["C_ep"], 1e-9, "C_ep after a re-sort", scale=mat["E"])
 
 
 class _OracleStages:
