@@ -311,8 +311,9 @@ int nlps_host_gid_mesh_read(const char *path, const nlps_gid_info *info, double 
  * LME.c:63-115 by the closed-form tables of nlps_host_stencil_tables.  Fails if the nodes are not such a lattice. */
 int nlps_host_lattice_from_nodes(int ndim, int nnodes, const double *coords, double *h, int n[3], double origin[3],
                                  int *canon);
-/* Particles of a body mesh: initial_position__Particles__ (Particles-Tools.c:8-28; Q4.c:342-452 with 1, 4, 5 or 9
- * and H8.c:389-575 with 1, 8 or 27 particles per element) and the volumes of initialise_particles
+/* Particles of a body mesh: initial_position__Particles__ (Particles-Tools.c:8-28; Q4.c:342-452 with 1, 4, 5 or 9,
+ * H8.c:389-575 with 1, 8 or 27, T3.c:337-440 with 1, 3, 4 or 9 and T4.c:322-420 with 1, 4 or 10 particles per
+ * element) and the volumes of initialise_particles
  * (Generate-One-Phase-Analysis.c:569-625: element volume by 2^d-point quadrature / particles per element; thickness
  * is Thickness_Plain_Stress of the 2-D build).  x[nelem * gp][ndim], vol0[nelem * gp], particle p = e * gp + j. */
 int nlps_host_particles_from_mesh(const nlps_gid_info *info, const double *coords, const int *conn, int gp_per_elem,

@@ -2,8 +2,8 @@
 // (Nodes/Read-GID-Mesh.c), the recognition of the structured GramsBox lattice behind a background mesh (what the
 // library needs instead of GramsBox's O(N_nodes x N_elem) neighbour construction, InOutFun/Read_GramsBox.c:293-456,
 // and of initialize__LME__'s element search, Nodes/LME.c:63-115), and the particles a body mesh generates
-// (InOutFun/Analysis/Generate-One-Phase-Analysis.c:569-625, Particles/Particles-Tools.c:8-28, Nodes/Q4.c:342-452,
-// Nodes/H8.c:389-575).  No GPU, no torch; entry points declared in include/nlps_gpu.h.
+// (InOutFun/Analysis/Generate-One-Phase-Analysis.c:569-625, Particles/Particles-Tools.c:8-28, Nodes/T3.c:337-440,
+// Nodes/Q4.c:342-452, Nodes/T4.c:322-420, Nodes/H8.c:389-575).  No GPU, no torch; entry points declared in include/nlps_gpu.h.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +88,30 @@ void dshape_h8(const double* x, double (*dN)[3]) {
   }
 }
 
+// N__T3__ / dN_Ref__T3__ (Nodes/T3.c:100-132) and N__T4__ / dN_Ref__T4__ (Nodes/T4.c:96-128)
+void shape_t3(const double* x, double* N) {
+  N[0] = 1 - x[0] - x[1];
+  N[1] = x[0];
+  N[2] = x[1];
+}
+void dshape_t3(double (*dN)[3]) {
+  dN[0][0] = -1, dN[0][1] = -1;
+  dN[1][0] = +1, dN[1][1] = +0;
+  dN[2][0] = +0, dN[2][1] = +1;
+}
+void shape_t4(const double* x, double* N) {
+  N[0] = x[0];
+  N[1] = x[1];
+  N[2] = x[2];
+  N[3] = 1. - x[0] - x[1] - x[2];
+}
+void dshape_t4(double (*dN)[3]) {
+  for (int a = 0; a < 4; a++)
+    for (int j = 0; j < 3; j++) dN[a][j] = a < 3 ? (a == j ? 1. : 0.) : -1.;
+}
+
+enum Elem { Q4, H8, T3, T4 };
+
 // I3__MatrixLib__, Matlib/MatrixOp.c:290-300
 double det(const double F[3][3], int nd) {
   if (nd == 2) return F[0][0] * F[1][1] - F[0][1] * F[1][0];
@@ -96,34 +120,67 @@ double det(const double F[3][3], int nd) {
 }
 
 // volume__Q4__ (Nodes/Q4.c:493-530) / volume__H8__ (Nodes/H8.c:643-690): sum of |det F_ref| over the 2^d
-// Gauss points 0.5773502692 (the reference's 10-digit constant), unit weights; F_ref = sum_I x_I (x) dN_I
-// (F_Ref__Q4__, Q4.c:160-208).
-double element_volume(int nd, int npe, const double (*X)[3]) {
+// Gauss points 0.5773502692 (the reference's 10-digit constant), unit weights; volume__T3__ (T3.c:506-540): three
+// points of weight 1/6; volume__T4__ (T4.c:488-524): four points of weight 1/24 (7-digit coordinates).
+// F_ref = sum_I x_I (x) dN_I (F_Ref__Q4__, Q4.c:160-208, and its siblings).
+double element_volume(Elem el, int nd, int npe, const double (*X)[3]) {
+  // (the simplices' quadrature points do not matter: their dN, and with it F_ref, is constant over the element)
   const double g = 0.577350269200000;
+  const int nq = el == T3 ? 3 : el == T4 ? 4 : (1 << nd);
+  const double w = el == T3 ? 1. / 6. : el == T4 ? 1. / 24. : 1.0;
   double vol = 0.0;
-  for (int q = 0; q < (1 << nd); q++) {
+  for (int q = 0; q < nq; q++) {
     double xi[3] = {(q & 1) ? g : -g, (q & 2) ? g : -g, (q & 4) ? g : -g};
     double dN[8][3];
-    if (nd == 2) dshape_q4(xi, dN);
-    else dshape_h8(xi, dN);
+    if (el == Q4) dshape_q4(xi, dN);
+    else if (el == H8) dshape_h8(xi, dN);
+    else if (el == T3) dshape_t3(dN);
+    else dshape_t4(dN);
     double F[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int I = 0; I < npe; I++)
       for (int i = 0; i < nd; i++)
         for (int j = 0; j < nd; j++) F[i][j] += X[I][i] * dN[I][j];
-    vol += std::fabs(det(F, nd)) * 1.0;
+    vol += std::fabs(det(F, nd)) * w;
   }
   return vol;
 }
 
 // natural coordinates of the particles of one element: element_to_particles__Q4__ (Q4.c:353-416: 1, 4, 5, 9) and
 // element_to_particles__H8__ (H8.c:399-548: 1, 8, 27), with the reference's truncated constants
-bool particle_sites(int nd, int gp, std::vector<double>& xi) {
+bool particle_sites(Elem el, int nd, int gp, std::vector<double>& xi) {
   xi.assign((size_t)gp * 3, 0.0);
   auto set = [&](int j, double a, double b, double c) {
     xi[3 * j] = a;
     xi[3 * j + 1] = b;
     xi[3 * j + 2] = c;
   };
+  if (el == T3) {  // element_to_particles__T3__, T3.c:348-412 (one particle sits on the first vertex, as there)
+    const double a = 0.16666666666, b = 0.66666666666, c = 0.33333333333;
+    const double n1 = 0.11111111111, n2 = 0.22222222222, n4 = 0.44444444444, n5 = 0.55555555555, n7 = 0.77777777777;
+    switch (gp) {
+      case 1: return true;
+      case 3: set(0, a, a, 0), set(1, b, a, 0), set(2, a, b, 0); return true;
+      case 4: set(0, a, a, 0), set(1, b, a, 0), set(2, a, b, 0), set(3, c, c, 0); return true;
+      case 9:
+        set(0, n1, n1, 0), set(1, n4, n1, 0), set(2, n7, n1, 0), set(3, n2, n2, 0), set(4, n5, n2, 0);
+        set(5, n1, n4, 0), set(6, n4, n4, 0), set(7, n2, n5, 0), set(8, n1, n7, 0);
+        return true;
+      default: return false;
+    }
+  }
+  if (el == T4) {  // element_to_particles__T4__, T4.c:333-392
+    const double a = 0.138196601125010, b = 0.585410196624968;
+    const double c = 0.108103018168070, d = 0.816847572980459, e = 0.445948490915965;
+    switch (gp) {
+      case 1: set(0, .25, .25, .25); return true;
+      case 4: set(0, a, a, a), set(1, b, a, a), set(2, a, b, a), set(3, a, a, b); return true;
+      case 10:
+        set(0, c, c, c), set(1, d, c, c), set(2, c, d, c), set(3, c, c, d), set(4, e, c, c), set(5, e, e, c);
+        set(6, c, e, c), set(7, c, c, e), set(8, e, c, e), set(9, c, e, e);
+        return true;
+      default: return false;
+    }
+  }
   if (nd == 2) {
     const double s = 1. / std::sqrt(3.0), t = 0.6666666666666;
     switch (gp) {
@@ -289,22 +346,27 @@ extern "C" int nlps_host_particles_from_mesh(const nlps_gid_info* info, const do
                                              int gp_per_elem, double thickness, double* x, double* vol0) {
   if (!info || !coords || !conn || !x || !vol0) return fail("null argument");
   const int nd = info->ndim, npe = info->nodes_per_elem;
-  const bool q4 = nd == 2 && npe == 4 && !strcmp(info->elem_type, "Quadrilateral");
-  const bool h8 = nd == 3 && npe == 8 && !strcmp(info->elem_type, "Hexahedra");
-  if (!q4 && !h8) return fail("particles are generated from Quadrilateral (4) or Hexahedra (8) body meshes only");
+  Elem el;
+  if (nd == 2 && npe == 4 && !strcmp(info->elem_type, "Quadrilateral")) el = Q4;
+  else if (nd == 3 && npe == 8 && !strcmp(info->elem_type, "Hexahedra")) el = H8;
+  else if (nd == 2 && npe == 3 && !strcmp(info->elem_type, "Triangle")) el = T3;
+  else if (nd == 3 && npe == 4 && !strcmp(info->elem_type, "Tetrahedra")) el = T4;
+  else return fail("particles are generated from linear Triangle / Quadrilateral / Tetrahedra / Hexahedra body meshes");
   std::vector<double> xi;
-  if (!particle_sites(nd, gp_per_elem, xi)) return fail("Wrong number of particles per element");
+  if (!particle_sites(el, nd, gp_per_elem, xi)) return fail("Wrong number of particles per element");
   for (int e = 0; e < info->nelem; e++) {
     double X[8][3];
     for (int k = 0; k < npe; k++)
       for (int l = 0; l < 3; l++) X[k][l] = l < nd ? coords[(size_t)conn[(size_t)e * npe + k] * nd + l] : 0.0;
-    double vol = element_volume(nd, npe, X);
+    double vol = element_volume(el, nd, npe, X);
     if (nd == 2) vol *= thickness;  // Thickness_Plain_Stress, Q4.c:524
     if (vol <= 0.0) return fail("Element with negative volume");  // Generate-One-Phase-Analysis.c:591-595
     for (int j = 0; j < gp_per_elem; j++) {
       double N[8];
-      if (q4) shape_q4(&xi[3 * j], N);
-      else shape_h8(&xi[3 * j], N);
+      if (el == Q4) shape_q4(&xi[3 * j], N);
+      else if (el == H8) shape_h8(&xi[3 * j], N);
+      else if (el == T3) shape_t3(&xi[3 * j], N);
+      else shape_t4(&xi[3 * j], N);
       const size_t p = (size_t)e * gp_per_elem + j;
       for (int l = 0; l < nd; l++) x[p * nd + l] = 0.0;
       for (int k = 0; k < npe; k++)  // Q4.c:433-442 / H8.c:560-569

@@ -192,8 +192,8 @@ def test_reader_errors(tmp_path):
     with pytest.raises(E, match="cannot open"):
         gid.read_gid_mesh(tmp_path / "missing.msh")
     coords, conn, _ = lattice_mesh(2, [2, 2])
-    write_gid(p, 2, "Triangle", coords, conn[:, :3])
-    with pytest.raises(E, match="Quadrilateral"):
+    write_gid(p, 2, "Pentagon", coords, np.hstack([conn, conn[:, :1]]))
+    with pytest.raises(E, match="linear Triangle"):
         gid.particles_from_mesh(gid.read_gid_mesh(p), 1)
 
 
@@ -305,3 +305,61 @@ def test_nodal_vtk_file(tmp_path, ndim, cells, etype):
         r = list(rea[a]) + [0.0] * (3 - ndim)
         L.append(("%.20g %.20g %.20g" % tuple(r)) if active[a] else "0 0 0 ")
     assert (tmp_path / "nodes.vtk").read_text() == "\n".join(L) + "\n"
+
+
+# ---- simplex bodies ------------------------------------------------------------------------------------------------
+def simplex_mesh(ndim, rng):
+    """A few positively oriented triangles / tetrahedra on random points."""
+    pts = rng.uniform(0.0, 3.0, size=(12, ndim))
+    conn = []
+    while len(conn) < 9:
+        ids = rng.choice(len(pts), size=ndim + 1, replace=False)
+        E = (pts[ids[1:]] - pts[ids[0]]).T
+        if abs(np.linalg.det(E)) > 0.2:
+            conn.append(ids)
+    return pts, np.asarray(conn, dtype=np.int64)
+
+
+T3_SITES = {1: [[0, 0]],
+            3: [[0.16666666666, 0.16666666666], [0.66666666666, 0.16666666666], [0.16666666666, 0.66666666666]],
+            4: [[0.16666666666, 0.16666666666], [0.66666666666, 0.16666666666], [0.16666666666, 0.66666666666],
+                [0.33333333333, 0.33333333333]],
+            9: [[0.11111111111, 0.11111111111], [0.44444444444, 0.11111111111], [0.77777777777, 0.11111111111],
+                [0.22222222222, 0.22222222222], [0.55555555555, 0.22222222222], [0.11111111111, 0.44444444444],
+                [0.44444444444, 0.44444444444], [0.22222222222, 0.55555555555], [0.11111111111, 0.77777777777]]}
+_a, _b = 0.138196601125010, 0.585410196624968
+_c, _d, _e = 0.108103018168070, 0.816847572980459, 0.445948490915965
+T4_SITES = {1: [[.25, .25, .25]], 4: [[_a, _a, _a], [_b, _a, _a], [_a, _b, _a], [_a, _a, _b]],
+            10: [[_c, _c, _c], [_d, _c, _c], [_c, _d, _c], [_c, _c, _d], [_e, _c, _c], [_e, _e, _c], [_c, _e, _c],
+                 [_c, _c, _e], [_e, _c, _e], [_c, _e, _e]]}
+
+
+@pytest.mark.parametrize("ndim,etype", [(2, "Triangle"), (3, "Tetrahedra")])
+def test_particles_of_simplex_bodies(tmp_path, ndim, etype):
+    """element_to_particles__T3__ / __T4__ (T3.c:337-440, T4.c:322-420) and volume__T3__ / __T4__ (T3.c:506-540,
+    T4.c:488-524): N = (1 - xi - eta, xi, eta) resp. (xi, eta, zeta, 1 - ...) on the chain (reversed file) order, the
+    site tables with the reference's truncated constants, volume = |det F_ref| x (3 x 1/6 | 4 x 1/24) x thickness."""
+    rng = np.random.default_rng(17)
+    pts, conn = simplex_mesh(ndim, rng)
+    write_gid(tmp_path / "body.msh", ndim, etype, pts, conn)
+    m = gid.read_gid_mesh(tmp_path / "body.msh")
+    sites = T3_SITES if ndim == 2 else T4_SITES
+    for gp, xis in sites.items():
+        x, vol0 = gid.particles_from_mesh(m, gp, thickness=1.5)
+        xr, vr = [], []
+        for row in conn:
+            X = m["coords"][row[::-1]]
+            if ndim == 2:
+                Fref = np.outer(X[0], [-1, -1]) + np.outer(X[1], [1, 0]) + np.outer(X[2], [0, 1])
+                v = abs(np.linalg.det(Fref)) * 0.5 * 1.5
+            else:
+                Fref = np.outer(X[0], [1, 0, 0]) + np.outer(X[1], [0, 1, 0]) + np.outer(X[2], [0, 0, 1]) + np.outer(X[3], [-1, -1, -1])
+                v = abs(np.linalg.det(Fref)) / 6.0
+            for xi in xis:
+                N = [1 - xi[0] - xi[1], xi[0], xi[1]] if ndim == 2 else [xi[0], xi[1], xi[2], 1 - xi[0] - xi[1] - xi[2]]
+                xr.append(np.asarray(N) @ X)
+                vr.append(v / gp)
+        assert np.abs(x - np.asarray(xr)).max() <= 1e-15 * 3.0
+        assert np.abs(vol0 - np.asarray(vr)).max() <= 1e-14 * max(vr)
+    with pytest.raises(nlps().NlpsError, match="Wrong number of particles per element"):
+        gid.particles_from_mesh(m, 2)
