@@ -319,6 +319,27 @@ int nlps_host_lattice_from_nodes(int ndim, int nnodes, const double *coords, dou
 int nlps_host_particles_from_mesh(const nlps_gid_info *info, const double *coords, const int *conn, int gp_per_elem,
                                   double thickness, double *x, double *vol0);
 
+/* ---- command file (.nlp), the subset the path needs before its first step: NLPS-Solver (Read_GramsTime.c:44-378, with
+ * its defaults and check_Solver), GramsShapeFun (Read_GramsShapeFun.c:20-200), the mesh of GramsBox
+ * (Read_GramsBox.c:235-262) and the body mesh / particles per element of One-Phase-Analysis
+ * (Generate-One-Phase-Analysis.c:386-445); file names come back joined to the directory of the command file
+ * (generate_route).  Materials, initial values, boundary conditions and outputs are not read.  Where the reference
+ * prints and exit()s, this returns 1 with the same wording in nlps_host_io_last_error(). */
+typedef struct nlps_deck {
+  char box_mesh[512], body_mesh[512];
+  int gp_per_elem;
+  char scheme[64]; /* NLPS-Solver Type */
+  double CFL, Cel;
+  int i0, N;
+  double epsilon_mass_matrix, beta_newmark, gamma_newmark, tol_newmark, rb_generalized_alpha, tol_generalized_alpha;
+  int max_iter, explicit_trial;
+  char shape_fun[16]; /* GramsShapeFun Type */
+  double gamma_lme, tol_zero_lme, tol_wrapper_lme;
+  int max_iter_lme;
+  char wrapper_lme[32];
+} nlps_deck;
+int nlps_host_read_deck(const char *path, nlps_deck *deck);
+
 /* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
  * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in
  * the layout of nlps_gpu_download_state ([np][ndim], tensors [np][5 | 9]); a NULL array leaves its block out, like

@@ -522,3 +522,133 @@ extern "C" int nlps_host_write_nodes_vtk(const char* path, const nlps_gid_info* 
   if (fclose(f)) return fail(std::string("write error on ") + path);
   return 0;
 }
+
+// ---- command file (.nlp), the subset the path needs before its first step -----------------------------------------
+// Blocks "Keyword (Key=value,...) {" + "Property = value" lines + "}" as the reference's readers take them:
+//   NLPS-Solver (Type=scheme) { CFL= Cel= N= i0= Epsilon= ... }          InOutFun/Read_GramsTime.c:44-230
+//   GramsShapeFun (Type=LME) { gamma= TOL-Zero= MaxIter= wrapper= TOL-Wrapper= }   InOutFun/Read_GramsShapeFun.c:20-200
+//   GramsBox (Type=GID,File=box.msh) { ... }                              InOutFun/Read_GramsBox.c:235-262
+//   One-Phase-Analysis (File=body.msh, GPxElement=n) ...                  Analysis/Generate-One-Phase-Analysis.c:386-445
+// Materials, initial values, boundary conditions and outputs are other blocks of the same file and are not read here.
+namespace {
+std::string dir_of(const char* path) {  // generate_route: the directory of the command file, with the separator
+  std::string p(path);
+  const size_t k = p.find_last_of('/');
+  return k == std::string::npos ? std::string("./") : p.substr(0, k + 1);
+}
+int tokens(char* line, const char* delims, std::vector<char*>& w) {
+  w.clear();
+  char* save = nullptr;
+  for (char* p = strtok_r(line, delims, &save); p; p = strtok_r(nullptr, delims, &save)) w.push_back(p);
+  return (int)w.size();
+}
+// "Property = value" lines up to the closing brace; fn returns false for a property it does not know
+template <class F>
+int read_properties(LineReader& in, const char* who, F fn) {
+  std::vector<char*> w;
+  while (true) {
+    if (!in.next()) return fail(std::string(who) + ": you forget to put a } !!!");
+    const int n = tokens(in.buf.data(), " =\t\r\n", w);
+    if (n > 0 && !strcmp(w[0], "}")) return 0;
+    if (n == 0) continue;  // (the reference stops on an empty line; tolerated here)
+    if (n != 2) return fail(std::string(who) + ": Use this format -> Propertie = value !!!");
+    if (!fn(w[0], w[1])) return fail(std::string(who) + ": Undefined " + w[0]);
+  }
+}
+}  // namespace
+
+extern "C" int nlps_host_read_deck(const char* path, nlps_deck* d) {
+  if (!path || !d) return fail("null argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  memset(d, 0, sizeof(*d));
+  // defaults of Initialise_Parameters (Read_GramsTime.c:246-262) and of GramsShapeFun (Read_GramsShapeFun.c:86-90)
+  d->CFL = 0.8;
+  d->epsilon_mass_matrix = 1.0;
+  d->beta_newmark = 0.25;
+  d->gamma_newmark = 0.5;
+  d->tol_newmark = 1E-10;
+  d->rb_generalized_alpha = 0.6;
+  d->tol_generalized_alpha = 1E-10;
+  d->max_iter = 10;
+  d->gamma_lme = 3;
+  d->tol_zero_lme = 1e-6;
+  d->tol_wrapper_lme = 1e-10;
+  d->max_iter_lme = 10;
+  snprintf(d->wrapper_lme, sizeof(d->wrapper_lme), "Newton-Raphson");
+  const std::string route = dir_of(path);
+  int n_solver = 0;
+  bool has_N = false, has_cel = false, has_cfl = false, has_beta = false, has_gamma = false, has_tol = false,
+       has_eps = false, has_rb = false, has_tolga = false;
+  std::vector<char*> w, kv;
+  std::vector<char> copy;
+  while (in.next()) {
+    copy.assign(in.buf.begin(), in.buf.begin() + strlen(in.buf.data()) + 1);
+    if (tokens(copy.data(), " \r\n\t", w) < 1) continue;
+    if (!strcmp(w[0], "NLPS-Solver")) {
+      n_solver++;
+      if (w.size() < 3 || tokens(w[1], "(=)", kv) != 2 || strcmp(kv[0], "Type"))
+        return fail("NLPS-Solver: Use this format -> NLPS-Solver (Type=string) { !!!");
+      snprintf(d->scheme, sizeof(d->scheme), "%s", kv[1]);
+      if (strcmp(w[2], "{")) return fail("NLPS-Solver: Use this format -> NLPS-Solver (Type=string) { !!!");
+      if (read_properties(in, "NLPS-Solver", [&](const char* k, const char* v) {
+            if (!strcmp(k, "CFL")) d->CFL = atof(v), has_cfl = true;
+            else if (!strcmp(k, "Cel")) d->Cel = atof(v), has_cel = true;
+            else if (!strcmp(k, "i0")) d->i0 = atoi(v);
+            else if (!strcmp(k, "N")) d->N = atoi(v), has_N = true;
+            else if (!strcmp(k, "Epsilon")) d->epsilon_mass_matrix = atof(v), has_eps = true;
+            else if (!strcmp(k, "rb-Generalized-alpha")) d->rb_generalized_alpha = atof(v), has_rb = true;
+            else if (!strcmp(k, "TOL-Generalized-alpha")) d->tol_generalized_alpha = atof(v), has_tolga = true;
+            else if (!strcmp(k, "Beta-Newmark-beta")) d->beta_newmark = atof(v), has_beta = true;
+            else if (!strcmp(k, "Gamma-Newmark-beta")) d->gamma_newmark = atof(v), has_gamma = true;
+            else if (!strcmp(k, "TOL-Newmark-beta")) d->tol_newmark = atof(v), has_tol = true;
+            else if (!strcmp(k, "Max-Iter")) d->max_iter = atoi(v);
+            else if (!strcmp(k, "Explicit-trial")) d->explicit_trial = atoi(v);
+            else return false;
+            return true;
+          }))
+        return 1;
+    } else if (!strcmp(w[0], "GramsShapeFun")) {
+      if (w.size() < 2 || tokens(w[1], "(=)", kv) != 2 || strcmp(kv[0], "Type"))
+        return fail("GramsShapeFun: Use this format -> (Type=string) !!!");
+      snprintf(d->shape_fun, sizeof(d->shape_fun), "%s", kv[1]);
+      if (w.size() < 3 || strcmp(w[2], "{")) return fail("GramsShapeFun: Use this format -> GramsShapeFun (Type=string) { !!!");
+      if (!(w.size() == 4 && !strcmp(w[3], "}")) &&
+          read_properties(in, "GramsShapeFun", [&](const char* k, const char* v) {
+            if (!strcmp(k, "gamma")) d->gamma_lme = atof(v);
+            else if (!strcmp(k, "TOL-Zero")) d->tol_zero_lme = atof(v);
+            else if (!strcmp(k, "MaxIter")) d->max_iter_lme = atoi(v);
+            else if (!strcmp(k, "wrapper")) snprintf(d->wrapper_lme, sizeof(d->wrapper_lme), "%s", v);
+            else if (!strcmp(k, "TOL-Wrapper")) d->tol_wrapper_lme = atof(v);
+            else return false;
+            return true;
+          }))
+        return 1;
+      if ((!strcmp(d->shape_fun, "LME") || !strcmp(d->shape_fun, "aLME")) && d->gamma_lme == 0)
+        return fail("GramsShapeFun: gamma parameter required for LME !!!");
+    } else if (!strcmp(w[0], "GramsBox")) {
+      copy.assign(in.buf.begin(), in.buf.begin() + strlen(in.buf.data()) + 1);
+      if (tokens(copy.data(), " =,()\r\n\t", w) < 5 || strcmp(w[1], "Type") || strcmp(w[3], "File"))
+        return fail("GramsBox: GramsBox (Type=GID,File=mesh.msh) {");
+      if (strcmp(w[2], "GID")) return fail("GramsBox: Unrecognised kind of mesh");
+      snprintf(d->box_mesh, sizeof(d->box_mesh), "%s%s", route.c_str(), w[4]);
+    } else if (!strcmp(w[0], "One-Phase-Analysis")) {
+      copy.assign(in.buf.begin(), in.buf.begin() + strlen(in.buf.data()) + 1);
+      if (tokens(copy.data(), " (,)\r\n\t", w) < 3) return fail("One-Phase-Analysis (File=Mesh.msh, GPxElement=int)");
+      if (tokens(w[1], "=", kv) != 2 || strcmp(kv[0], "File")) return fail("One-Phase-Analysis (File=Mesh.msh, *)");
+      snprintf(d->body_mesh, sizeof(d->body_mesh), "%s%s", route.c_str(), kv[1]);
+      if (tokens(w[2], "=", kv) != 2 || strcmp(kv[0], "GPxElement")) return fail("One-Phase-Analysis (*, GPxElement=int)");
+      d->gp_per_elem = atoi(kv[1]);
+    }
+  }
+  // check_Solver, Read_GramsTime.c:265-378
+  if (n_solver != 1) return fail(n_solver ? "NLPS-Solver: more than one solver defined" : "NLPS-Solver: no solver defined");
+  if (!(has_N && has_cel && has_cfl)) return fail("NLPS-Solver: N, Cel and CFL are required");
+  if (!strcmp(d->scheme, "Newmark-beta-Finite-Strains") && !(has_beta && has_gamma && has_tol && has_eps))
+    return fail("NLPS-Solver: Newmark-beta-Finite-Strains needs Beta-Newmark-beta, Gamma-Newmark-beta, TOL-Newmark-beta, Epsilon");
+  if (!strcmp(d->scheme, "Generalized-alpha") && !(has_rb && has_tolga))
+    return fail("NLPS-Solver: Generalized-alpha needs rb-Generalized-alpha and TOL-Generalized-alpha");
+  if (!strcmp(d->scheme, "Discrete-Energy-Momentum") && !(has_rb && has_tolga && has_eps))
+    return fail("NLPS-Solver: Discrete-Energy-Momentum needs rb-Generalized-alpha, TOL-Generalized-alpha and Epsilon");
+  return 0;
+}

@@ -132,3 +132,26 @@ def write_nodes_vtk(path, mesh, canon, active, reactions):
     f.argtypes = [C.c_char_p, C.POINTER(GidInfo)] + [C.c_void_p] * 5
     _check(f(str(path).encode(), C.byref(info), coords.ctypes.data, conn.ctypes.data, None if cn is None else cn.ctypes.data,
              act.ctypes.data, rea.ctypes.data), "nlps_host_write_nodes_vtk")
+
+
+class Deck(C.Structure):
+    _fields_ = [("box_mesh", C.c_char * 512), ("body_mesh", C.c_char * 512), ("gp_per_elem", C.c_int),
+                ("scheme", C.c_char * 64), ("CFL", C.c_double), ("Cel", C.c_double), ("i0", C.c_int), ("N", C.c_int),
+                ("epsilon_mass_matrix", C.c_double), ("beta_newmark", C.c_double), ("gamma_newmark", C.c_double),
+                ("tol_newmark", C.c_double), ("rb_generalized_alpha", C.c_double), ("tol_generalized_alpha", C.c_double),
+                ("max_iter", C.c_int), ("explicit_trial", C.c_int), ("shape_fun", C.c_char * 16),
+                ("gamma_lme", C.c_double), ("tol_zero_lme", C.c_double), ("tol_wrapper_lme", C.c_double),
+                ("max_iter_lme", C.c_int), ("wrapper_lme", C.c_char * 32)]
+
+
+def read_deck(path):
+    """The subset of a .nlp command file the path needs before its first step (see include/nlps_gpu.h) as a dict."""
+    d = Deck()
+    f = _nlps.lib().nlps_host_read_deck
+    f.argtypes = [C.c_char_p, C.POINTER(Deck)]
+    _check(f(str(path).encode(), C.byref(d)), "nlps_host_read_deck")
+    out = {}
+    for name, _ in Deck._fields_:
+        v = getattr(d, name)
+        out[name] = v.decode() if isinstance(v, bytes) else v
+    return out

@@ -363,3 +363,61 @@ def test_particles_of_simplex_bodies(tmp_path, ndim, etype):
         assert np.abs(vol0 - np.asarray(vr)).max() <= 1e-14 * max(vr)
     with pytest.raises(nlps().NlpsError, match="Wrong number of particles per element"):
         gid.particles_from_mesh(m, 2)
+
+
+# ---- command file ------------------------------------------------------------------------------------------------
+DECK = """# impact of an elastic block
+GramsBox (Type=GID,File=box.msh) {
+  GramsBoundary (File=bottom.txt) {
+    BcDirichlet V.y NULL
+  }
+}
+One-Phase-Analysis (File=body.msh, GPxElement=4) {
+}
+GramsShapeFun (Type=LME) {
+\tgamma=2.3
+\tTOL-Zero = 10e-6
+\tMaxIter=20
+}
+NLPS-Solver (Type=NPC-FS) {
+  CFL=0.6
+  Cel = 100.0
+  N=4000
+  i0=10
+}
+"""
+
+
+def test_command_file_subset(tmp_path):
+    """NLPS-Solver (Read_GramsTime.c), GramsShapeFun (Read_GramsShapeFun.c), the GramsBox mesh (Read_GramsBox.c:235-262)
+    and One-Phase-Analysis (Generate-One-Phase-Analysis.c:386-445): values, the reference's defaults for what a block
+    leaves out, file names joined to the directory of the command file, and its syntax errors as failures."""
+    E = nlps().NlpsError
+    p = tmp_path / "run.nlp"
+    p.write_text(DECK)
+    d = gid.read_deck(p)
+    assert d["box_mesh"] == str(tmp_path) + "/box.msh" and d["body_mesh"] == str(tmp_path) + "/body.msh"
+    assert d["gp_per_elem"] == 4
+    assert (d["scheme"], d["CFL"], d["Cel"], d["N"], d["i0"]) == ("NPC-FS", 0.6, 100.0, 4000, 10)
+    assert (d["shape_fun"], d["gamma_lme"], d["tol_zero_lme"], d["max_iter_lme"]) == ("LME", 2.3, 10e-6, 20)
+    # defaults: Initialise_Parameters (Read_GramsTime.c:246-262), GramsShapeFun (Read_GramsShapeFun.c:86-90)
+    assert (d["epsilon_mass_matrix"], d["beta_newmark"], d["gamma_newmark"], d["max_iter"]) == (1.0, 0.25, 0.5, 10)
+    assert (d["tol_wrapper_lme"], d["wrapper_lme"]) == (1e-10, "Newton-Raphson")
+    # an empty shape-function block on one line keeps every default
+    p.write_text(DECK.replace("GramsShapeFun (Type=LME) {\n\tgamma=2.3\n\tTOL-Zero = 10e-6\n\tMaxIter=20\n}", "GramsShapeFun (Type=uGIMP) { }"))
+    d = gid.read_deck(p)
+    assert (d["shape_fun"], d["gamma_lme"], d["tol_zero_lme"], d["max_iter_lme"]) == ("uGIMP", 3.0, 1e-6, 10)
+    for bad, msg in ((DECK.replace("  N=4000\n", ""), "N, Cel and CFL are required"),
+                     (DECK.replace("CFL=0.6", "Courant=0.6"), "Undefined Courant"),
+                     (DECK.replace("  i0=10\n}", "  i0=10\n"), "forget to put a }"),
+                     (DECK.replace("NLPS-Solver (Type=NPC-FS) {", "NLPS-Solver (Kind=NPC-FS) {"), "Type=string"),
+                     (DECK + "NLPS-Solver (Type=NPC-FS) {\n CFL=1\n Cel=1\n N=1\n}\n", "more than one solver"),
+                     (DECK.replace("Type=GID", "Type=GMSH"), "Unrecognised kind of mesh"),
+                     (DECK.replace("GPxElement=4", "Particles=4"), "GPxElement=int"),
+                     (DECK.replace("Type=NPC-FS", "Type=Newmark-beta-Finite-Strains"), "needs Beta-Newmark-beta"),
+                     (DECK.replace("gamma=2.3", "gamma=0"), "gamma parameter required")):
+        p.write_text(bad)
+        with pytest.raises(E, match=msg):
+            gid.read_deck(p)
+    with pytest.raises(E, match="cannot open"):
+        gid.read_deck(tmp_path / "none.nlp")
