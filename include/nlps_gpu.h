@@ -339,6 +339,13 @@ typedef struct nlps_deck {
   char wrapper_lme[32];
 } nlps_deck;
 int nlps_host_read_deck(const char *path, nlps_deck *deck);
+/* The Define-Material(idx=i,Model=m) { property = value ... } blocks of the same file for the four laws of this path
+ * (Read_GramsMaterials2.c:51-175; property names, defaults and completeness checks of Material/Hyperelastic/
+ * Neo-Hookean.c, Hencky.c, Material/Plasticity/Drucker-Prager.c incl. its default reference plastic strain, and
+ * Von-Mises.c).  mats / rho / idx (may be NULL) have room for max_materials entries, *nmats comes back.  Any other
+ * model, or Fbar = true, is an error: this path does not cover them. */
+int nlps_host_read_materials(const char *path, int max_materials, nlps_material *mats, double *rho, int *idx,
+                             int *nmats);
 
 /* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
  * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in

@@ -652,3 +652,87 @@ extern "C" int nlps_host_read_deck(const char* path, nlps_deck* d) {
     return fail("NLPS-Solver: Discrete-Energy-Momentum needs rb-Generalized-alpha, TOL-Generalized-alpha and Epsilon");
   return 0;
 }
+
+// Define-Material blocks (InOutFun/Material/Read_GramsMaterials2.c:51-175) of the four laws of this path:
+//   Define-Material(idx=0,Model=Neo-Hookean-Wriggers | Hencky | Drucker-Prager | Von-Mises) { property = value ... }
+// with the property names, defaults and completeness checks of Material/Hyperelastic/Neo-Hookean.c, Hencky.c and
+// Material/Plasticity/Drucker-Prager.c, Von-Mises.c.  The eigenerosion / eigensoftening constants (Ceps, Gf, ft,
+// heps, wcrit) are accepted and dropped, as the reference does when those drivers are off.
+extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlps_material* mats, double* rho,
+                                        int* idx, int* nmats) {
+  if (!path || !mats || !rho || !nmats || max_materials < 1) return fail("bad argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  *nmats = 0;
+  std::vector<char*> w, kv;
+  while (in.next()) {
+    if (tokens(in.buf.data(), " ,()\r\n\t", w) < 1 || strcmp(w[0], "Define-Material")) continue;
+    if (w.size() < 3) return fail("Define-Material: Define-Material(idx=int,Model=string)");
+    if (*nmats >= max_materials) return fail("Define-Material: more materials than the caller has room for");
+    // Read_Index_and_Model, :178-210: "idx=0" or "0", "Model=X" or "X"
+    int n = tokens(w[1], "=", kv);
+    const int id = atoi(kv[n == 2 ? 1 : 0]);
+    n = tokens(w[2], "=", kv);
+    const std::string model = kv[n == 2 ? 1 : 0];
+    nlps_material m;
+    memset(&m, 0, sizeof(m));
+    m.theta_voce = 1.0;  // Von-Mises.c:70-75
+    if (model == "Neo-Hookean-Wriggers") m.type = NLPS_MAT_NEO_HOOKEAN;
+    else if (model == "Hencky") m.type = NLPS_MAT_HENCKY;
+    else if (model == "Drucker-Prager") m.type = NLPS_MAT_DRUCKER_PRAGER;
+    else if (model == "Von-Mises") m.type = NLPS_MAT_VON_MISES;
+    else return fail("Define-Material: model " + model + " is not one of the laws of this path");
+    const std::string who = "Define-Material(" + model + ")";
+    bool open = false, closed = false, has_rho = false, has_E = false, has_nu = false, has_phi = false, has_psi = false,
+         has_eps0 = false, has_yield = false, fbar = false;
+    double H = 0.0, r = 0.0;
+    while (!closed) {
+      if (!in.next()) return fail(who + ": the block is not closed");
+      const int np_ = tokens(in.buf.data(), " =\t\r\n", kv);
+      if (np_ == 0) continue;
+      const char* k = kv[0];
+      const double v = np_ > 1 ? atof(kv[1]) : 0.0;
+      const bool dp = m.type == NLPS_MAT_DRUCKER_PRAGER, vm = m.type == NLPS_MAT_VON_MISES;
+      if (!strcmp(k, "{") && np_ == 1) open = true;
+      else if (!strcmp(k, "}") && np_ == 1) closed = true;
+      else if (np_ != 2) return fail(who + ": Use this format -> Propertie = value");
+      else if (!strcmp(k, "rho")) r = v, has_rho = true;
+      else if (!strcmp(k, "E")) m.E = v, has_E = true;
+      else if (!strcmp(k, "nu")) m.nu = v, has_nu = true;
+      else if (!strcmp(k, "Ceps") || !strcmp(k, "Gf") || !strcmp(k, "ft") || !strcmp(k, "heps") || !strcmp(k, "wcrit")) {
+      } else if (m.type == NLPS_MAT_NEO_HOOKEAN && !strcmp(k, "Fbar"))
+        fbar = !strcmp(kv[1], "true") || !strcmp(kv[1], "True") || !strcmp(kv[1], "TRUE") || !strcmp(kv[1], "1");
+      else if (m.type == NLPS_MAT_NEO_HOOKEAN && !strcmp(k, "Fbar-alpha")) {
+      } else if (dp && !strcmp(k, "m")) m.exponent_ortiz = v;
+      else if (dp && !strcmp(k, "Hardening-modulus")) H = v;
+      else if (dp && !strcmp(k, "Reference-pressure")) m.p_ref = v;
+      else if (dp && !strcmp(k, "Reference-plastic-strain")) m.eps_0 = v, has_eps0 = true;
+      else if (dp && !strcmp(k, "kappa-0")) m.kappa_0 = v;
+      else if (dp && !strcmp(k, "Friction-angle")) m.phi_deg = v, has_phi = true;
+      else if (dp && !strcmp(k, "Dilatancy-angle")) m.psi_deg = v, has_psi = true;
+      else if (dp && !strcmp(k, "J2-degradated")) {
+      } else if (vm && !strcmp(k, "Yield-stress")) m.kappa_0 = v, has_yield = true;
+      else if (vm && !strcmp(k, "Hardening-Modulus")) m.hardening_modulus = v;
+      else if (vm && !strcmp(k, "theta")) m.theta_voce = v;
+      else if (vm && !strcmp(k, "K-0")) m.K0_voce = v;
+      else if (vm && !strcmp(k, "K-inf")) m.Kinf_voce = v;
+      else if (vm && !strcmp(k, "delta")) m.delta_voce = v;
+      else return fail(who + ": Undefined " + k);
+    }
+    (void)open;  // the reference notes the opening brace and never asks for it either
+    if (!(has_rho && has_E && has_nu)) return fail(who + ": rho, E and nu are required");
+    if (fbar) return fail(who + ": Fbar needs the quadratic-triangle patches this path does not cover");
+    if (m.type == NLPS_MAT_DRUCKER_PRAGER) {
+      if (!(has_phi && has_psi)) return fail(who + ": Friction-angle and Dilatancy-angle are required");
+      const double mo = m.exponent_ortiz;
+      if (!((mo > 0 && H > 0) || (mo < 0 && H < 0))) return fail(who + ": m and Hardening-modulus must have one sign");
+      if (!has_eps0) m.eps_0 = (m.kappa_0 / (mo * H)) * std::pow(1, (1.0 / mo - 1.0));  // Drucker-Prager.c:200-209
+    }
+    if (m.type == NLPS_MAT_VON_MISES && !has_yield) return fail(who + ": Yield-stress is required");
+    mats[*nmats] = m;
+    rho[*nmats] = r;
+    if (idx) idx[*nmats] = id;
+    (*nmats)++;
+  }
+  return 0;
+}

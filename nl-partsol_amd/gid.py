@@ -155,3 +155,19 @@ def read_deck(path):
         v = getattr(d, name)
         out[name] = v.decode() if isinstance(v, bytes) else v
     return out
+
+
+def read_materials(path, max_materials=16):
+    """The Define-Material blocks of a command file -> list of (idx, rho, material dict as nlps.Solver takes it)."""
+    mats = (_nlps.Material * max_materials)()
+    rho = (C.c_double * max_materials)()
+    idx = (C.c_int * max_materials)()
+    n = C.c_int(0)
+    f = _nlps.lib().nlps_host_read_materials
+    f.argtypes = [C.c_char_p, C.c_int, C.POINTER(_nlps.Material), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                  C.POINTER(C.c_int)]
+    _check(f(str(path).encode(), max_materials, mats, rho, idx, C.byref(n)), "nlps_host_read_materials")
+    out = []
+    for i in range(n.value):
+        out.append((idx[i], rho[i], {k: getattr(mats[i], k) for k, _ in _nlps.Material._fields_}))
+    return out

@@ -421,3 +421,73 @@ def test_command_file_subset(tmp_path):
             gid.read_deck(p)
     with pytest.raises(E, match="cannot open"):
         gid.read_deck(tmp_path / "none.nlp")
+
+
+MATERIALS = """Define-Material(idx=0,Model=Neo-Hookean-Wriggers)
+{
+\trho=1000
+\tE=1.0e7
+\tnu = 0.3
+\tCeps=1.5
+}
+Define-Material(idx=1,Model=Drucker-Prager)
+{
+  rho=1600
+  E=1.0e4
+  nu=0.2
+  m=1.0
+  Hardening-modulus=0.1
+  Reference-pressure=-20.0
+  kappa-0=40.0
+  Friction-angle=39.0
+  Dilatancy-angle=6.0
+}
+Define-Material(idx=2,Model=Von-Mises)
+{
+  rho=7800
+  E=1.0e4
+  nu=0.3
+  Yield-stress=30.0
+  Hardening-Modulus=400.0
+  K-0=30.0
+  K-inf=45.0
+  delta=12.0
+}
+Define-Material(idx=3,Model=Hencky)
+{
+  rho=1000
+  E=2.0e6
+  nu=0.25
+}
+"""
+
+
+def test_define_material_blocks(tmp_path):
+    """Define-Material for the four laws of the path (Read_GramsMaterials2.c:51-175 and the readers under
+    InOutFun/Material): values, the reference's defaults (D-P reference plastic strain kappa_0/(m H),
+    Drucker-Prager.c:200-209; Von-Mises theta = 1, Von-Mises.c:70-75), completeness checks, and models this path does
+    not cover as failures.  The D-P block is the material of the parity tests (synth.drucker_prager_material)."""
+    E = nlps().NlpsError
+    p = tmp_path / "run.nlp"
+    p.write_text(DECK + MATERIALS)
+    mats = gid.read_materials(p)
+    assert [(i, r, m["type"]) for i, r, m in mats] == [(0, 1000.0, 0), (1, 1600.0, 2), (2, 7800.0, 3), (3, 1000.0, 1)]
+    assert (mats[0][2]["E"], mats[0][2]["nu"]) == (1.0e7, 0.3)
+    dp, ref = mats[1][2], synth.drucker_prager_material()
+    for k in ("type", "E", "nu", "phi_deg", "psi_deg", "kappa_0", "exponent_ortiz", "eps_0", "p_ref"):
+        assert dp[k] == ref[k], k
+    vm, vref = mats[2][2], synth.von_mises_material()
+    assert vm["theta_voce"] == 1.0  # default
+    for k in ("E", "nu", "kappa_0", "hardening_modulus", "K0_voce", "Kinf_voce", "delta_voce"):
+        assert vm[k] == vref[k], k
+    gid.read_deck(p)  # the material blocks do not disturb the other reader
+    for bad, msg in ((MATERIALS.replace("  Yield-stress=30.0\n", ""), "Yield-stress is required"),
+                     (MATERIALS.replace("  m=1.0\n", ""), "must have one sign"),
+                     (MATERIALS.replace("Model=Hencky", "Model=Matsuoka-Nakai"), "not one of the laws"),
+                     (MATERIALS.replace("\tCeps=1.5\n", "\tFbar=true\n"), "Fbar needs"),
+                     (MATERIALS.replace("  nu=0.25\n}", "  nu=0.25\n"), "not closed"),
+                     (MATERIALS.replace("  nu=0.25\n", ""), "rho, E and nu are required"),
+                     (MATERIALS.replace("K-inf=45.0", "Kinf=45.0"), "Undefined Kinf")):
+        p.write_text(bad)
+        with pytest.raises(E, match=msg):
+            gid.read_materials(p)
