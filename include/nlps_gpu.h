@@ -346,6 +346,13 @@ int nlps_host_read_deck(const char *path, nlps_deck *deck);
  * model, or Fbar = true, is an error: this path does not cover them. */
 int nlps_host_read_materials(const char *path, int max_materials, nlps_material *mats, double *rho, int *idx,
                              int *nmats);
+/* The Dirichlet boundaries of the same file, GramsBoundary (File=nodes.txt) { BcDirichlet V.x curve.txt | NULL ... }
+ * (NLPS-Read-u-Dirichlet-Boundary-Conditions.c:46-300, File2Chain.c, ReadCurve.c with its six curve kinds), in the
+ * layout of nlps_bcc: boundary b has nnodes[b] nodes (concatenated in nodes[], in the reference's reversed file
+ * order and in FILE numbering: map them through canon[] of nlps_host_lattice_from_nodes), dir and value
+ * [b][ndim][nsteps].  With nodes / dir / value NULL only the counts come back (*nbounds, and nnodes[] if given). */
+int nlps_host_read_boundaries(const char *path, int ndim, int nsteps, int max_bounds, int node_cap, int *nbounds,
+                              int *nnodes, int *nodes, int *dir, double *value);
 
 /* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
  * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in

@@ -4,6 +4,7 @@
 // and of initialize__LME__'s element search, Nodes/LME.c:63-115), and the particles a body mesh generates
 // (InOutFun/Analysis/Generate-One-Phase-Analysis.c:569-625, Particles/Particles-Tools.c:8-28, Nodes/T3.c:337-440,
 // Nodes/Q4.c:342-452, Nodes/T4.c:322-420, Nodes/H8.c:389-575).  No GPU, no torch; entry points declared in include/nlps_gpu.h.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -734,5 +735,121 @@ extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlp
     if (idx) idx[*nmats] = id;
     (*nmats)++;
   }
+  return 0;
+}
+
+// ---- Dirichlet boundaries of the command file ------------------------------------------------------------------------
+//   GramsBoundary (File=nodes.txt) { BcDirichlet V.x curve.txt | NULL ... }
+// (Boundary-Conditions/NLPS-Read-u-Dirichlet-Boundary-Conditions.c:46-300): the node list is one id per line
+// (File2Chain.c: first word of every line, pushed, so the list runs in REVERSED file order), every direction with a
+// curve is active for the first min(NumTimeStep, curve.Num) steps (active_direction, :367-371) and carries the
+// curve's values.  Curves: ReadCurve.c (DAT_CURVE NUM#n, then CONSTANT_CURVE SCALE#s | RAMP_CURVE SCALE#s |
+// HEAVISIDE_CURVE SCALE#s Tc#t | DELTA_CURVE SCALE#s Tc#t | HAT_CURVE SCALE#s T0#a T1#b | CUSTOM_CURVE + n lines).
+namespace {
+int read_curve(const std::string& file, std::vector<double>& fx) {
+  LineReader in(file.c_str());
+  if (!in.f) return fail("ReadCurve: during the lecture of " + file);
+  fx.clear();
+  std::vector<char*> w, a, b, c;
+  auto kv = [&](char* word, std::vector<char*>& out, const char* key) {
+    return tokens(word, "#\r\n", out) == 2 && !strcmp(out[0], key);
+  };
+  while (in.next()) {
+    if (tokens(in.buf.data(), " \r\n\t", w) < 1) continue;
+    const int n = (int)fx.size();
+    if (!strcmp(w[0], "DAT_CURVE")) {
+      for (size_t i = 1; i < w.size(); i++)
+        if (kv(w[i], a, "NUM")) fx.assign((size_t)std::max(0, atoi(a[1])), 0.0);
+    } else if (!strcmp(w[0], "CUSTOM_CURVE")) {
+      for (int i = 0; i < n && in.next(); i++)
+        if (tokens(in.buf.data(), " \r\n\t", a) > 0) fx[i] += atof(a[0]);
+    } else if (!strcmp(w[0], "CONSTANT_CURVE")) {
+      if (w.size() < 2 || !kv(w[1], a, "SCALE")) return fail("fill_ConstantCurve: Wrong parameters");
+      for (int i = 0; i < n; i++) fx[i] += atof(a[1]);
+    } else if (!strcmp(w[0], "RAMP_CURVE")) {
+      if (w.size() < 2 || !kv(w[1], a, "SCALE")) return fail("fill_RampCurve: Wrong parameters");
+      for (int i = 0; i < n; i++) fx[i] = atof(a[1]) * (double)i / n;
+    } else if (!strcmp(w[0], "HEAVISIDE_CURVE") || !strcmp(w[0], "DELTA_CURVE")) {
+      if (w.size() < 3 || !kv(w[1], a, "SCALE") || !kv(w[2], b, "Tc")) return fail(std::string(w[0]) + ": Wrong parameters");
+      const double s = atof(a[1]);
+      const int tc = atoi(b[1]);
+      if (tc > n || tc < 0) return fail(std::string(w[0]) + ": Tc outside the curve");
+      const bool step = !strcmp(w[0], "HEAVISIDE_CURVE");
+      for (int i = 0; i < n; i++) fx[i] += step ? (i <= tc ? 0.0 : s) : (i == tc ? s : 0.0);
+    } else if (!strcmp(w[0], "HAT_CURVE")) {
+      if (w.size() < 4 || !kv(w[1], a, "SCALE") || !kv(w[2], b, "T0") || !kv(w[3], c, "T1")) return fail("fill_HatCurve: Wrong parameters");
+      const int t0 = atoi(b[1]), t1 = atoi(c[1]);
+      if (t0 > t1 || t1 > n || t0 < 0) return fail("fill_HatCurve: T0, T1 outside the curve");
+      // as written (ReadCurve.c:433-441) the hat never comes down: (i >= T0) || (i <= T1) holds for every i >= T0
+      for (int i = 0; i < n; i++) fx[i] += i < t0 ? 0.0 : atof(a[1]);
+    }
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps, int max_bounds, int node_cap,
+                                         int* nbounds, int* nnodes, int* nodes, int* dir, double* value) {
+  if (!path || !nbounds || (ndim != 2 && ndim != 3) || nsteps < 1) return fail("bad argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  const std::string route = dir_of(path);
+  const bool fill = nnodes && nodes && dir && value;  // nnodes alone: only the node counts are wanted
+  *nbounds = 0;
+  int used = 0;
+  std::vector<char*> w, kv;
+  std::vector<double> fx;
+  while (in.next()) {
+    if (tokens(in.buf.data(), " ,()\r\n\t", w) < 1 || strcmp(w[0], "GramsBoundary")) continue;
+    if (w.size() < 2 || tokens(w[1], "=", kv) != 2 || strcmp(kv[0], "File"))
+      return fail("GramsBoundary: use this format -> GramsBoundary (File=Nodes.txt)");
+    const int b = *nbounds;
+    if (nnodes && b >= max_bounds) return fail("GramsBoundary: more boundaries than the caller has room for");
+    // File2Chain: first word of every line; the chain, and with it the node array, is in reversed file order
+    std::vector<int> ids;
+    {
+      LineReader nf((route + kv[1]).c_str());
+      if (!nf.f) return fail("File2Chain: Incorrect lecture of " + route + kv[1]);
+      std::vector<char*> t;
+      while (nf.next())
+        if (tokens(nf.buf.data(), " \r\n\t", t) > 0) ids.push_back(atoi(t[0]));
+    }
+    if (nnodes) nnodes[b] = (int)ids.size();
+    if (fill) {
+      if (used + (int)ids.size() > node_cap) return fail("GramsBoundary: more boundary nodes than the caller has room for");
+      for (size_t i = 0; i < ids.size(); i++) nodes[used + (int)i] = ids[ids.size() - 1 - i];
+      for (int k = 0; k < ndim * nsteps; k++) {
+        dir[(size_t)b * ndim * nsteps + k] = 0;
+        value[(size_t)b * ndim * nsteps + k] = 0.0;
+      }
+    }
+    used += (int)ids.size();
+    bool closed = false;
+    while (!closed) {
+      if (!in.next()) return fail("GramsBoundary: the block is not closed");
+      const int n = tokens(in.buf.data(), " =\t\r\n", w);
+      if (n == 0) continue;
+      if (n == 1 && !strcmp(w[0], "{")) continue;
+      if (n == 1 && !strcmp(w[0], "}")) {
+        closed = true;
+      } else if (n == 3 && !strcmp(w[0], "BcDirichlet")) {
+        const int k = !strcmp(w[1], "V.x") ? 0 : !strcmp(w[1], "V.y") ? 1 : !strcmp(w[1], "V.z") ? 2 : -1;
+        if (k < 0) return fail(std::string("GramsBoundary: Velocity component ") + w[1] + " is not available");
+        if (!strcmp(w[2], "NULL") || k >= ndim) continue;
+        if (read_curve(route + w[2], fx)) return 1;
+        if (fill) {
+          const int na = std::min(nsteps, (int)fx.size());
+          for (int t = 0; t < na; t++) {
+            dir[((size_t)b * ndim + k) * nsteps + t] = 1;
+            value[((size_t)b * ndim + k) * nsteps + t] = fx[t];
+          }
+        }
+      } else {
+        return fail(std::string("GramsBoundary: undefined property ") + w[0]);
+      }
+    }
+    (*nbounds)++;
+  }
+  (void)used;
   return 0;
 }

@@ -171,3 +171,28 @@ def read_materials(path, max_materials=16):
     for i in range(n.value):
         out.append((idx[i], rho[i], {k: getattr(mats[i], k) for k, _ in _nlps.Material._fields_}))
     return out
+
+
+def read_boundaries(path, ndim, nsteps):
+    """The GramsBoundary blocks of a command file -> list of dicts in the layout nlps.BccSet takes (nodes in FILE
+    numbering and in the reference's reversed file order: map them through canon of lattice_from_nodes)."""
+    f = _nlps.lib().nlps_host_read_boundaries
+    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)] + [C.c_void_p] * 4
+    nb = C.c_int(0)
+    _check(f(str(path).encode(), ndim, nsteps, 0, 0, C.byref(nb), None, None, None, None), "nlps_host_read_boundaries")
+    if nb.value == 0:
+        return []
+    cnt = np.zeros(nb.value, dtype=np.int32)
+    _check(f(str(path).encode(), ndim, nsteps, nb.value, 0, C.byref(nb), cnt.ctypes.data, None, None, None),
+           "nlps_host_read_boundaries")
+    total = int(cnt.sum())
+    nodes = np.zeros(max(total, 1), dtype=np.int32)
+    dirs = np.zeros((nb.value, ndim, nsteps), dtype=np.int32)
+    vals = np.zeros((nb.value, ndim, nsteps))
+    _check(f(str(path).encode(), ndim, nsteps, nb.value, total, C.byref(nb), cnt.ctypes.data, nodes.ctypes.data,
+             dirs.ctypes.data, vals.ctypes.data), "nlps_host_read_boundaries")
+    out, at = [], 0
+    for b in range(nb.value):
+        out.append({"nodes": nodes[at:at + cnt[b]].copy(), "dim": ndim, "dir": dirs[b].copy(), "value": vals[b].copy()})
+        at += cnt[b]
+    return out

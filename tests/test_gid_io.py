@@ -491,3 +491,57 @@ def test_define_material_blocks(tmp_path):
         p.write_text(bad)
         with pytest.raises(E, match=msg):
             gid.read_materials(p)
+
+
+def test_dirichlet_boundaries_and_curves(tmp_path):
+    """GramsBoundary blocks (NLPS-Read-u-Dirichlet-Boundary-Conditions.c:46-300): node lists through File2Chain
+    (first word per line, reversed), active directions for min(NumTimeStep, curve.Num) steps, and the curve kinds of
+    ReadCurve.c rebuilt here from its fill_* loops (the hat that never comes down included)."""
+    E = nlps().NlpsError
+    (tmp_path / "bottom.txt").write_text("4\n7 extra words are ignored\n9\n12\n")
+    (tmp_path / "side.txt").write_text("3\n1\n")
+    (tmp_path / "const.txt").write_text("DAT_CURVE NUM#6\nCONSTANT_CURVE SCALE#0.0\n")
+    (tmp_path / "ramp.txt").write_text("DAT_CURVE NUM#4\nRAMP_CURVE SCALE#2.0\n")
+    (tmp_path / "heavi.txt").write_text("DAT_CURVE NUM#8\nHEAVISIDE_CURVE SCALE#-1.5 Tc#2\n")
+    (tmp_path / "delta.txt").write_text("DAT_CURVE NUM#8\nDELTA_CURVE SCALE#3.0 Tc#5\n")
+    (tmp_path / "hat.txt").write_text("DAT_CURVE NUM#8\nHAT_CURVE SCALE#1.0 T0#2 T1#4\n")
+    (tmp_path / "custom.txt").write_text("DAT_CURVE NUM#3\nCUSTOM_CURVE\n0.5\n-0.25\n4\n")
+    deck = tmp_path / "run.nlp"
+    deck.write_text("""GramsBox (Type=GID,File=box.msh) {
+  GramsBoundary (File=bottom.txt) {
+    BcDirichlet V.x const.txt
+    BcDirichlet V.y ramp.txt
+    BcDirichlet V.z NULL
+  }
+  GramsBoundary (File=side.txt)
+  {
+    BcDirichlet V.x heavi.txt
+    BcDirichlet V.y delta.txt
+    BcDirichlet V.z hat.txt
+  }
+}
+""")
+    nsteps = 6
+    b = gid.read_boundaries(deck, 3, nsteps)
+    assert len(b) == 2
+    assert list(b[0]["nodes"]) == [12, 9, 7, 4] and list(b[1]["nodes"]) == [1, 3]
+    assert np.array_equal(b[0]["dir"], [[1] * 6, [1, 1, 1, 1, 0, 0], [0] * 6])
+    assert np.array_equal(b[0]["value"], [[0.0] * 6, [0.0, 0.5, 1.0, 1.5, 0, 0], [0.0] * 6])
+    assert np.array_equal(b[1]["dir"], np.ones((3, 6), dtype=int))
+    assert np.array_equal(b[1]["value"], [[0, 0, 0, -1.5, -1.5, -1.5], [0, 0, 0, 0, 0, 3.0], [0, 0, 1, 1, 1, 1]])
+    b2 = gid.read_boundaries(deck, 2, 3)  # the 2-D build has no V.z; fewer steps than curve values
+    assert b2[1]["value"].shape == (2, 3) and np.array_equal(b2[1]["value"][0], [0, 0, 0])
+    deck.write_text("GramsBoundary (File=side.txt) {\n BcDirichlet V.x custom.txt\n}\n")
+    c = gid.read_boundaries(deck, 2, 5)[0]
+    assert np.array_equal(c["value"][0], [0.5, -0.25, 4.0, 0, 0]) and list(c["dir"][0]) == [1, 1, 1, 0, 0]
+    # a BccSet of the solver takes them as they are (node ids through canon in a real run)
+    nlps().BccSet(b)
+    for text, msg in (("GramsBoundary (Nodes=side.txt) {\n}\n", "File=Nodes.txt"),
+                      ("GramsBoundary (File=side.txt) {\n BcDirichlet V.w const.txt\n}\n", "V.w is not available"),
+                      ("GramsBoundary (File=side.txt) {\n BcDirichlet V.x none.txt\n}\n", "ReadCurve"),
+                      ("GramsBoundary (File=none.txt) {\n}\n", "File2Chain"),
+                      ("GramsBoundary (File=side.txt) {\n BcDirichlet V.x const.txt\n", "not closed")):
+        deck.write_text(text)
+        with pytest.raises(E, match=msg):
+            gid.read_boundaries(deck, 3, 4)
+    assert gid.read_boundaries(tmp_path / "ramp.txt", 3, 4) == []

@@ -1195,9 +1195,10 @@ def test_maximum_size_8m_particles():
 
 @pytest.mark.parametrize("ndim", [2, 3])
 def test_run_from_gid_mesh_files(tmp_path, ndim):
-    """Input side: a background mesh file with shuffled node numbers and a distorted body mesh, read
-    by the host helpers of csrc/nlps_io.cpp, drive the HIP path; the oracle runs the same arrays.  The Dirichlet
-    nodes are given in FILE numbering and travel through the canon map of nlps_host_lattice_from_nodes."""
+    """Input side: a command file naming a background mesh with shuffled node numbers, a distorted body
+    mesh, a material and a Dirichlet boundary, read by the host helpers of csrc/nlps_io.cpp, drives the HIP path; the
+    oracle runs the same arrays.  The Dirichlet nodes are given in FILE numbering and travel through the canon map of
+    nlps_host_lattice_from_nodes."""
     import importlib
     import test_gid_io as tg
     gid = importlib.import_module("nl-partsol_amd.gid")
@@ -1215,16 +1216,33 @@ def test_run_from_gid_mesh_files(tmp_path, ndim):
     bc_ = bc_ + rng.uniform(-0.08, 0.08, size=bc_.shape)
     tg.write_gid(tmp_path / "body.msh", ndim, etype, bc_, bconn)
 
-    box = gid.read_gid_mesh(tmp_path / "box.msh")
-    h, gn, origin, canon = gid.lattice_from_nodes(box["coords"])
-    cloud = gid.cloud_from_mesh(gid.read_gid_mesh(tmp_path / "body.msh"), 4 if ndim == 2 else 8, rho=1000.0,
-                                velocity=[0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0])
-    case = {"ndim": ndim, "cells": cells, "grid_n": gn, "origin": origin, "h": h, "cloud": cloud, "materials": [NH]}
+    # the command file around them: solver, shape function, material, one Dirichlet boundary with constant curves
     nsteps = 4
-    plane_file = np.nonzero(box["coords"][:, ndim - 1] == 2.0)[0]  # file numbering
-    bcs = [{"nodes": np.sort(canon[plane_file]).astype(np.int32), "dim": ndim,
-            "dir": np.ones((ndim, nsteps), dtype=np.int32), "value": np.zeros((ndim, nsteps))}]
-    assert np.array_equal(bcs[0]["nodes"], dirichlet_plane(case, ndim - 1, 2, nsteps)["nodes"])
+    plane_file = np.nonzero(bg_coords[:, ndim - 1] == 2.0)[0]  # file numbering, 0-based (File2Chain)
+    (tmp_path / "floor.txt").write_text("".join("%d\n" % i for i in plane_file))
+    (tmp_path / "zero.txt").write_text("DAT_CURVE NUM#%d\nCONSTANT_CURVE SCALE#0.0\n" % nsteps)
+    (tmp_path / "run.nlp").write_text(
+        "GramsBox (Type=GID,File=box.msh) {\n  GramsBoundary (File=floor.txt) {\n"
+        + "".join("    BcDirichlet V.%s zero.txt\n" % "xyz"[a] for a in range(ndim)) + "  }\n}\n"
+        + "One-Phase-Analysis (File=body.msh, GPxElement=%d) {\n}\n" % (4 if ndim == 2 else 8)
+        + "GramsShapeFun (Type=LME) {\n  gamma=3.0\n}\n"
+        + "NLPS-Solver (Type=NPC-FS) {\n  CFL=0.1\n  Cel=100.0\n  N=%d\n}\n" % nsteps
+        + "Define-Material(idx=0,Model=Neo-Hookean-Wriggers)\n{\n  rho=1000.0\n  E=%r\n  nu=%r\n}\n" % (NH["E"], NH["nu"]))
+    deck = gid.read_deck(tmp_path / "run.nlp")
+    (_, rho, material), = gid.read_materials(tmp_path / "run.nlp")
+    assert (deck["N"], deck["shape_fun"], deck["gamma_lme"], material["type"]) == (nsteps, "LME", 3.0, 0)
+
+    box = gid.read_gid_mesh(deck["box_mesh"])
+    h, gn, origin, canon = gid.lattice_from_nodes(box["coords"])
+    cloud = gid.cloud_from_mesh(gid.read_gid_mesh(deck["body_mesh"]), deck["gp_per_elem"], rho=rho,
+                                velocity=[0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0])
+    case = {"ndim": ndim, "cells": cells, "grid_n": gn, "origin": origin, "h": h, "cloud": cloud,
+            "materials": [{k: material[k] for k in ("type", "E", "nu")}]}
+    bcs = gid.read_boundaries(tmp_path / "run.nlp", ndim, deck["N"])
+    for b in bcs:
+        b["nodes"] = np.sort(canon[b["nodes"]]).astype(np.int32)  # file -> library numbering
+    assert len(bcs) == 1 and np.array_equal(bcs[0]["nodes"], dirichlet_plane(case, ndim - 1, 2, nsteps)["nodes"])
+    assert np.array_equal(bcs[0]["dir"], np.ones((ndim, nsteps))) and not bcs[0]["value"].any()
     dt = 0.1 * h / np.sqrt(NH["E"] / 1000.0)
     M, P, prm, mats = oracle_setup(case)
     S = gpu_setup(case, nsteps=nsteps)
