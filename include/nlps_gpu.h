@@ -353,6 +353,10 @@ int nlps_host_read_materials(const char *path, int max_materials, nlps_material 
  * [b][ndim][nsteps].  With nodes / dir / value NULL only the counts come back (*nbounds, and nnodes[] if given). */
 int nlps_host_read_boundaries(const char *path, int ndim, int nsteps, int max_bounds, int node_cap, int *nbounds,
                               int *nnodes, int *nodes, int *dir, double *value);
+/* The initial velocities of the same file, GramsInitials (Nodes=list.txt) { Value=[vx,vy,vz] }
+ * (Read_GramsInitials.c:7-186): the list names ELEMENTS of the body mesh (0-based), all gp_per_elem particles of a
+ * listed element get the value.  vel[nparticles][ndim] is updated in place. */
+int nlps_host_read_initials(const char *path, int ndim, int gp_per_elem, int nparticles, double *vel);
 
 /* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
  * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in

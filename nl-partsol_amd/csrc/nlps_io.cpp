@@ -853,3 +853,47 @@ extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps,
   (void)used;
   return 0;
 }
+
+// GramsInitials (Nodes=list.txt) { Value=[vx,vy,vz] }  (Initial-Conditions/Read_GramsInitials.c:7-186): the list
+// holds ELEMENT ids of the body mesh (0-based, File2Chain), every particle e * GPxElement + j of a listed element
+// gets the velocity.  vel[nparticles][ndim] is updated in place; elements outside the cloud are an error here
+// (the reference writes out of bounds).
+extern "C" int nlps_host_read_initials(const char* path, int ndim, int gp_per_elem, int nparticles, double* vel) {
+  if (!path || !vel || (ndim != 2 && ndim != 3) || gp_per_elem < 1) return fail("bad argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  const std::string route = dir_of(path);
+  std::vector<char*> w, kv, val;
+  while (in.next()) {
+    if (tokens(in.buf.data(), " \r\n\t", w) < 1 || strcmp(w[0], "GramsInitials")) continue;
+    if (w.size() < 3 || tokens(w[1], "(=)", kv) != 2 || strcmp(kv[0], "Nodes"))
+      return fail("GramsInitials: Use this format -> (Nodes=str) !!!");
+    if (strcmp(w[2], "{")) return fail("GramsInitials: Use this format -> GramsInitials (Nodes=str) { !!!");
+    std::vector<int> ids;
+    {
+      LineReader nf((route + kv[1]).c_str());
+      if (!nf.f) return fail("File2Chain: Incorrect lecture of " + route + kv[1]);
+      std::vector<char*> t;
+      while (nf.next())
+        if (tokens(nf.buf.data(), " \r\n\t", t) > 0) ids.push_back(atoi(t[0]));
+    }
+    bool any = false;
+    while (true) {
+      if (!in.next()) return fail("GramsInitials: you forget to put a } !!!");
+      const int n = tokens(in.buf.data(), " =\t\r\n", kv);
+      if (n > 0 && !strcmp(kv[0], "}")) break;
+      if (n == 0) continue;
+      if (n != 2) return fail("GramsInitials: Use this format -> Propertie = value !!!");
+      if (strcmp(kv[0], "Value")) return fail(std::string("GramsInitials: Undefined ") + kv[0]);
+      if (tokens(kv[1], "[,]", val) != ndim) return fail("GramsInitials: Use this format -> Value=[vx,vy,vz] with one entry per dimension");
+      for (int e : ids) {
+        if (e < 0 || (long long)(e + 1) * gp_per_elem > nparticles) return fail("GramsInitials: element " + std::to_string(e) + " is outside the particle set");
+        for (int j = 0; j < gp_per_elem; j++)
+          for (int k = 0; k < ndim; k++) vel[((size_t)e * gp_per_elem + j) * ndim + k] = atof(val[k]);
+      }
+      any = true;
+    }
+    if (!any) return fail("GramsInitials: Undefined initial condition !!!");
+  }
+  return 0;
+}

@@ -196,3 +196,12 @@ def read_boundaries(path, ndim, nsteps):
         out.append({"nodes": nodes[at:at + cnt[b]].copy(), "dim": ndim, "dir": dirs[b].copy(), "value": vals[b].copy()})
         at += cnt[b]
     return out
+
+
+def read_initials(path, gp_per_elem, vel):
+    """Applies the GramsInitials blocks of a command file to vel[nparticles][ndim] (in place) and returns it."""
+    vel = np.ascontiguousarray(vel, dtype=np.float64)
+    f = _nlps.lib().nlps_host_read_initials
+    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _check(f(str(path).encode(), vel.shape[1], int(gp_per_elem), vel.shape[0], vel.ctypes.data), "nlps_host_read_initials")
+    return vel

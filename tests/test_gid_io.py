@@ -545,3 +545,26 @@ def test_dirichlet_boundaries_and_curves(tmp_path):
         with pytest.raises(E, match=msg):
             gid.read_boundaries(deck, 3, 4)
     assert gid.read_boundaries(tmp_path / "ramp.txt", 3, 4) == []
+
+
+def test_initial_velocities(tmp_path):
+    """GramsInitials (Read_GramsInitials.c:7-186): the list names elements of the body mesh; every particle
+    e * GPxElement + j of a listed element gets the value; later blocks overwrite earlier ones."""
+    E = nlps().NlpsError
+    (tmp_path / "all.txt").write_text("0\n1\n2\n3\n")
+    (tmp_path / "top.txt").write_text("3\n2\n")
+    deck = tmp_path / "run.nlp"
+    deck.write_text("GramsInitials (Nodes=all.txt) {\n  Value=[1.5,-2.0]\n}\nGramsInitials (Nodes=top.txt) {\n  Value=[0.0,-10.0]\n}\n")
+    vel = gid.read_initials(deck, 4, np.zeros((16, 2)))
+    assert np.array_equal(vel[:8], np.tile([1.5, -2.0], (8, 1))) and np.array_equal(vel[8:], np.tile([0.0, -10.0], (8, 1)))
+    for text, msg in (("GramsInitials (Elements=all.txt) {\n Value=[1,2]\n}\n", "Nodes=str"),
+                      ("GramsInitials (Nodes=all.txt) {\n Value=[1,2,3]\n}\n", "one entry per dimension"),
+                      ("GramsInitials (Nodes=all.txt) {\n Speed=[1,2]\n}\n", "Undefined Speed"),
+                      ("GramsInitials (Nodes=all.txt) {\n}\n", "Undefined initial condition"),
+                      ("GramsInitials (Nodes=all.txt) {\n Value=[1,2]\n", "forget to put a }")):
+        deck.write_text(text)
+        with pytest.raises(E, match=msg):
+            gid.read_initials(deck, 4, np.zeros((16, 2)))
+    deck.write_text("GramsInitials (Nodes=all.txt) {\n Value=[1,2]\n}\n")
+    with pytest.raises(E, match="outside the particle set"):
+        gid.read_initials(deck, 4, np.zeros((12, 2)))

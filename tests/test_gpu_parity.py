@@ -1227,15 +1227,18 @@ def test_run_from_gid_mesh_files(tmp_path, ndim):
         + "One-Phase-Analysis (File=body.msh, GPxElement=%d) {\n}\n" % (4 if ndim == 2 else 8)
         + "GramsShapeFun (Type=LME) {\n  gamma=3.0\n}\n"
         + "NLPS-Solver (Type=NPC-FS) {\n  CFL=0.1\n  Cel=100.0\n  N=%d\n}\n" % nsteps
-        + "Define-Material(idx=0,Model=Neo-Hookean-Wriggers)\n{\n  rho=1000.0\n  E=%r\n  nu=%r\n}\n" % (NH["E"], NH["nu"]))
+        + "Define-Material(idx=0,Model=Neo-Hookean-Wriggers)\n{\n  rho=1000.0\n  E=%r\n  nu=%r\n}\n" % (NH["E"], NH["nu"])
+        + "GramsInitials (Nodes=body_elements.txt) {\n  Value=[%s]\n}\n" % ",".join(["0.0"] * (ndim - 1) + ["-10.0"]))
+    (tmp_path / "body_elements.txt").write_text("".join("%d\n" % e for e in range(len(bconn))))
     deck = gid.read_deck(tmp_path / "run.nlp")
     (_, rho, material), = gid.read_materials(tmp_path / "run.nlp")
     assert (deck["N"], deck["shape_fun"], deck["gamma_lme"], material["type"]) == (nsteps, "LME", 3.0, 0)
 
     box = gid.read_gid_mesh(deck["box_mesh"])
     h, gn, origin, canon = gid.lattice_from_nodes(box["coords"])
-    cloud = gid.cloud_from_mesh(gid.read_gid_mesh(deck["body_mesh"]), deck["gp_per_elem"], rho=rho,
-                                velocity=[0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0])
+    cloud = gid.cloud_from_mesh(gid.read_gid_mesh(deck["body_mesh"]), deck["gp_per_elem"], rho=rho)
+    cloud["vel"] = gid.read_initials(tmp_path / "run.nlp", deck["gp_per_elem"], cloud["vel"])
+    assert np.array_equal(cloud["vel"][:, ndim - 1], np.full(len(cloud["vel"]), -10.0))
     case = {"ndim": ndim, "cells": cells, "grid_n": gn, "origin": origin, "h": h, "cloud": cloud,
             "materials": [{k: material[k] for k in ("type", "E", "nu")}]}
     bcs = gid.read_boundaries(tmp_path / "run.nlp", ndim, deck["N"])
