@@ -357,6 +357,10 @@ int nlps_host_read_boundaries(const char *path, int ndim, int nsteps, int max_bo
  * (Read_GramsInitials.c:7-186): the list names ELEMENTS of the body mesh (0-based), all gp_per_elem particles of a
  * listed element get the value.  vel[nparticles][ndim] is updated in place. */
 int nlps_host_read_initials(const char *path, int ndim, int gp_per_elem, int nparticles, double *vel);
+/* The gravity field of the same file, generate-gravity-field-constant { g.x = .. } or generate-gravity-field-curve
+ * { g = file.csv } (Read_Generate_Gravity_Field.c:170-371): g[nsteps][ndim], row t is the gravity argument of
+ * nlps_gpu_explicit_step at step t; *found (may be NULL) tells whether the file holds such a block. */
+int nlps_host_read_gravity(const char *path, int ndim, int nsteps, double *g, int *found);
 
 /* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
  * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in

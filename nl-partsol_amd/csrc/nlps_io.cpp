@@ -897,3 +897,47 @@ extern "C" int nlps_host_read_initials(const char* path, int ndim, int gp_per_el
   }
   return 0;
 }
+
+// generate-gravity-field-constant { g.x = .. g.y = .. g.z = .. } and generate-gravity-field-curve { g = file.csv }
+// (Read_Generate_Gravity_Field.c:170-371): the gravity vector of every time step, g[nsteps][ndim] (the argument of
+// nlps_gpu_explicit_step per step).  The csv holds one "gx,gy[,gz]" line per step and is opened by the name as written
+// (the reference does not join it to the directory of the command file).  No block: zeros, *found = 0.
+extern "C" int nlps_host_read_gravity(const char* path, int ndim, int nsteps, double* g, int* found) {
+  if (!path || !g || (ndim != 2 && ndim != 3) || nsteps < 1) return fail("bad argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  for (int k = 0; k < nsteps * ndim; k++) g[k] = 0.0;
+  if (found) *found = 0;
+  std::vector<char*> w, col;
+  int kind = 0;
+  while (!kind && in.next()) {
+    if (tokens(in.buf.data(), " \r\n\t", w) < 1) continue;
+    if (!strcmp(w[0], "generate-gravity-field-constant")) kind = 1;
+    else if (!strcmp(w[0], "generate-gravity-field-curve")) kind = 2;
+  }
+  if (!kind) return 0;
+  if (found) *found = 1;
+  bool open = false, closed = false;
+  while (!closed && in.next()) {
+    const int n = tokens(in.buf.data(), "= \r\n\t", w);
+    if (n < 1) continue;
+    if (!strcmp(w[0], "{")) open = true;
+    else if (open && !strcmp(w[0], "}")) closed = true;
+    else if (open && kind == 1 && n > 1) {
+      const int a = !strcmp(w[0], "g.x") ? 0 : !strcmp(w[0], "g.y") ? 1 : !strcmp(w[0], "g.z") ? 2 : -1;
+      if (a >= 0 && a < ndim)
+        for (int t = 0; t < nsteps; t++) g[(size_t)t * ndim + a] = atof(w[1]);
+    } else if (open && kind == 2 && n > 1 && !strcmp(w[0], "g")) {
+      LineReader csv(w[1]);
+      if (!csv.f) return fail(std::string("gravity field: ") + w[1] + " is not a file");
+      for (int t = 0; t < nsteps; t++) {
+        if (!csv.next()) return fail(std::string("gravity field: ") + w[1] + " ends before step " + std::to_string(t + 1));
+        if (tokens(csv.buf.data(), ",\r\n", col) != ndim)
+          return fail(std::string("gravity field: ") + w[1] + ": wrong number of columns in line " + std::to_string(t + 1));
+        for (int a = 0; a < ndim; a++) g[(size_t)t * ndim + a] = atof(col[a]);
+      }
+    }
+  }
+  if (!open || !closed) return fail("gravity field: the block needs its braces");
+  return 0;
+}

@@ -205,3 +205,13 @@ def read_initials(path, gp_per_elem, vel):
     f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _check(f(str(path).encode(), vel.shape[1], int(gp_per_elem), vel.shape[0], vel.ctypes.data), "nlps_host_read_initials")
     return vel
+
+
+def read_gravity(path, ndim, nsteps):
+    """-> g[nsteps][ndim] of the gravity-field block of a command file, or None if it has none."""
+    g = np.zeros((nsteps, ndim))
+    found = C.c_int(0)
+    f = _nlps.lib().nlps_host_read_gravity
+    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    _check(f(str(path).encode(), ndim, nsteps, g.ctypes.data, C.byref(found)), "nlps_host_read_gravity")
+    return g if found.value else None

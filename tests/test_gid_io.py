@@ -568,3 +568,25 @@ def test_initial_velocities(tmp_path):
     deck.write_text("GramsInitials (Nodes=all.txt) {\n Value=[1,2]\n}\n")
     with pytest.raises(E, match="outside the particle set"):
         gid.read_initials(deck, 4, np.zeros((12, 2)))
+
+
+def test_gravity_field(tmp_path):
+    """generate-gravity-field-constant / -curve (Read_Generate_Gravity_Field.c:170-371)."""
+    E = nlps().NlpsError
+    deck = tmp_path / "run.nlp"
+    deck.write_text(DECK + "generate-gravity-field-constant\n{\n  g.x = 0.0\n  g.y=-9.81\n}\n")
+    g = gid.read_gravity(deck, 2, 5)
+    assert np.array_equal(g, np.tile([0.0, -9.81], (5, 1)))
+    csv = tmp_path / "g.csv"
+    csv.write_text("0,0,-1\n0,0,-2\n0.5,0,-3\n")
+    deck.write_text("generate-gravity-field-curve\n{\n  g = %s\n}\n" % csv)  # the brace on its own line, as the reference wants it
+    assert np.array_equal(gid.read_gravity(deck, 3, 3), [[0, 0, -1], [0, 0, -2], [0.5, 0, -3]])
+    with pytest.raises(E, match="ends before step 4"):
+        gid.read_gravity(deck, 3, 4)
+    with pytest.raises(E, match="wrong number of columns"):
+        gid.read_gravity(deck, 2, 3)
+    deck.write_text("generate-gravity-field-constant\n  g.y=-9.81\n")
+    with pytest.raises(E, match="needs its braces"):
+        gid.read_gravity(deck, 2, 3)
+    deck.write_text(DECK)
+    assert gid.read_gravity(deck, 2, 3) is None
