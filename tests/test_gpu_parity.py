@@ -5,7 +5,8 @@ fields, 1e-10 for nodal sums (atomics reorder them)."""
 import numpy as np
 import pytest
 
-from util import (DP, HENCKY, NH, VM, assert_close, dirichlet_plane, gpu_setup, make_case, nlps, oracle_setup, orc)
+from util import (DP, HENCKY, NH, VM, assert_close, dirichlet_plane, free_port, gpu_setup, make_case, nlps, oracle_setup,
+                  orc)
 
 pytestmark = pytest.mark.gpu
 
@@ -756,7 +757,7 @@ def test_halo_callback_and_rccl_on_library_memory():
     stream = torch.cuda.current_stream().cuda_stream
     S = gpu_setup(case, nsteps=3, stream=stream)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -837,7 +838,7 @@ def test_multirank_on_one_gpu(world, overlap, ndim):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29600 + (os.getpid() + world) % 300
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "mr_gpu_worker.py")]
     env = dict(os.environ, NLPS_OVERLAP=str(overlap), NLPS_NDIM=str(ndim))
@@ -899,7 +900,7 @@ def test_migration_between_ranks_on_one_gpu(world):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29700 + (os.getpid() + world) % 200
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "tests", "mr_gpu_migrate_worker.py")]
@@ -916,7 +917,7 @@ def test_bench_multi_rank_path_rehearsal():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29900 + os.getpid() % 90
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "2", "--cells", "16", "--no-cpu-baseline"]

@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from util import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CELLS, MARGIN, NX = 7, 4, 11
 
@@ -107,7 +109,7 @@ def _worker(rank, world, port, mode, out_dir):
 @pytest.mark.parametrize("world,mode", [(2, "p2p"), (3, "p2p"), (2, "allreduce")])
 def test_slab_partition_matches_single_process(world, mode, tmp_path):
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000) + world * 7 + (0 if mode == "p2p" else 3)
+    port = free_port()
     mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / ("rank%d.txt" % r)).read() == "OK"

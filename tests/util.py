@@ -81,3 +81,11 @@ def dirichlet_plane(case, axis, index, nsteps, dims=None, value=0.0):
     dirs = np.ones((d, nsteps), dtype=np.int32) if dims is None else np.asarray(dims, dtype=np.int32)
     vals = np.full((d, nsteps), value, dtype=np.float64)
     return {"nodes": nodes, "dim": d, "dir": dirs, "value": vals}
+
+
+def free_port():
+    """A TCP port nobody listens on right now (for torch.distributed rendezvous on 127.0.0.1)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
