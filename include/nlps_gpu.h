@@ -361,6 +361,18 @@ int nlps_host_read_initials(const char *path, int ndim, int gp_per_elem, int npa
  * { g = file.csv } (Read_Generate_Gravity_Field.c:170-371): g[nsteps][ndim], row t is the gravity argument of
  * nlps_gpu_explicit_step at step t; *found (may be NULL) tells whether the file holds such a block. */
 int nlps_host_read_gravity(const char *path, int ndim, int nsteps, double *g, int *found);
+/* The output block of the same file, GramsOutputs (i=int) { DIR=dir Particles-file=name Nodes-file=name Out-...=true|false }
+ * (Outputs/Read_GramsOutputs.c:25-345): interval, directory (joined to the command file's; it has to exist), file
+ * names, and the Out_* switches of the blocks nlps_host_write_particles_vtk writes; switches of other blocks are
+ * accepted and counted in `unsupported` when on.  found = 0 if the file has no such block. */
+typedef struct nlps_outputs {
+  int found, results_time_step;
+  char dir[512], particles_file[128], nodes_file[128];
+  int global_coordinates, mass, density, nodal_idx, material_idx, velocity, acceleration, displacement, stress,
+      volumetric_stress, deformation_gradient, energy, eps;
+  int unsupported;
+} nlps_outputs;
+int nlps_host_read_outputs(const char *path, nlps_outputs *out);
 
 /* ---- output format: the particle file of particle_results_vtk__InOutFun__ (InOutFun/Outputs/WriteVtk.c:95-266):
  * legacy ASCII VTK, one vertex cell per particle, numbers as %.20g, blocks in the reference's order.  Arrays are in

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "../../include/nlps_gpu.h"
 
 namespace {
@@ -939,5 +941,72 @@ extern "C" int nlps_host_read_gravity(const char* path, int ndim, int nsteps, do
     }
   }
   if (!open || !closed) return fail("gravity field: the block needs its braces");
+  return 0;
+}
+
+// GramsOutputs (i=int) { DIR=dir  Particles-file=name  Nodes-file=name  Out-...=true|false }
+// (Outputs/Read_GramsOutputs.c:25-345): output interval, directory (joined to the command file's, must exist), file
+// names and the Out_* switches.  The switches the particle writer of this library knows come back as the selection
+// nlps_host_write_particles_vtk understands; the others (water pressure, strains, damage ...) are accepted and
+// counted in `unsupported` when they are switched on.
+extern "C" int nlps_host_read_outputs(const char* path, nlps_outputs* o) {
+  if (!path || !o) return fail("null argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  memset(o, 0, sizeof(*o));
+  const std::string route = dir_of(path);
+  std::vector<char*> w, kv;
+  bool have_dir = false;
+  auto on = [&](const char* v, bool& bad) {
+    if (!strcmp(v, "true")) return 1;
+    if (!strcmp(v, "false")) return 0;
+    bad = true;
+    return 0;
+  };
+  while (in.next()) {
+    if (tokens(in.buf.data(), " \r\n\t", w) < 1 || strcmp(w[0], "GramsOutputs")) continue;
+    o->found = 1;
+    if (w.size() < 3 || tokens(w[1], "(=)", kv) != 2 || strcmp(kv[0], "i")) return fail("GramsOutputs: Use this format -> (i=int)");
+    o->results_time_step = atoi(kv[1]);
+    if (strcmp(w[2], "{")) return fail("GramsOutputs: Use this format -> GramsOutputs (Type=string) { ");
+    while (true) {
+      if (!in.next()) return fail("GramsOutputs: you forget to put a }");
+      const int n = tokens(in.buf.data(), " =\t\r\n", kv);
+      if (n > 0 && !strcmp(kv[0], "}")) break;
+      if (n == 0) continue;
+      if (n != 2) return fail("GramsOutputs: Use this format -> Propertie = value");
+      const char *k = kv[0], *v = kv[1];
+      bool bad = false;
+      if (!strcmp(k, "DIR")) {
+        snprintf(o->dir, sizeof(o->dir), "%s%s", route.c_str(), v);
+        struct stat info;  // Check_Output_directory, :333-341: it has to exist
+        have_dir = stat(o->dir, &info) == 0 && S_ISDIR(info.st_mode);
+      } else if (!strcmp(k, "Particles-file")) snprintf(o->particles_file, sizeof(o->particles_file), "%s", v);
+      else if (!strcmp(k, "Nodes-file")) snprintf(o->nodes_file, sizeof(o->nodes_file), "%s", v);
+      else if (!strcmp(k, "Out-global-coordinates")) o->global_coordinates = on(v, bad);
+      else if (!strcmp(k, "Out-mass")) o->mass = on(v, bad);
+      else if (!strcmp(k, "Out-density")) o->density = on(v, bad);
+      else if (!strcmp(k, "Out-nodal-idx")) o->nodal_idx = on(v, bad);
+      else if (!strcmp(k, "Out-material-idx")) o->material_idx = on(v, bad);
+      else if (!strcmp(k, "Out-velocity")) o->velocity = on(v, bad);
+      else if (!strcmp(k, "Out-acceleration")) o->acceleration = on(v, bad);
+      else if (!strcmp(k, "Out-displacement")) o->displacement = on(v, bad);
+      else if (!strcmp(k, "Out-stress")) o->stress = on(v, bad);
+      else if (!strcmp(k, "Out-volumetric-stress")) o->volumetric_stress = on(v, bad);
+      else if (!strcmp(k, "Out-deformation-gradient")) o->deformation_gradient = on(v, bad);
+      else if (!strcmp(k, "Out-energy")) o->energy = on(v, bad);
+      else if (!strcmp(k, "Out-Equivalent-Plastic-Strain")) o->eps = on(v, bad);
+      else if (!strcmp(k, "Out-element-coordinates") || !strcmp(k, "Out-damage") || !strcmp(k, "Out-eigenvalues-stress") ||
+               !strcmp(k, "Out-water-pressure") || !strcmp(k, "Out-Pore-water-pressure") ||
+               !strcmp(k, "Out-Rate-Pore-water-pressure") || !strcmp(k, "Out-strain") || !strcmp(k, "Out-eigenvalues-strain") ||
+               !strcmp(k, "Out-green-lagrange") || !strcmp(k, "Out-plastic-deformation-gradient") || !strcmp(k, "Out-Metric") ||
+               !strcmp(k, "Out-plastic-jacobian") || !strcmp(k, "Out-Von-Mises") || !strcmp(k, "Out-Check-Partition-Unity"))
+        o->unsupported += on(v, bad);
+      else return fail(std::string("GramsOutputs: the output ") + k + " is not available");
+      if (bad) return fail(std::string("GramsOutputs: the input was ") + v + ". Please, use : true/false");
+    }
+    if (!have_dir) return fail("GramsOutputs: No output dir was defined");
+    break;
+  }
   return 0;
 }

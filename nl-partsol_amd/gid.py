@@ -215,3 +215,41 @@ def read_gravity(path, ndim, nsteps):
     f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
     _check(f(str(path).encode(), ndim, nsteps, g.ctypes.data, C.byref(found)), "nlps_host_read_gravity")
     return g if found.value else None
+
+
+class Outputs(C.Structure):
+    _fields_ = [("found", C.c_int), ("results_time_step", C.c_int), ("dir", C.c_char * 512),
+                ("particles_file", C.c_char * 128), ("nodes_file", C.c_char * 128)] + \
+               [(k, C.c_int) for k in ("global_coordinates", "mass", "density", "nodal_idx", "material_idx", "velocity",
+                                       "acceleration", "displacement", "stress", "volumetric_stress",
+                                       "deformation_gradient", "energy", "eps", "unsupported")]
+
+
+def read_outputs(path):
+    """The GramsOutputs block of a command file as a dict, or None if it has none."""
+    o = Outputs()
+    f = _nlps.lib().nlps_host_read_outputs
+    f.argtypes = [C.c_char_p, C.POINTER(Outputs)]
+    _check(f(str(path).encode(), C.byref(o)), "nlps_host_read_outputs")
+    if not o.found:
+        return None
+    return {k: (getattr(o, k).decode() if isinstance(getattr(o, k), bytes) else getattr(o, k)) for k, _ in Outputs._fields_}
+
+
+def write_selected_particles_vtk(outputs, time_step, state):
+    """particle_results_vtk__InOutFun__ with the switches of a GramsOutputs block: <DIR>/<Particles-file>_<step>.vtk."""
+    keep = {"x": state["x"]}
+    for flag, key in (("mass", "mass"), ("density", "rho"), ("nodal_idx", "I0"), ("material_idx", "matidx"),
+                      ("velocity", "vel"), ("acceleration", "acc"), ("displacement", "dis"), ("stress", "Stress"),
+                      ("deformation_gradient", "F_n"), ("eps", "EPS_n")):
+        if outputs[flag] and key in state:
+            keep[key] = state[key]
+    flags = VTK_X_GC * bool(outputs["global_coordinates"]) | VTK_P * bool(outputs["volumetric_stress"])
+    if outputs["volumetric_stress"] and "Stress" not in keep:
+        keep["Stress"] = state["Stress"]  # (the reference writes P without STRESS; here P rides on the stress block)
+    if outputs["energy"]:
+        flags |= VTK_ENERGY
+        keep.update({k: state[k] for k in ("W", "vel", "mass")})
+    name = "%s/%s_%d.vtk" % (outputs["dir"], outputs["particles_file"], time_step)
+    write_particles_vtk(name, outputs["results_time_step"], keep, flags)
+    return name

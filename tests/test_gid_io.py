@@ -590,3 +590,33 @@ def test_gravity_field(tmp_path):
         gid.read_gravity(deck, 2, 3)
     deck.write_text(DECK)
     assert gid.read_gravity(deck, 2, 3) is None
+
+
+def test_outputs_block(tmp_path):
+    """GramsOutputs (Read_GramsOutputs.c:25-345): interval, directory (must exist), file names and switches."""
+    E = nlps().NlpsError
+    (tmp_path / "results").mkdir()
+    deck = tmp_path / "run.nlp"
+    text = ("GramsOutputs (i=50) {\n  DIR=results\n  Particles-file=particles\n  Nodes-file=nodes\n  Out-velocity=true\n"
+            "  Out-stress = true\n  Out-energy=false\n  Out-Equivalent-Plastic-Strain=true\n  Out-strain=true\n  Out-damage=false\n}\n")
+    deck.write_text(DECK + text)
+    o = gid.read_outputs(deck)
+    assert (o["results_time_step"], o["dir"], o["particles_file"], o["nodes_file"]) == (50, str(tmp_path) + "/results", "particles", "nodes")
+    assert (o["velocity"], o["stress"], o["energy"], o["eps"], o["mass"], o["unsupported"]) == (1, 1, 0, 1, 0, 1)
+    rng = np.random.default_rng(1)
+    st = {"x": rng.normal(size=(5, 2)), "vel": rng.normal(size=(5, 2)), "Stress": rng.normal(size=(5, 5)),
+          "EPS_n": rng.uniform(size=5), "mass": np.ones(5), "acc": np.zeros((5, 2))}
+    name = gid.write_selected_particles_vtk(o, 100, st)
+    txt = open(name).read()
+    assert name.endswith("results/particles_100.vtk") and "Results time step 50" in txt
+    assert "VELOCITY" in txt and "STRESS" in txt and "EPS" in txt and "MASS" not in txt and "ACCELERATION" not in txt
+    for bad, msg in ((text.replace("DIR=results", "DIR=nowhere"), "No output dir"),
+                     (text.replace("(i=50)", "(every=50)"), "i=int"),
+                     (text.replace("Out-velocity=true", "Out-velocity=yes"), "true/false"),
+                     (text.replace("Out-velocity", "Out-speed"), "Out-speed is not available"),
+                     (text.replace("  Out-damage=false\n}", "  Out-damage=false\n"), "forget to put a }")):
+        deck.write_text(bad)
+        with pytest.raises(E, match=msg):
+            gid.read_outputs(deck)
+    deck.write_text(DECK)
+    assert gid.read_outputs(deck) is None
