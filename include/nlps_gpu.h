@@ -173,6 +173,13 @@ int nlps_gpu_constitutive(nlps_gpu *h);
 /* __nodal_internal_forces, U-Newmark-beta.c:1257-1374 (+ push_forward_dN__MeshTools__,
  * Shape-Functions.c:405-448).  R[nactive*ndim] is ACCUMULATED into; Dirichlet dofs are skipped. */
 int nlps_gpu_internal_forces(nlps_gpu *h, double *R);
+/* __nodal_traction_forces (U-Newmark-beta.c:1376-1500): R_A -= N_pA T A0_p over the particles of the Neumann contours
+ * (the reference runs it serially on the host between the internal and the inertial forces).  loads[l]
+ * is a Load like the Dirichlet ones with nodes = PARTICLE indices in the caller's order; the traction of the current
+ * step is value where dir is 1 and, as upstream, the previous contour's value where it is 0.  A0_p is Vol_0 / thickness
+ * in 2-D (Thickness_Plain_Stress) and area0[p] (Phi.Area_0, caller's order) in 3-D.  R: masked, host or device. */
+int nlps_gpu_nodal_traction_forces(nlps_gpu *h, double *R, const nlps_bcc *loads, int nloads, int step,
+                                   double thickness, const double *area0);
 
 /* __update_particles_internal_variables, U-Newmark-beta.c:1917-1978 */
 int nlps_gpu_roll_state(nlps_gpu *h);

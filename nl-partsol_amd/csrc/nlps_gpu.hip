@@ -1943,6 +1943,91 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
   return from_grid(h, R, h->N.force, ND, ND, 0, 0, 1, nullptr);
 }
 
+// __nodal_traction_forces (U-Newmark-beta.c:1376-1500): R_A -= N_pA T A0_p over the particles of the Neumann contours.
+// One thread per listed particle (a contour holds few), global atomics into a grid array.
+__global__ void k_inverse_perm(const int* __restrict__ perm, int np, int* __restrict__ inv) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < np) inv[perm[s]] = s;
+}
+template <int ND>
+__global__ void k_traction(PView P, GridD g, int n, const int* __restrict__ ids, const int* __restrict__ inv,
+                           const double* __restrict__ T, const double* __restrict__ A0, double thickness,
+                           double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int p = inv[ids[e]];
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  const double a0 = A0 ? A0[e] : PF(P, F_VOL0, p) / thickness;  // :1440-1444
+  const double zinv = lme_zinv<ND>(c);
+  for (int k = 0; k < Lme<ND>::KN; k++)
+    for (int j = 0; j < 5; j++)
+      for (int i = 0; i < 5; i++) {
+        if (!c.on(i + 5 * j + 25 * k)) continue;
+        const double Npa = c.ex[i] * c.ey[j] * (ND == 3 ? c.ez[k % Lme<ND>::KN] : 1.0) * zinv;
+        const int node = c.I0 + c.node_offset(g, i, j, k + (ND == 3 ? 0 : 2));
+        for (int a = 0; a < ND; a++) atomic_add_f64(out + (size_t)node * ND + a, -Npa * T[(size_t)e * ND + a] * a0);
+      }
+}
+
+extern "C" int nlps_gpu_nodal_traction_forces(nlps_gpu* h, double* R, const nlps_bcc* loads, int nloads, int step,
+                                              double thickness, const double* area0) {
+  if (need_masks(h, "nlps_gpu_nodal_traction_forces")) return 1;
+  const int ND = h->nd, np = h->P.np;
+  if (step < 0 || step >= h->nsteps) {
+    h->err = "nlps_gpu_nodal_traction_forces: step outside [0, nsteps)";
+    return 1;
+  }
+  if (ND == 3 && !area0) {
+    h->err = "nlps_gpu_nodal_traction_forces: the 3-D build needs Phi.Area_0 (area0)";
+    return 1;
+  }
+  if (h->migrated) {
+    h->err = "nlps_gpu_nodal_traction_forces: not available after a migration (particle order is by global id)";
+    return 1;
+  }
+  // the traction vector carries over from contour to contour where a direction is switched off (:1457-1461)
+  std::vector<int> ids;
+  std::vector<double> T, A;
+  double Tc[3] = {0.0, 0.0, 0.0};
+  for (int l = 0; l < nloads; l++) {
+    for (int i = 0; i < ND; i++)
+      if (loads[l].dir[(size_t)i * h->nsteps + step] == 1) Tc[i] = loads[l].value[(size_t)i * h->nsteps + step];
+    for (int q = 0; q < loads[l].nnodes; q++) {
+      const int p = loads[l].nodes[q];
+      if (p < 0 || p >= np) {
+        h->err = "nlps_gpu_nodal_traction_forces: particle index outside the cloud";
+        return 1;
+      }
+      ids.push_back(p);
+      for (int i = 0; i < ND; i++) T.push_back(Tc[i]);
+      if (ND == 3) A.push_back(area0[p]);
+    }
+  }
+  const int n = (int)ids.size();
+  if (n == 0) return 0;
+  int* ids_d = nullptr;
+  double *T_d = nullptr, *A_d = nullptr;
+  HIPCHK(hipMalloc((void**)&ids_d, (size_t)n * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&T_d, (size_t)n * ND * sizeof(double)));
+  if (ND == 3) HIPCHK(hipMalloc((void**)&A_d, (size_t)n * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(ids_d, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(T_d, T.data(), (size_t)n * ND * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (ND == 3) HIPCHK(hipMemcpyAsync(A_d, A.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->perm_d, np, h->sval_d);
+  HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
+  if (ND == 2) hipLaunchKernelGGL(k_traction<2>, dim3(nblk(n)), dim3(BLK), 0, h->stream, h->P, h->g, n, ids_d, h->sval_d, T_d, A_d, thickness, h->gridA);
+  else hipLaunchKernelGGL(k_traction<3>, dim3(nblk(n)), dim3(BLK), 0, h->stream, h->P, h->g, n, ids_d, h->sval_d, T_d, A_d, thickness, h->gridA);
+  HIPCHK(hipGetLastError());
+  const int st = from_grid(h, R, h->gridA, ND, ND, 0, 0, 1, nullptr);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(ids_d);
+  (void)hipFree(T_d);
+  if (A_d) (void)hipFree(A_d);
+  return st;
+}
+
 extern "C" int nlps_gpu_roll_state(nlps_gpu* h) {
   if (materialise_roll(h)) return 1;
   LAUNCH_ND((k_roll<2>), (k_roll<3>), nblk(h->P.np), h->P);

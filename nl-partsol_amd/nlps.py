@@ -64,7 +64,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_download_state", "nlps_gpu_download_lists", "nlps_gpu_download_active",
            "nlps_gpu_status_flags", "nlps_gpu_initialize_lme", "nlps_gpu_local_search", "nlps_gpu_active_masks",
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
-           "nlps_gpu_internal_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
+           "nlps_gpu_internal_forces", "nlps_gpu_nodal_traction_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
            "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_form_initial_guess", "nlps_gpu_nodal_kinetic_increments", "nlps_gpu_nodal_inertial_forces",
@@ -305,6 +305,14 @@ class Solver:
 
     def nodal_internal_forces(self, R):                 # __nodal_internal_forces (accumulates into R)
         self._chk(self.L.nlps_gpu_internal_forces(self.h, _vp(R)))
+        return R
+
+    def nodal_traction_forces(self, R, loads, step, thickness=1.0, area0=None):   # __nodal_traction_forces
+        self.L.nlps_gpu_nodal_traction_forces.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Bcc), C.c_int, C.c_int,
+                                                          C.c_double, C.c_void_p]
+        a0 = None if area0 is None else np.ascontiguousarray(area0, dtype=np.float64)
+        self._chk(self.L.nlps_gpu_nodal_traction_forces(self.h, _vp(R), loads.arr, loads.n, int(step), float(thickness),
+                                                        None if a0 is None else a0.ctypes.data))
         return R
 
     def update_particles_internal_variables(self):      # __update_particles_internal_variables

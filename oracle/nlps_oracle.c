@@ -1317,6 +1317,36 @@ int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, co
   return STATUS;
 }
 
+/* __nodal_traction_forces, U-Newmark-beta.c:1376-1500: over the Neumann contours and their particles, serial.
+ * ids = the particle lists one after the other (load_n[l] each), dir / val [nloads][ndim] of the current step.
+ * The traction vector T keeps a component from the previous contour where Dir is 0 (:1457-1461 never reset it);
+ * A0_p = Vol_0 / Thickness_Plain_Stress in 2-D (:1440), Phi.Area_0 in 3-D (:1442). */
+int orc_nodal_traction_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
+                              const int *dofs2mask, int nloads, const int *load_n, const int *ids, const int *dir,
+                              const double *val, double thickness, const double *area0) {
+  int ndim = M->ndim, at = 0;
+  double T[3] = {0.0, 0.0, 0.0};
+  for (int l = 0; l < nloads; l++)
+    for (int q = 0; q < load_n[l]; q++) {
+      int p = ids[at++];
+      double A0_p = (ndim == 2) ? P->vol0[p] / thickness : area0[p];
+      double N[ORC_MAXNB];
+      int nn = orc_compute_N(N, P, M, p);
+      if (nn < 0) return 1;
+      const int *conn = &P->list[(size_t)p * ORC_MAXNB];
+      for (int i = 0; i < ndim; i++)
+        if (dir[l * ndim + i] == 1) T[i] = val[l * ndim + i];
+      for (int A = 0; A < nn; A++) {
+        int Mask_node_A = nodes2mask[conn[A]];
+        for (int i = 0; i < ndim; i++) {
+          int idx = Mask_node_A * ndim + i;
+          if (dofs2mask[idx] != -1) R[idx] += -N[A] * T[i] * A0_p;
+        }
+      }
+    }
+  return 0;
+}
+
 /* compute_stiffness_density_Neo_Hookean, Hyperelastic/Neo-Hookean.c:89-141 (the only law whose tangent is
  * restated: the spectral tangents of Hencky and the elastoplastic laws divide by eigenvalue differences down to
  * 1e-14 (Hencky.c:205-214, Elastoplastic-Tangent-Matrix.c:137-147), which no second eigen-solver reproduces) */

@@ -133,6 +133,9 @@ int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, co
 /* __compute_trial_b_e, Drucker-Prager.c:617-633 */
 void orc_trial_b_e(double *btr, const double *d_phi, const double *b_e_n, int ndim);
 /* __jacobian_evaluation + __create_sparsity_pattern (U-Newmark-beta.c:1568-1830), Neo-Hookean, dense */
+int orc_nodal_traction_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
+                              const int *dofs2mask, int nloads, const int *load_n, const int *ids, const int *dir,
+                              const double *val, double thickness, const double *area0);
 int orc_stiffness_density_spectral(double *Kd, int ndim, const double *dN_alpha_n1, const double *dN_beta_n1,
                                    const double *b, const double *Cmod, const double *Stress);
 int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lumped_mass, const orc_particles *P,

@@ -283,6 +283,20 @@ def internal_forces(P, M, n2m, d2m, nactive):
     return R, st
 
 
+def nodal_traction_forces(R, P, M, n2m, d2m, loads, step, nsteps, thickness=1.0, area0=None):
+    """__nodal_traction_forces: loads = list of dicts like the Dirichlet ones, nodes = particle indices; R updated in place"""
+    nd = P.ndim
+    load_n = np.array([len(l["nodes"]) for l in loads], dtype=np.int32)
+    ids = np.concatenate([np.asarray(l["nodes"], dtype=np.int32) for l in loads]) if loads else np.zeros(0, np.int32)
+    dirs = np.array([[np.asarray(l["dir"]).reshape(nd, nsteps)[i, step] for i in range(nd)] for l in loads], dtype=np.int32)
+    vals = np.array([[np.asarray(l["value"]).reshape(nd, nsteps)[i, step] for i in range(nd)] for l in loads], dtype=np.float64)
+    f = lib().orc_nodal_traction_forces
+    f.argtypes = [_dp, C.POINTER(CParticles), C.POINTER(Mesh), _ip, _ip, C.c_int, _ip, _ip, _ip, _dp, C.c_double, _dp]
+    a0 = np.ascontiguousarray(area0, dtype=np.float64) if area0 is not None else None
+    return f(_d(R), C.byref(P.c), M.ptr, _i(n2m), _i(d2m), len(loads), _i(load_n), _i(np.ascontiguousarray(ids)),
+             _i(np.ascontiguousarray(dirs)), _d(np.ascontiguousarray(vals)), float(thickness), _d(a0) if a0 is not None else None)
+
+
 def tangent_matrix(P, M, mats, n2m, d2m, nactive, alpha_1=0.0, lumped_mass=None, with_pattern=True):
     """dense Jacobian [ntot, ntot] in masked numbering and the per-row sparsity pattern"""
     ntot = nactive * P.ndim

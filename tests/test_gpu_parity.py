@@ -1262,3 +1262,57 @@ def test_run_from_gid_mesh_files(tmp_path, ndim):
     for k, ok in (("x", "x"), ("vel", "vel"), ("F_n", "F_n"), ("Stress", "stress"), ("lambda", "lambda")):
         assert_close(st[k], P[ok], 1e-9, k)
     assert np.abs(st["Stress"]).max() > 1.0
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_nodal_traction_forces(ndim):
+    """__nodal_traction_forces (U-Newmark-beta.c:1376-1500) on the device against the oracle's serial
+    restatement: two Neumann contours of particles, the second with one direction switched off (it inherits the first
+    contour's traction, as upstream), Dirichlet dofs skipped, accumulated into a residual that already holds the internal
+    forces; host and device residual vectors; after a physical re-sort the caller's particle indices still address the
+    same particles."""
+    o = orc()
+    n = nlps()
+    if ndim == 2:
+        case = make_case(2, [12, 11], [3, 3], [5, 4], material=NH, velocity=[1.0, -2.0])
+    else:
+        case = make_case(3, [8, 8, 7], [3, 3, 2], [2, 2, 2], material=NH, velocity=[1.0, -2.0, 0.5])
+    nsteps, step = 3, 1
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    n2m, d2m, na = masks(S, M, bcs_list, step, nsteps)
+    rng = np.random.default_rng(4)
+    npart = case["cloud"]["x"].shape[0]
+    pick = rng.choice(npart, size=24, replace=False).astype(np.int32)
+    d1, d2 = np.ones((ndim, nsteps), dtype=np.int32), np.ones((ndim, nsteps), dtype=np.int32)
+    d2[0, step] = 0
+    loads = [{"nodes": pick[:14], "dim": ndim, "dir": d1, "value": rng.normal(size=(ndim, nsteps)) * 1e7},
+             {"nodes": pick[14:], "dim": ndim, "dir": d2, "value": rng.normal(size=(ndim, nsteps)) * 1e7}]
+    area0 = rng.uniform(0.2, 0.3, size=npart) if ndim == 3 else None
+    dU = 1e-2 * rng.normal(size=na * ndim)
+    assert o.compatibility(dU, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+    S.local_compatibility_conditions(dU)
+    S.constitutive_update()
+    R_o, st = o.internal_forces(P, M, n2m, d2m, na)
+    assert st == 0
+    fint = np.abs(R_o).max()
+    assert o.nodal_traction_forces(R_o, P, M, n2m, d2m, loads, step, nsteps, 0.5, area0) == 0
+    R_g = S.nodal_internal_forces(np.zeros(na * ndim))
+    S.nodal_traction_forces(R_g, n.BccSet(loads), step, 0.5, area0)
+    assert np.abs(R_o).max() > 2 * fint, "the tractions must matter"
+    assert_close(R_g, R_o, 1e-10, "internal + traction forces (host residual)")
+    import torch
+    R_d = torch.zeros(na * ndim, dtype=torch.float64, device="cuda")
+    S.nodal_internal_forces(R_d.data_ptr())
+    S.nodal_traction_forces(R_d.data_ptr(), n.BccSet(loads), step, 0.5, area0)
+    torch.cuda.synchronize()
+    assert_close(R_d.cpu().numpy(), R_o, 1e-10, "device residual")
+    S.resort()
+    S.local_search()
+    assert o.local_search(P, M, prm) == 0
+    n2m, d2m, na2 = masks(S, M, bcs_list, step, nsteps)
+    R_o2 = np.zeros(na2 * ndim)
+    assert o.nodal_traction_forces(R_o2, P, M, n2m, d2m, loads, step, nsteps, 0.5, area0) == 0
+    R_g2 = S.nodal_traction_forces(np.zeros(na2 * ndim), n.BccSet(loads), step, 0.5, area0)
+    assert_close(R_g2, R_o2, 1e-10, "tractions after a re-sort")
