@@ -360,6 +360,14 @@ int nlps_host_read_materials(const char *path, int max_materials, nlps_material 
  * [b][ndim][nsteps].  With nodes / dir / value NULL only the counts come back (*nbounds, and nnodes[] if given). */
 int nlps_host_read_boundaries(const char *path, int ndim, int nsteps, int max_bounds, int node_cap, int *nbounds,
                               int *nnodes, int *nodes, int *dir, double *value);
+/* The Neumann contours of the same file, Define-Neumann-Boundary(File=elements.txt) { T.x curve.txt | NULL ... }
+ * (NLPS-Read-u-Neumann-Boundary-Conditions.c:150-352): as above, but the list names elements of the body mesh and every
+ * element stands for its particles e * gp_per_elem + j; the result is what nlps_gpu_nodal_traction_forces takes. */
+int nlps_host_read_neumann(const char *path, int ndim, int nsteps, int gp_per_elem, int max_bounds, int node_cap,
+                           int *nbounds, int *nnodes, int *nodes, int *dir, double *value);
+/* Assign-material-to-particles (MatIdx=i, Particles=elements.txt) (Generate-One-Phase-Analysis.c:458-566):
+ * matidx[nparticles] is updated in place for the particles of the listed body elements. */
+int nlps_host_read_material_assignment(const char *path, int gp_per_elem, int nmaterials, int nparticles, int *matidx);
 /* The initial velocities of the same file, GramsInitials (Nodes=list.txt) { Value=[vx,vy,vz] }
  * (Read_GramsInitials.c:7-186): the list names ELEMENTS of the body mesh (0-based), all gp_per_elem particles of a
  * listed element get the value.  vel[nparticles][ndim] is updated in place. */

@@ -790,9 +790,13 @@ int read_curve(const std::string& file, std::vector<double>& fx) {
 }
 }  // namespace
 
-extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps, int max_bounds, int node_cap,
-                                         int* nbounds, int* nnodes, int* nodes, int* dir, double* value) {
-  if (!path || !nbounds || (ndim != 2 && ndim != 3) || nsteps < 1) return fail("bad argument");
+namespace {
+// gp = 0: GramsBoundary / BcDirichlet V.* with a node list; gp > 0: Define-Neumann-Boundary / T.* with a list of body
+// elements, each standing for its gp particles e * gp + j (NLPS-Read-u-Neumann-Boundary-Conditions.c:150-185, 318-352)
+int read_bounds(const char* path, int ndim, int nsteps, int gp, int max_bounds, int node_cap, int* nbounds, int* nnodes,
+                int* nodes, int* dir, double* value) {
+  if (!path || !nbounds || (ndim != 2 && ndim != 3) || nsteps < 1 || gp < 0) return fail("bad argument");
+  const char* keyword = gp ? "Define-Neumann-Boundary" : "GramsBoundary";
   LineReader in(path);
   if (!in.f) return fail(std::string("cannot open ") + path);
   const std::string route = dir_of(path);
@@ -802,9 +806,9 @@ extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps,
   std::vector<char*> w, kv;
   std::vector<double> fx;
   while (in.next()) {
-    if (tokens(in.buf.data(), " ,()\r\n\t", w) < 1 || strcmp(w[0], "GramsBoundary")) continue;
+    if (tokens(in.buf.data(), " ,()\r\n\t", w) < 1 || strcmp(w[0], keyword)) continue;
     if (w.size() < 2 || tokens(w[1], "=", kv) != 2 || strcmp(kv[0], "File"))
-      return fail("GramsBoundary: use this format -> GramsBoundary (File=Nodes.txt)");
+      return fail(std::string(keyword) + ": use this format -> " + keyword + " (File=Nodes.txt)");
     const int b = *nbounds;
     if (nnodes && b >= max_bounds) return fail("GramsBoundary: more boundaries than the caller has room for");
     // File2Chain: first word of every line; the chain, and with it the node array, is in reversed file order
@@ -815,6 +819,12 @@ extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps,
       std::vector<char*> t;
       while (nf.next())
         if (tokens(nf.buf.data(), " \r\n\t", t) > 0) ids.push_back(atoi(t[0]));
+    }
+    if (gp) {  // the chain (reversed file order) of elements, each expanded to its particles
+      std::vector<int> parts;
+      for (size_t i = 0; i < ids.size(); i++)
+        for (int j = 0; j < gp; j++) parts.push_back(ids[ids.size() - 1 - i] * gp + j);
+      ids.assign(parts.rbegin(), parts.rend());  // (the copy below reverses once more)
     }
     if (nnodes) nnodes[b] = (int)ids.size();
     if (fill) {
@@ -834,11 +844,13 @@ extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps,
       if (n == 1 && !strcmp(w[0], "{")) continue;
       if (n == 1 && !strcmp(w[0], "}")) {
         closed = true;
-      } else if (n == 3 && !strcmp(w[0], "BcDirichlet")) {
-        const int k = !strcmp(w[1], "V.x") ? 0 : !strcmp(w[1], "V.y") ? 1 : !strcmp(w[1], "V.z") ? 2 : -1;
-        if (k < 0) return fail(std::string("GramsBoundary: Velocity component ") + w[1] + " is not available");
-        if (!strcmp(w[2], "NULL") || k >= ndim) continue;
-        if (read_curve(route + w[2], fx)) return 1;
+      } else if ((!gp && n == 3 && !strcmp(w[0], "BcDirichlet")) || (gp && n == 2 && w[0][0] == 'T' && w[0][1] == '.')) {
+        const char* comp = gp ? w[0] + 2 : (w[1][0] == 'V' && w[1][1] == '.' ? w[1] + 2 : "?");
+        const char* file = gp ? w[1] : w[2];
+        const int k = !strcmp(comp, "x") ? 0 : !strcmp(comp, "y") ? 1 : !strcmp(comp, "z") ? 2 : -1;
+        if (k < 0) return fail(std::string(keyword) + ": Velocity component " + (gp ? w[0] : w[1]) + " is not available");
+        if (!strcmp(file, "NULL") || k >= ndim) continue;
+        if (read_curve(route + file, fx)) return 1;
         if (fill) {
           const int na = std::min(nsteps, (int)fx.size());
           for (int t = 0; t < na; t++) {
@@ -847,12 +859,51 @@ extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps,
           }
         }
       } else {
-        return fail(std::string("GramsBoundary: undefined property ") + w[0]);
+        return fail(std::string(keyword) + ": undefined property " + w[0]);
       }
     }
     (*nbounds)++;
   }
   (void)used;
+  return 0;
+}
+}  // namespace
+
+extern "C" int nlps_host_read_boundaries(const char* path, int ndim, int nsteps, int max_bounds, int node_cap,
+                                         int* nbounds, int* nnodes, int* nodes, int* dir, double* value) {
+  return read_bounds(path, ndim, nsteps, 0, max_bounds, node_cap, nbounds, nnodes, nodes, dir, value);
+}
+extern "C" int nlps_host_read_neumann(const char* path, int ndim, int nsteps, int gp_per_elem, int max_bounds,
+                                      int node_cap, int* nbounds, int* nnodes, int* nodes, int* dir, double* value) {
+  if (gp_per_elem < 1) return fail("bad argument");
+  return read_bounds(path, ndim, nsteps, gp_per_elem, max_bounds, node_cap, nbounds, nnodes, nodes, dir, value);
+}
+
+// Assign-material-to-particles (MatIdx=i, Particles=list.txt)  (Generate-One-Phase-Analysis.c:458-566): the list
+// names body elements; their particles e * GPxElement + j get material i.  matidx[nparticles] is updated in place.
+extern "C" int nlps_host_read_material_assignment(const char* path, int gp_per_elem, int nmaterials, int nparticles,
+                                                  int* matidx) {
+  if (!path || !matidx || gp_per_elem < 1) return fail("bad argument");
+  LineReader in(path);
+  if (!in.f) return fail(std::string("cannot open ") + path);
+  const std::string route = dir_of(path);
+  std::vector<char*> w, kv;
+  while (in.next()) {
+    if (tokens(in.buf.data(), " (,)\r\n\t", w) < 3 || strcmp(w[0], "Assign-material-to-particles")) continue;
+    if (tokens(w[1], "=", kv) != 2 || strcmp(kv[0], "MatIdx")) return fail("Assign-material-to-particles (MatIdx=Int, *)");
+    const int mi = atoi(kv[1]);
+    if (mi < 0 || mi >= nmaterials) return fail("Assign-material-to-particles: MatIdx should go from 0 to " + std::to_string(nmaterials - 1));
+    if (tokens(w[2], "=", kv) != 2 || strcmp(kv[0], "Particles")) return fail("Assign-material-to-particles (*, Particles=List-Particles.txt)");
+    LineReader nf((route + kv[1]).c_str());
+    if (!nf.f) return fail("File2Chain: Incorrect lecture of " + route + kv[1]);
+    std::vector<char*> t;
+    while (nf.next()) {
+      if (tokens(nf.buf.data(), " \r\n\t", t) < 1) continue;
+      const int e = atoi(t[0]);
+      if (e < 0 || (long long)(e + 1) * gp_per_elem > nparticles) return fail("Assign-material-to-particles: element " + std::to_string(e) + " is outside the particle set");
+      for (int j = 0; j < gp_per_elem; j++) matidx[(size_t)e * gp_per_elem + j] = mi;
+    }
+  }
   return 0;
 }
 

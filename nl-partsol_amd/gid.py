@@ -173,11 +173,17 @@ def read_materials(path, max_materials=16):
     return out
 
 
-def read_boundaries(path, ndim, nsteps):
+def read_boundaries(path, ndim, nsteps, gp_per_elem=0):
     """The GramsBoundary blocks of a command file -> list of dicts in the layout nlps.BccSet takes (nodes in FILE
-    numbering and in the reference's reversed file order: map them through canon of lattice_from_nodes)."""
-    f = _nlps.lib().nlps_host_read_boundaries
-    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)] + [C.c_void_p] * 4
+    numbering and in the reference's reversed file order: map them through canon of lattice_from_nodes).  With
+    gp_per_elem > 0: the Define-Neumann-Boundary contours instead, nodes = particle indices."""
+    L = _nlps.lib()
+    L.nlps_host_read_boundaries.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)] + [C.c_void_p] * 4
+    L.nlps_host_read_neumann.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)] + [C.c_void_p] * 4
+    if gp_per_elem:
+        f = lambda p_, nd_, ns_, *rest: L.nlps_host_read_neumann(p_, nd_, ns_, int(gp_per_elem), *rest)  # noqa: E731
+    else:
+        f = L.nlps_host_read_boundaries
     nb = C.c_int(0)
     _check(f(str(path).encode(), ndim, nsteps, 0, 0, C.byref(nb), None, None, None, None), "nlps_host_read_boundaries")
     if nb.value == 0:
@@ -253,3 +259,18 @@ def write_selected_particles_vtk(outputs, time_step, state):
     name = "%s/%s_%d.vtk" % (outputs["dir"], outputs["particles_file"], time_step)
     write_particles_vtk(name, outputs["results_time_step"], keep, flags)
     return name
+
+
+def read_neumann(path, ndim, nsteps, gp_per_elem):
+    """The Define-Neumann-Boundary contours of a command file (nodes = particle indices), for Solver.nodal_traction_forces."""
+    return read_boundaries(path, ndim, nsteps, gp_per_elem)
+
+
+def read_material_assignment(path, gp_per_elem, nmaterials, matidx):
+    """Applies the Assign-material-to-particles lines of a command file to matidx[nparticles] (in place)."""
+    m = np.ascontiguousarray(matidx, dtype=np.int32)
+    f = _nlps.lib().nlps_host_read_material_assignment
+    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _check(f(str(path).encode(), int(gp_per_elem), int(nmaterials), m.shape[0], m.ctypes.data),
+           "nlps_host_read_material_assignment")
+    return m

@@ -74,7 +74,8 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_set_particle_ids", "nlps_gpu_download_ids",
            "nlps_gpu_set_timing", "nlps_gpu_get_timing", "nlps_host_stencil_tables",
            "nlps_host_io_last_error", "nlps_host_gid_mesh_info", "nlps_host_gid_mesh_read",
-           "nlps_host_lattice_from_nodes", "nlps_host_particles_from_mesh", "nlps_host_write_particles_vtk", "nlps_host_write_nodes_vtk", "nlps_host_read_deck", "nlps_host_read_materials", "nlps_host_read_boundaries", "nlps_host_read_initials", "nlps_host_read_gravity", "nlps_host_read_outputs"]
+           "nlps_host_lattice_from_nodes", "nlps_host_particles_from_mesh", "nlps_host_write_particles_vtk", "nlps_host_write_nodes_vtk", "nlps_host_read_deck", "nlps_host_read_materials", "nlps_host_read_boundaries", "nlps_host_read_initials", "nlps_host_read_gravity", "nlps_host_read_outputs", "nlps_host_read_neumann",
+           "nlps_host_read_material_assignment"]
 
 
 def lib():

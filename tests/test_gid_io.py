@@ -620,3 +620,29 @@ def test_outputs_block(tmp_path):
             gid.read_outputs(deck)
     deck.write_text(DECK)
     assert gid.read_outputs(deck) is None
+
+
+def test_neumann_contours_and_material_assignment(tmp_path):
+    """Define-Neumann-Boundary (NLPS-Read-u-Neumann-Boundary-Conditions.c:150-352): the list names body elements, each
+    standing for its GPxElement particles, in the chain's reversed order; T.x / T.y / T.z with the curves of ReadCurve.c.
+    Assign-material-to-particles (Generate-One-Phase-Analysis.c:458-566)."""
+    E = nlps().NlpsError
+    (tmp_path / "top.txt").write_text("5\n2\n")
+    (tmp_path / "load.txt").write_text("DAT_CURVE NUM#3\nRAMP_CURVE SCALE#-300.0\n")
+    deck = tmp_path / "run.nlp"
+    deck.write_text("Define-Neumann-Boundary(File=top.txt)\n{\n  T.x NULL\n  T.y load.txt\n}\n"
+                    "Assign-material-to-particles (MatIdx=1, Particles=top.txt)\n")
+    (c,) = gid.read_neumann(deck, 2, 4, 4)
+    assert list(c["nodes"]) == [8, 9, 10, 11, 20, 21, 22, 23]  # element 2 first (the chain is reversed), then 5
+    assert np.array_equal(c["dir"], [[0, 0, 0, 0], [1, 1, 1, 0]])
+    assert np.array_equal(c["value"], [[0, 0, 0, 0], [0.0, -100.0, -200.0, 0.0]])
+    assert gid.read_boundaries(deck, 2, 4) == []  # no Dirichlet block in this file
+    m = gid.read_material_assignment(deck, 4, 2, np.zeros(24, dtype=np.int32))
+    assert list(np.nonzero(m)[0]) == [8, 9, 10, 11, 20, 21, 22, 23] and m.max() == 1
+    with pytest.raises(E, match="MatIdx should go from 0 to 0"):
+        gid.read_material_assignment(deck, 4, 1, np.zeros(24, dtype=np.int32))
+    with pytest.raises(E, match="outside the particle set"):
+        gid.read_material_assignment(deck, 4, 2, np.zeros(20, dtype=np.int32))
+    deck.write_text("Define-Neumann-Boundary(File=top.txt)\n{\n  T.w load.txt\n}\n")
+    with pytest.raises(E, match="T.w is not available"):
+        gid.read_neumann(deck, 2, 4, 4)
