@@ -674,8 +674,10 @@ extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlp
     if (*nmats >= max_materials) return fail("Define-Material: more materials than the caller has room for");
     // Read_Index_and_Model, :178-210: "idx=0" or "0", "Model=X" or "X"
     int n = tokens(w[1], "=", kv);
+    if (n < 1) return fail("Define-Material: Define-Material(idx=int,Model=string)");
     const int id = atoi(kv[n == 2 ? 1 : 0]);
     n = tokens(w[2], "=", kv);
+    if (n < 1) return fail("Define-Material: Define-Material(idx=int,Model=string)");
     const std::string model = kv[n == 2 ? 1 : 0];
     nlps_material m;
     memset(&m, 0, sizeof(m));
