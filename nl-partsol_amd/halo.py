@@ -15,7 +15,7 @@ class SlabHalo:
         self.torch, self.dist, self.rank, self.world, self.mode = torch, dist, rank, world, mode
         self.plane, self.nz = int(plane_nodes), int(nlayers)
         self.lo, self.hi = list(lo), list(hi)
-        self.plans, self.tensors, self.pending, self.side = {}, {}, {}, None
+        self.plans, self.tensors, self.pending, self.events, self.side = {}, {}, {}, {}, None
         for r in range(world - 2):
             if self.hi[r] >= self.lo[r + 2]:
                 raise ValueError("slabs too thin: rank %d overlaps rank %d" % (r, r + 2))
@@ -164,7 +164,9 @@ class SlabHalo:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 st = self.exchange(t, nfield, kind)
-                ev = torch.cuda.Event()
+                ev = self.events.get((dptr, nfield, kind))  # one event per nodal array, re-recorded every step
+                if ev is None:
+                    ev = self.events[(dptr, nfield, kind)] = torch.cuda.Event()
                 ev.record(self.side)
             self.pending[(dptr, nfield, kind)] = ev
             return st
