@@ -499,8 +499,11 @@ __global__ void k_nodal_dU(int n0, int nnodes, int n0b, int nnodesb, NView N) { 
   int A = blockIdx.x * blockDim.x + threadIdx.x;  // two node ranges: [n0, n0+nnodes) and [n0b, n0b+nnodesb)
   if (A >= nnodes + nnodesb) return;
   A = A < nnodes ? n0 + A : n0b + (A - nnodes);
-  bool act = N.active[A];
   double M = N.nm[(size_t)A * (1 + ND)];
+  // an active node no particle lists (narrow LME kernels: the 1-ring activation reaches further than the cut-off
+  // radius) has M = 0: its value is 0 like VecPointwiseDivide's in the maintained driver, never 0/0 (the gather
+  // kernels read every window slot, a NaN there would poison the zero-weighted non-members)
+  bool act = N.active[A] && M != 0.0;
 #pragma unroll
   for (int a = 0; a < ND; a++) N.dU[(size_t)A * ND + a] = act ? N.nm[(size_t)A * (1 + ND) + 1 + a] / M : 0.0;
 }
@@ -527,8 +530,8 @@ __global__ void k_nodal_accel(int n0, int nnodes, int n0b, int nnodesb, NView N,
   int A = blockIdx.x * blockDim.x + threadIdx.x;
   if (A >= nnodes + nnodesb) return;
   A = A < nnodes ? n0 + A : n0b + (A - nnodes);
-  bool act = N.active[A];
   double M = N.nm[(size_t)A * (1 + ND)];
+  bool act = N.active[A] && M != 0.0;  // massless active node: see k_nodal_dU
   double gv[3] = {g0, g1, g2};
 #pragma unroll
   for (int a = 0; a < ND; a++) {
@@ -566,7 +569,8 @@ __global__ void k_compact(double* __restrict__ out, const double* __restrict__ g
     else if (mode == 1) {
       if (d2m[idx] != -1) out[idx] += v;
     } else {
-      out[idx] = ((d2m[idx] == -1) ? 0.0 : v) / div[idx];
+      const double dv = div[idx];  // VecPointwiseDivide (U-Newmark-beta.c:695-696): 0 where the lumped mass is 0
+      out[idx] = dv != 0.0 ? ((d2m[idx] == -1) ? 0.0 : v) / dv : 0.0;
     }
   }
 }

@@ -338,7 +338,8 @@ class Solver:
         return out
 
     # ------------------------------------------------------------------ downloads
-    def download_state(self):
+    def download_state(self, fields=None):
+        """All particle fields in the caller's order; `fields` (names as below) limits the download (large clouds)."""
         n, d, T = self.np, self.ndim, self.T
         o = {"x_GC": np.zeros((n, d)), "dis": np.zeros((n, d)), "vel": np.zeros((n, d)), "acc": np.zeros((n, d)),
              "F_n": np.zeros((n, T)), "F_n1": np.zeros((n, T)), "DF": np.zeros((n, T)), "Stress": np.zeros((n, T)),
@@ -348,17 +349,22 @@ class Solver:
              "lambda_": np.zeros((n, d)), "Beta": np.zeros(n), "dt_F_n": np.zeros((n, T)),
              "dt_F_n1": np.zeros((n, T)), "dt_DF": np.zeros((n, T)), "C_ep": np.zeros((n, d * d)),
              "Back_stress": np.zeros((n, 3))}
-        i0 = np.zeros(n, dtype=np.int32)
+        if fields is not None:
+            alias = {"x": "x_GC", "lambda": "lambda_", "beta": "Beta"}
+            want = {alias.get(k, k) for k in fields}
+            o = {k: a for k, a in o.items() if k in want}
+        i0 = np.zeros(n, dtype=np.int32) if fields is None or "I0" in fields else None
         hp = Particles()
         hp.np = n
         for k, a in o.items():
             setattr(hp, k, _d(a))
         hp.I0 = _i(i0)
         self._chk(self.L.nlps_gpu_download_state(self.h, C.byref(hp)))
-        o["I0"] = i0
-        o["x"] = o["x_GC"]
-        o["lambda"] = o["lambda_"]
-        o["beta"] = o["Beta"]
+        if i0 is not None:
+            o["I0"] = i0
+        for short, full in (("x", "x_GC"), ("lambda", "lambda_"), ("beta", "Beta")):
+            if full in o:
+                o[short] = o[full]
         return o
 
     def download_lists(self):

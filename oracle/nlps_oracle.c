@@ -789,9 +789,12 @@ int orc_nodal_field_n(double *V, double *Av, const double *Mv, const orc_particl
       }
     }
   }
-  for (int i = 0; i < nactive * ndim; i++) { /* VecPointwiseDivide :695-696 */
-    V[i] = V[i] / Mv[i];
-    Av[i] = Av[i] / Mv[i];
+  /* VecPointwiseDivide :695-696.  PETSc (third-party, not vendored; src/vec/vec/impls/seq/bvec2.c,
+   * VecPointwiseDivide_Seq) writes 0 where the denominator is 0: an active node no particle lists (narrow LME
+   * kernels, gamma_LME >= ~5: the 1-ring activation reaches further than the cut-off radius) has zero lumped mass. */
+  for (int i = 0; i < nactive * ndim; i++) {
+    V[i] = Mv[i] != 0.0 ? V[i] / Mv[i] : 0.0;
+    Av[i] = Mv[i] != 0.0 ? Av[i] / Mv[i] : 0.0;
   }
   return 0;
 }
@@ -1607,7 +1610,10 @@ int orc_explicit_step(orc_particles *P, orc_mesh *M, const orc_material *mats, c
       }
     }
   }
-  for (int i = 0; i < nd; i++) out->dU[i] = out->dU[i] / out->mass[i];
+  /* U-Verlet.c:357-362 divides as written (0/0 at an active node no particle lists); the composition keeps the
+   * convention of the maintained driver's VecPointwiseDivide instead (0 where the lumped mass is 0): such a node
+   * is in no particle's list, so no particle result depends on the choice. */
+  for (int i = 0; i < nd; i++) out->dU[i] = out->mass[i] != 0.0 ? out->dU[i] / out->mass[i] : 0.0;
 
   /* impose_Dirichlet_Boundary_Conditions :455-527 */
   for (int b = 0; b < nbcc; b++)
@@ -1645,7 +1651,8 @@ int orc_explicit_step(orc_particles *P, orc_mesh *M, const orc_material *mats, c
     for (int i = 0; i < ndim; i++) {
       int idx = A * ndim + i;
       if (out->dofs2mask[idx] != -1) {
-        out->accel[idx] = (gravity ? gravity[i] : 0.0) + out->force[idx] / out->mass[idx];
+        out->accel[idx] = out->mass[idx] != 0.0 ? (gravity ? gravity[i] : 0.0) + out->force[idx] / out->mass[idx]
+                                                : 0.0; /* massless active node: see the dU division above */
       } else {
         out->accel[idx] = 0.0;
         out->reaction[idx] = out->force[idx];

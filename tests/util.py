@@ -28,15 +28,18 @@ VM = synth.von_mises_material()
 
 
 def make_case(ndim, cells, lo, blk, material=NH, velocity=None, jitter=0.05, ppc=None, seed=12345, h=1.0,
-              origin=None, rho=1000.0):
+              origin=None, rho=1000.0, gamma=None, tol_zero=None):
     cells = list(cells)
     cloud = synth.make_cloud(ndim, cells, lo, blk, h=h, origin=origin, jitter=jitter, seed=seed, ppc=ppc,
                              velocity=velocity, rho=rho)
     if material["type"] == 2:  # Kappa_n = kappa_0 at start (InOutFun/Analysis/Generate-One-Phase-Analysis.c:621)
         cloud["kappa_n"][:] = material["kappa_0"]
-    return {"ndim": ndim, "cells": cells, "grid_n": synth.grid_nodes(cells),
+    case = {"ndim": ndim, "cells": cells, "grid_n": synth.grid_nodes(cells),
             "origin": [0.0] * ndim if origin is None else list(origin), "h": h, "cloud": cloud,
             "materials": [material]}
+    if gamma is not None or tol_zero is not None:  # LME globals other than the defaults of Read_GramsShapeFun.c:100-104
+        case["lme"] = (3.0 if gamma is None else float(gamma), 1e-6 if tol_zero is None else float(tol_zero))
+    return case
 
 
 def oracle_setup(case, init=True):
@@ -44,6 +47,8 @@ def oracle_setup(case, init=True):
     M = o.OracleMesh(case["ndim"], case["grid_n"], case["origin"], case["h"])
     P = o.OracleParticles(case["cloud"])
     prm = o.default_params()
+    if "lme" in case:
+        prm.gamma_lme, prm.tol_zero_lme = case["lme"]
     mats = o.make_materials(case["materials"])
     if init:
         assert o.initialize_lme(P, M, prm) == 0
@@ -52,6 +57,9 @@ def oracle_setup(case, init=True):
 
 def gpu_setup(case, init=True, nsteps=1, **kw):
     n = nlps()
+    if "lme" in case and "params" not in kw:
+        kw["params"] = n.default_params()
+        kw["params"].gamma_lme, kw["params"].tol_zero_lme = case["lme"]
     S = n.Solver(case["ndim"], case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"],
                  nsteps=nsteps, **kw)
     if init:
