@@ -65,6 +65,11 @@ struct ParamsD {
 #ifndef NLPS_LAMBDA_EXTRAPOLATE
 #define NLPS_LAMBDA_EXTRAPOLATE 0
 #endif
+// The last pass of the lambda Newton iteration only confirms |r| <= TOL_wrapper_LME; when the bound on the next
+// residual says it will, it is replaced by a second-order update of Z and of the separable factors (k2_tile)
+#ifndef NLPS_NEWTON_PREDICT_LAST
+#define NLPS_NEWTON_PREDICT_LAST 1
+#endif
 #ifndef NLPS_JUNROLL_K3
 #define NLPS_JUNROLL_K3 5  // unrolled gather rows: the LDS reads of the next rows overlap this row's arithmetic (-3 %)
 #endif

@@ -839,6 +839,8 @@ struct nlps_gpu {
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists (k_tile_scan)
+  double* slab_d = nullptr; // P2G window slabs [ntiles][K2_SPLIT][1+ND][NW] (TileD::slab), deterministic mode only
+  bool deterministic = false;
   int band_lo = -(1 << 30), band_hi = 1 << 30;  // ghost bands: layers <= band_lo and >= band_hi are shared with neighbours
   bool overlap = false;     // overlap the halo exchanges with the interior tiles (needs bands + a two-phase callback)
   unsigned long long* phase_d = nullptr;
@@ -1041,7 +1043,7 @@ extern "C" int nlps_gpu_set_node_window(nlps_gpu* h, int layer_lo, int layer_hi)
 }
 
 #if NLPS_PHASE_TIMING
-extern "C" int nlps_gpu_debug_phases(nlps_gpu* h, unsigned long long* out, int reset) {
+extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_phases(nlps_gpu* h, unsigned long long* out, int reset) {
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<unsigned long long> tmp(16 * 1024);
   HIPCHK(hipMemcpy(tmp.data(), h->phase_d, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1492,6 +1494,10 @@ extern "C" int nlps_gpu_migration_commit(nlps_gpu* h, const void* rows_a, int n_
 }
 
 extern "C" int nlps_gpu_resort(nlps_gpu* h) { return resort(h); }
+extern "C" int nlps_gpu_set_deterministic(nlps_gpu* h, int on) {
+  h->deterministic = on != 0;
+  return 0;
+}
 extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
   h->resort_every = every_n_steps;
   return 0;
@@ -1503,7 +1509,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1653,6 +1659,8 @@ static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 bound
   for (int a = 0; a < 3; a++) td.nt[a] = h->nt[a];
   td.ntiles = h->ntiles;
   td.tile0 = h->tile0;
+  td.ntw = h->ntw;
+  td.slab = h->deterministic ? h->slab_d : nullptr;
   td.work[0] = h->work1_d;
   td.work[1] = h->work2_d;
   td.range = h->nwork_d + 4 * cls;
@@ -1785,6 +1793,14 @@ static int ensure_bcs(nlps_gpu* h, const nlps_bcc* bcc, int nbcc) {
   return 0;
 }
 
+// bcc[i].dir / value are indexed [k * nsteps + step] (Types.h:296-351): a step outside the range given at create
+// would read past the caller's arrays
+static int check_step(nlps_gpu* h, int step, const char* who) {
+  if (step >= 0 && step < h->nsteps) return 0;
+  h->err = std::string(who) + ": step outside [0, nsteps) (nsteps is fixed at nlps_gpu_create)";
+  return 1;
+}
+
 static int dirbits_of(const nlps_bcc& b, int step, int nsteps) {
   int bits = 0;
   for (int k = 0; k < b.dim && k < 3; k++)
@@ -1795,6 +1811,7 @@ static int dirbits_of(const nlps_bcc& b, int step, int nsteps) {
 extern "C" int nlps_gpu_active_masks(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, int* nactive,
                                      int* nfree_dofs, int* nodes2mask, int* dofs2mask) {
   int ND = h->nd, nn = h->g.nnodes;
+  if (nbcc > 0 && check_step(h, step, "nlps_gpu_active_masks")) return 1;
   if (compute_node_mask(h)) return 1;
   HIPCHK(hipMemcpyAsync(&h->nactive, h->total_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -2044,14 +2061,30 @@ extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const d
   if (need_masks(h, "nlps_gpu_update_kinetics")) return 1;
   int ND = h->nd;
   size_t st = (size_t)h->g.nnodes * ND;
+  // Un_dt = dU_dt = dU_dt2 = NULL: the quasi-static driver's __update_Particles (U-Static.c:1380-1470) moves the
+  // particles by sum N dU and leaves velocity and acceleration alone
+  const bool quasi_static = !Un_dt && !dU_dt && !dU_dt2;
+  if (!quasi_static && (!Un_dt || !dU_dt || !dU_dt2)) {
+    h->err = "nlps_gpu_update_kinetics: pass all of Un_dt, dU_dt, dU_dt2 or none of them (quasi-static update)";
+    return 1;
+  }
+  if (!dU) {
+    h->err = "nlps_gpu_update_kinetics: dU is NULL";
+    return 1;
+  }
   if (to_grid(h, h->gridB, dU, ND)) return 1;
-  if (to_grid(h, h->gridB + st, Un_dt, ND)) return 1;
-  if (to_grid(h, h->gridB + 2 * st, dU_dt, ND)) return 1;
-  if (to_grid(h, h->gridB + 3 * st, dU_dt2, ND)) return 1;
+  if (quasi_static) {
+    HIPCHK(hipMemsetAsync(h->gridB + st, 0, 3 * st * sizeof(double), h->stream));
+  } else {
+    if (to_grid(h, h->gridB + st, Un_dt, ND)) return 1;
+    if (to_grid(h, h->gridB + 2 * st, dU_dt, ND)) return 1;
+    if (to_grid(h, h->gridB + 3 * st, dU_dt2, ND)) return 1;
+  }
   {
     TileD td = tile_view(h);
-    if (ND == 2) hipLaunchKernelGGL(kb_kinetics_tile<2>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
-    else hipLaunchKernelGGL(kb_kinetics_tile<3>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st);
+    const int qs = quasi_static ? 1 : 0;
+    if (ND == 2) hipLaunchKernelGGL(kb_kinetics_tile<2>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st, qs);
+    else hipLaunchKernelGGL(kb_kinetics_tile<3>, dim3(h->ntw), dim3(BLK), 0, h->stream, h->P, h->g, td, alpha_blend, h->gridB, h->gridB + st, h->gridB + 2 * st, h->gridB + 3 * st, qs);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -2062,6 +2095,7 @@ __global__ void k_null_bracket(PView, GridD, NView, TileD, const MatD*, ParamsD,
 extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, double dt, double gamma_nm,
                                       const double* gravity) {
   int ND = h->nd;
+  if (nbcc > 0 && check_step(h, step, "nlps_gpu_explicit_step")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
   if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
     if (resort(h)) return 1;
@@ -2076,6 +2110,27 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   double gv[3] = {0, 0, 0};
   if (gravity)
     for (int a = 0; a < ND; a++) gv[a] = gravity[a];
+  const bool det = h->deterministic;
+  if (det && !h->slab_d) {
+    const size_t NWs = ND == 3 ? TileCfg<3>::NW : TileCfg<2>::NW;
+    const size_t per_tile = std::max<size_t>((size_t)K2_SPLIT * (1 + ND), (size_t)K3_SPLIT * ND) * NWs;
+    HIPCHK(hipMalloc((void**)&h->slab_d, (size_t)h->ntiles * per_tile * sizeof(double)));
+  }
+  // second half of the P2G flush: per node, the window slabs of the tiles that hold it (part: node ranges as below)
+  auto gather_nm = [&](int part) {
+    const NodeRanges r = node_ranges(h, part);
+    if (!det || r.an + r.bn == 0) return;
+    TileD td = tile_view(h, 0);
+    if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 3, K2_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.nm);
+    else hipLaunchKernelGGL((k_slab_gather<3, 4, K2_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.nm);
+  };
+  auto gather_force = [&](int part) {
+    const NodeRanges r = node_ranges(h, part);
+    if (!det || r.an + r.bn == 0) return;
+    TileD td = tile_view(h, 0);
+    if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 2, K3_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
+    else hipLaunchKernelGGL((k_slab_gather<3, 3, K3_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
+  };
   auto nodal_dU = [&](int part) {
     const NodeRanges r = node_ranges(h, part);
     if (r.an + r.bn == 0) return;
@@ -2141,15 +2196,20 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel; the nodal accumulators of
   // the node window are reset by k_step_clear inside search_and_lists)
   if (search_and_lists(h, false, true, dt, gamma_nm, ov)) return 1;
-  if (halo(h, h->N.nm, 1 + ND, 8, 0, ov ? 1 : 0)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+  // with ghost bands the shared layers are gathered first (only boundary tiles reach them) and go on their way
+  // while the rest is summed
+  gather_nm(ov ? 2 : 0);
+  if (halo(h, h->N.nm, 1 + ND, 8, 0, ov ? 1 : 0)) return 1;
   // nodal dU = (sum m N dD) / M + Dirichlet values; S3 + S4
   if (ov) {
+    gather_nm(1);
     nodal_dU(1);
+    // timing brackets: the K3 bucket starts before the interior tiles (the band nodes' dU then counts as K3 time)
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     launch_k3(2);
     if (halo(h, h->N.nm, 1 + ND, 8, 0, 2)) return 1;
     nodal_dU(2);
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
     launch_k3(1);
   } else {
     nodal_dU(0);
@@ -2157,15 +2217,17 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     launch_k3(0);
   }
   HIPCHK(hipGetLastError());
-  if (halo(h, h->N.force, ND, 8, 0, ov ? 1 : 0)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
+  gather_force(ov ? 2 : 0);
+  if (halo(h, h->N.force, ND, 8, 0, ov ? 1 : 0)) return 1;
   // nodal acceleration; S5
   if (ov) {
+    gather_force(1);
     nodal_accel(1);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
     launch_k5(2);
     if (halo(h, h->N.force, ND, 8, 0, 2)) return 1;
     nodal_accel(2);
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
     launch_k5(1);
   } else {
     nodal_accel(0);
@@ -2303,6 +2365,7 @@ extern "C" int nlps_gpu_form_initial_guess(nlps_gpu* h, double* dU, const double
                                            int use_explicit_trial, const nlps_bcc* bcc, int nbcc, int step) {
   VecIO io;
   if (vec_begin(h, "nlps_gpu_form_initial_guess", io)) return 1;
+  if (nbcc > 0 && check_step(h, step, "nlps_gpu_form_initial_guess")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
   const int n = (int)io.n, ND = h->nd;
   double* d = io.out(dU, true);

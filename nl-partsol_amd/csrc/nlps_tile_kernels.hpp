@@ -53,6 +53,13 @@ struct TileD {
   int nt[3];
   int ntiles;
   int tile0;  // first tile of the launched range (node window)
+  int ntw;    // tiles in that range
+  // Deterministic mode (nlps_gpu_set_deterministic), nullptr otherwise: the P2G results leave a workgroup as ONE plain,
+  // coalesced copy of its LDS window into the slab of its (tile, part), slab[(tile * SPLIT + part)][field][window slot];
+  // k_slab_gather then sums, for every node, the <= 2^d windows that hold it in a fixed order.  No global atomics and
+  // an inter-tile summation order that never changes -- measured 7 % slower per step than the atomic flush (the
+  // no-return atomics hide behind the other workgroups' arithmetic, the gather is two more passes over the grid).
+  double* slab;
   const int* start;
   const int* count;
   const int* order;
@@ -75,6 +82,7 @@ struct TileD {
 #endif
 #if NLPS_PHASE_TIMING
 #define PH_INIT long long ph_t0 = clock64();
+#define PH_COUNT(k, n) atomicAdd(&td.phase[(k) + 16 * (blockIdx.x & 1023)], (unsigned long long)(n));
 #define PH(k)                                                                                               \
   {                                                                                                         \
     long long ph_t1 = clock64();                                                                            \
@@ -85,6 +93,7 @@ struct TileD {
 #else
 #define PH_INIT
 #define PH(k)
+#define PH_COUNT(k, n)
 #endif
 
 template <int ND>
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
       double r[ND], J[ND * ND], Jm1[ND * ND];
       c.factors(lam, beta, g.h);
       lme_moments_h<ND>(c, Zinv, r, J);
+      PH_COUNT(7, 1)
       double aux = 0.0;
 #pragma unroll
       for (int a = 0; a < ND; a++) aux += dsqr(r[a]);
@@ -355,14 +365,44 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
           st |= ST_NEWTON;
           break;
         }
+        double dl[ND], dlr = 0.0, dl2 = 0.0;
 #pragma unroll
         for (int a = 0; a < ND; a++) {
-          double dl = 0.0;
+          double d = 0.0;
 #pragma unroll
-          for (int b2 = 0; b2 < ND; b2++) dl = fma(Jm1[a * ND + b2], r[b2], dl);
-          lam[a] -= dl;
+          for (int b2 = 0; b2 < ND; b2++) d = fma(Jm1[a * ND + b2], r[b2], d);
+          dl[a] = d;
+          lam[a] -= d;
+          dlr = fma(d, r[a], dlr);
+          dl2 = fma(d, d, dl2);
         }
         NumIter++;
+#if NLPS_NEWTON_PREDICT_LAST
+        // The reference's next pass would only confirm convergence: with D = -J^-1 r exactly, r(lambda + D) =
+        // (1/2) T[D,D] + ..., T the third central moment of l under p, and |T_s[D,D]| <= max|l_a - r| D.J_s.D with
+        // D.J.D = |D.r|.  Members satisfy |l_a| <= Ra, so |r_next| <= (1/2)(Ra + |r|) |D.r| (1 + O(|D| Ra)).  A hundred
+        // times that below TOL_wrapper_LME means the reference stops at this lambda too; the pass that would have
+        // told it so is replaced by the second-order update of what the scatter needs at the new lambda:
+        // Z' = Z exp(D.r + D.J.D / 2) = Z exp(-dl.r / 2) and e'(l) = e(l) exp(D.l), both to < 1e-16 relative because
+        // |D| Ra <= 1e-3 is required as well (then |D.r| <= 2e-12 / Ra forces |D| Ra ~ 1e-5 in practice).
+        {
+          const double nr = sqrt(aux);
+          if (100.0 * 0.5 * (Ra + nr) * fabs(dlr) <= prm.tol_wrapper && dl2 * (Ra * Ra) <= 1.0e-6) {
+            Zinv *= fma(0.5, dlr, 1.0);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+              const double tx = -dl[0] * c.lx[i], ty = -dl[1] * c.ly[i];
+              c.ex[i] *= fma(tx, fma(tx, fma(tx, 1.0 / 6.0, 0.5), 1.0), 1.0);
+              c.ey[i] *= fma(ty, fma(ty, fma(ty, 1.0 / 6.0, 0.5), 1.0), 1.0);
+              if (ND == 3) {
+                const double tz = -dl[ND - 1] * c.lz[i % KN];
+                c.ez[i % KN] *= fma(tz, fma(tz, fma(tz, 1.0 / 6.0, 0.5), 1.0), 1.0);
+              }
+            }
+            break;
+          }
+        }
+#endif
       } else {
         break;
       }
@@ -416,6 +456,11 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
   if (!P2G) return;
   __syncthreads();
   PH(4)
+  if (td.slab) {
+    double* out = td.slab + ((size_t)tile * K2_SPLIT + part) * (NF * NW);
+    for (int q = threadIdx.x; q < NW * NF; q += BLK) out[q] = acc[q];
+    return;
+  }
   for (int q = threadIdx.x; q < NW * NF; q += BLK) {
     int f = q % NF, idx = q / NF;
     double v = acc[f * NW + idx];
@@ -762,6 +807,11 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
   if (MODE != 1) return;
   __syncthreads();
   PH(13)
+  if (td.slab) {
+    double* out = td.slab + ((size_t)tile * K3_SPLIT + part) * (ND * NW);
+    for (int qq = threadIdx.x; qq < NW * ND; qq += K3_BLK) out[qq] = fac[qq];
+    return;
+  }
   for (int qq = threadIdx.x; qq < NW * ND; qq += K3_BLK) {
     int f = qq % ND, idx = qq / ND;
     double v = fac[f * NW + idx];
@@ -771,6 +821,45 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
       if (in) atomic_add_f64(N.force + (size_t)node * ND + f, v);
     }
   }
+}
+
+// Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)
+// in a fixed order and writes out[node][NF]: the second half of the P2G flush (see TileD::slab).  A tile's slab is
+// valid iff the tile was launched this step (inside [tile0, tile0 + ntw) and count > 0; part p exists iff count > p BLK).
+template <int ND, int NF, int SPLIT>
+__global__ void k_slab_gather(int a0, int an, int b0, int bn, GridD g, TileD td, double* __restrict__ out) {
+  constexpr int TB = TileCfg<ND>::TB, W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW;
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= an + bn) return;
+  A = A < an ? a0 + A : b0 + (A - an);
+  const int ijk[3] = {A % g.n[0], (A / g.n[0]) % g.n[1], A / (g.n[0] * g.n[1])};
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    lo[a] = ijk[a] >= 2 ? (ijk[a] - 2) / TB : 0;  // window of tile t covers nodes [TB t - 2, TB t + TB + 1]
+    hi[a] = min(td.nt[a] - 1, (ijk[a] + 2) / TB);
+  }
+  double s[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) s[f] = 0.0;
+  for (int tz = lo[2]; tz <= hi[2]; tz++)
+    for (int ty = lo[1]; ty <= hi[1]; ty++)
+      for (int tx = lo[0]; tx <= hi[0]; tx++) {
+        const int t = tx + td.nt[0] * (ty + td.nt[1] * tz);
+        if (t < td.tile0 || t >= td.tile0 + td.ntw) continue;
+        const int cnt = td.count[t];
+        if (cnt <= 0) continue;
+        const int idx = (ijk[0] - (tx * TB - 2)) + W * (ijk[1] - (ty * TB - 2)) + (ND == 3 ? PS * (ijk[2] - (tz * TB - 2)) : 0);
+#pragma unroll
+        for (int part = 0; part < SPLIT; part++) {
+          if (part > 0 && cnt <= part * BLK) break;
+          const double* src = td.slab + ((size_t)t * SPLIT + part) * (NF * NW) + idx;
+#pragma unroll
+          for (int f = 0; f < NF; f++) s[f] += src[f * NW];
+        }
+      }
+#pragma unroll
+  for (int f = 0; f < NF; f++) out[(size_t)A * NF + f] = s[f];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1028,7 +1117,7 @@ template <int ND>
 __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD td, double alpha_blend,
                                                         const double* __restrict__ dU, const double* __restrict__ Un_dt,
                                                         const double* __restrict__ dU_dt,
-                                                        const double* __restrict__ dU_dt2) {
+                                                        const double* __restrict__ dU_dt2, int quasi_static) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr int NV = 4 * ND, NP = NV / 2;
   __shared__ __attribute__((aligned(16))) double win[NW * NV];
@@ -1098,8 +1187,10 @@ __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD 
 #pragma unroll
     for (int a = 0; a < ND; a++) {
       const double du = sv[a] * Zinv, vn = sv[ND + a] * Zinv, dv = sv[2 * ND + a] * Zinv, da = sv[3 * ND + a] * Zinv;
-      PF(P, F_ACC + a, p) = PF(P, F_ACC + a, p) + da;
-      PF(P, F_VEL + a, p) = alpha_blend * PF(P, F_VEL + a, p) + (dv + beta_blend * vn);
+      if (!quasi_static) {  // U-Static.c:1380-1470 touches dis and x_GC only
+        PF(P, F_ACC + a, p) = PF(P, F_ACC + a, p) + da;
+        PF(P, F_VEL + a, p) = alpha_blend * PF(P, F_VEL + a, p) + (dv + beta_blend * vn);
+      }
       PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + du;
       PF(P, F_X + a, p) = PF(P, F_X + a, p) + du;
     }

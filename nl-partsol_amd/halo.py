@@ -102,7 +102,15 @@ class SlabHalo:
         select + pack on the device, counts and rows exchanged with the two neighbours, commit.  Returns
         (sent_down, sent_up, received)."""
         torch, dist = self.torch, self.dist
+        # an edge rank has no neighbour on its outer side: its keep range is clamped to the grid there, so that no
+        # particle is ever selected towards a rank that does not exist (it would be dropped at the commit)
+        if self.rank == 0:
+            keep_lo = 0
+        if self.rank == self.world - 1:
+            keep_hi = self.nz - 1
         n_down, n_up, rw, dptr_down, dptr_up = S.migration_select(keep_lo, keep_hi)
+        if (n_down and self.rank == 0) or (n_up and self.rank == self.world - 1):
+            raise RuntimeError("migrate: %d / %d particles selected towards a non-existent neighbour" % (n_down, n_up))
         if self.world == 1:
             S.migration_commit(0, 0, 0, 0)
             return n_down, n_up, 0
