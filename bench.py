@@ -7,9 +7,13 @@ One "step" = one fused explicit predictor-corrector particle step (search + LME 
 and momentum, G2P gradient + F-update + Kirchhoff stress, P2G of the internal force, G2P kinematic
 update) over the synthetic cloud.  N = 1 runs BASELINE configs[1]: 3-D elastic cube impact,
 1 M particles (50^3 cells x 8), LME, Neo-Hookean, inside a 60^3-cell grid with a rigid floor.
-N > 1 is WEAK scaling: every rank owns one such 1 M-particle block, stacked along z (the slab axis),
-ghost-node layers exchanged with the two z-neighbours over RCCL (torch.distributed, backend nccl).
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+N > 1 is WEAK scaling by default: every rank owns one such 1 M-particle block, stacked along z (the slab axis),
+ghost-node layers exchanged with the two z-neighbours over RCCL (torch.distributed, backend nccl);
+`--scaling strong --particles-total 8000000` splits ONE cube (BASELINE configs[3], 100^3 cells x 8) into N z-slabs
+instead, so N = 1, 2, 4, 8 all run the same 8 M-particle job.
+Inputs are resident in HBM before the timed region; the timed region holds ONE physical re-sort of the particle
+arrays (the library's housekeeping, default cadence one per 50 steps: charged here at one per K steps).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -46,28 +50,37 @@ def parse():
     ap.add_argument("--workload", choices=["step", "tangent"], default="step",
                     help="step: the explicit particle step (the headline metric); tangent: the Neo-Hookean tangent "
                          "assembly of the implicit driver (SURVEY 8f n1), one JSON line per case")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --cells^3 x 8 particles per rank; strong: --particles-total split into z-slabs")
+    ap.add_argument("--particles-total", type=int, default=8000000, help="--scaling strong: size of the one job")
+    ap.add_argument("--no-stirred", action="store_true", help="skip the stirred-cloud figure (N = 1 only)")
     ap.add_argument("--overlap", type=int, choices=[0, 1], default=1,
                     help="N > 1: run the halo exchanges behind the interior tiles (1) or blocking in place (0)")
     return ap.parse_args()
 
 
-def build_case(rank, world, cells, margin=5):
+def build_case(rank, world, cells, margin=5, cells_z=None):
+    """Rank's block: cells x cells x cells_z cells (8 particles each) at z-offset rank * cells_z of a grid that holds
+    `world` such blocks plus a margin."""
     synth = importlib.import_module("nl-partsol_amd.synth")
-    gc = [cells + 2 * margin, cells + 2 * margin, cells * world + 2 * margin]
-    lo = [margin, margin, margin + cells * rank]
-    cloud = synth.make_cloud(3, gc, lo, [cells] * 3, h=1.0, jitter=0.05, seed=12345 + rank,
+    cells_z = cells if cells_z is None else cells_z
+    gc = [cells + 2 * margin, cells + 2 * margin, cells_z * world + 2 * margin]
+    lo = [margin, margin, margin + cells_z * rank]
+    cloud = synth.make_cloud(3, gc, lo, [cells, cells, cells_z], h=1.0, jitter=0.05, seed=12345 + rank,
                              velocity=[0.0, 0.0, -10.0])
     return {"ndim": 3, "cells": gc, "grid_n": synth.grid_nodes(gc), "origin": [0.0, 0.0, 0.0], "h": 1.0,
             "cloud": cloud, "materials": [{"type": 0, "E": 1.0e7, "nu": 0.3}], "block_lo": lo}
 
 
-def cpu_baseline(cells, budget_s=25.0):
-    """Times the oracle's explicit step (a from-scratch CPU port with OpenMP and the reference's
-    omp-critical nodal accumulation, U-Newmark-beta.c:582-586) on a bounded 3-D sample of the same
-    workload.  The critical sections make the port scale badly, so a few thread counts are tried inside
-    a time budget and the best is reported with the thread count that produced it."""
+def cpu_baseline(cells, budget_s=30.0):
+    """Times the oracle's explicit step (a from-scratch CPU port with OpenMP and the reference's omp-critical nodal
+    accumulation, U-Newmark-beta.c:582-586), built with the reference's release flags (-Ofast -fopenmp,
+    CMakeLists.txt:42,86), on a bounded 3-D sample of the same workload: one warm-up step, then the median of five
+    steps, at 1 thread and at all host cores.  kind = "port": the reference's own path cannot be built in this image
+    (LAPACK), so no port / reference ratio exists."""
     os.environ.pop("OMP_NUM_THREADS", None)
     from oracle import orc
+    orc.use_fast_build(True)
     synth = importlib.import_module("nl-partsol_amd.synth")
     margin = 5
     gc = [cells + 2 * margin] * 3
@@ -75,31 +88,49 @@ def cpu_baseline(cells, budget_s=25.0):
     M = orc.OracleMesh(3, gn, [0.0] * 3, 1.0)
     prm = orc.default_params()
     mats = orc.make_materials([{"type": 0, "E": 1.0e7, "nu": 0.3}])
-    nsteps = 3
+    nsteps = 8
     nodes = synth.plane_nodes(gn, 2, 0)
     bcs = orc.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nsteps), dtype=np.int32),
                        "value": np.zeros((3, nsteps))}])
-    ncpu = os.cpu_count() or 1
-    best = None
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    # "all cores" = this process's share of the host: a one-GPU box hands out 16 cores per GPU however many it has
+    nall = min(ncpu, 16)
+    rates = {}
     t_begin = time.perf_counter()
-    for nthr in sorted({1, min(8, ncpu), min(32, ncpu)}):
-        if best is not None and time.perf_counter() - t_begin > budget_s:
-            break
+    npart = 0
+    for nthr in sorted({1, nall}):
         orc.set_num_threads(nthr)
         cloud = synth.make_cloud(3, gc, [margin] * 3, [cells] * 3, velocity=[0.0, 0.0, -10.0])
         P = orc.OracleParticles(cloud)
+        npart = P.np
         assert orc.initialize_lme(P, M, prm) == 0
         st = orc.ExplicitStepper(P, M, mats, prm, bcs, nsteps)
         t0 = time.perf_counter()
-        assert st.step(0, 1e-3) == 0
-        dt = time.perf_counter() - t0
-        rate = P.np / dt
-        if best is None or rate > best[0]:
-            best = (rate, nthr, P.np)
-    return {"value": best[0], "unit": "particle-steps/s", "cores": best[1], "kind": "port",
-            "sample": "%d^3 cells x 8 = %d particles, 3-D LME Neo-Hookean, one explicit step per thread count "
-                      "(best of 1/8/32 threads inside %.0f s), oracle/nlps_oracle.c with OpenMP and the "
-                      "reference's omp-critical nodal accumulation" % (cells, best[2], budget_s)}
+        assert st.step(0, 1e-3) == 0  # warm-up (first touch, caches)
+        t_warm = time.perf_counter() - t0
+        ts = []
+        for t in range(1, 6):
+            if ts and time.perf_counter() - t_begin + max(ts) > budget_s * (0.5 if nthr == 1 else 1.0):
+                break  # bounded sample: the omp-critical accumulation can make a many-thread step very slow
+            t0 = time.perf_counter()
+            assert st.step(t, 1e-3) == 0
+            ts.append(time.perf_counter() - t0)
+        if not ts:
+            ts = [t_warm]
+        rates[nthr] = (P.np / float(np.median(ts)), len(ts))
+    best = max(rates, key=lambda k: rates[k][0])
+    return {"value": rates[best][0], "unit": "particle-steps/s", "cores": best, "kind": "port",
+            "threads_1": rates[1][0], "threads_all": rates[nall][0], "threads_all_count": nall, "host_cores": ncpu,
+            "flags": "-Ofast -fopenmp (the reference's CMAKE_C_FLAGS_RELEASE + OpenMP)",
+            "port_over_reference": None,
+            "sample": "%d^3 cells x 8 = %d particles, 3-D LME Neo-Hookean explicit step, median of %d steps after one "
+                      "warm-up step, at 1 thread and at %d threads (this GPU's share of the host cores); oracle/nlps_oracle.c keeps the "
+                      "reference's omp-critical nodal accumulation, which is why more threads do not help; no "
+                      "port/reference ratio exists (the reference path needs LAPACK, absent from the image)"
+                      % (cells, npart, rates[best][1], nall)}
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -180,6 +211,42 @@ def bench_tangent(a):
         S.close()
 
 
+def stirred_figure(nlps, synth, a, stream):
+    """The same cloud after 65 steps of a sheared velocity field (1.3 cells of relative drift): particles
+    have changed closest node and tile, the memory runs of the tile lists are broken.  Timed like the headline: K steps
+    with one physical re-sort in the middle."""
+    import torch
+    case = build_case(0, 1, a.cells)
+    x = case["cloud"]["x"]
+    c = x.mean(axis=0)
+    v = np.zeros_like(x)
+    v[:, 0] = 10.0 * (x[:, 2] - c[2]) / (0.5 * a.cells)
+    v[:, 1] = 10.0 * (x[:, 0] - c[0]) / (0.5 * a.cells)
+    v[:, 2] = -3.0
+    case["cloud"]["vel"] = v
+    soft = {"type": 0, "E": 1.0e5, "nu": 0.3}
+    S = nlps.Solver(3, case["grid_n"], case["origin"], case["h"], case["cloud"], [soft], nsteps=1, stream=stream)
+    S.set_resort_interval(0)
+    S.initialise_shapefun()
+    bcs = nlps.BccSet([])
+    dt = 2e-3
+    for _ in range(65):
+        S.explicit_step(bcs, 0, dt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        if i == a.steps // 2:
+            S.resort()
+        S.explicit_step(bcs, 0, dt)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    flags = S.status_flags()
+    S.close()
+    return {"ms_per_step": ms, "steps": a.steps, "shear_steps_before": 65, "resorts_in_timed_region": 1,
+            "status_flags": flags,
+            "workload": "bench cloud, Neo-Hookean E=1e5, sheared velocity field, no re-sort during the 65 shear steps"}
+
+
 def main():
     a = parse()
     if a.workload == "tangent":
@@ -208,7 +275,13 @@ def main():
     synth = importlib.import_module("nl-partsol_amd.synth")
 
     margin = 5
-    case = build_case(rank, world, a.cells, margin)
+    cells, cells_z = a.cells, a.cells
+    if a.scaling == "strong":  # one cube of --particles-total particles, z-slabs of equal thickness
+        cells = int(round((a.particles_total / 8.0) ** (1.0 / 3.0)))
+        if cells % world:
+            raise SystemExit("--scaling strong: %d cell layers do not split evenly over %d ranks" % (cells, world))
+        cells_z = cells // world
+    case = build_case(rank, world, cells, margin, cells_z)
     total_steps = a.steps + a.warmup + 1
     # One real (non-default) HIP stream shared by the library's kernels and the torch ops of the halo callback:
     # on the legacy default stream every torch op would synchronise with the library's own stream across queues
@@ -224,7 +297,7 @@ def main():
     if world > 1:
         halo_mod = importlib.import_module("nl-partsol_amd.halo")
         gn = case["grid_n"]
-        lo, hi = halo_mod.SlabHalo.layer_ranges(world, a.cells, margin, gn[2])
+        lo, hi = halo_mod.SlabHalo.layer_ranges(world, cells_z, margin, gn[2])
         halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)
         nnodes = gn[0] * gn[1] * gn[2]
 
@@ -246,8 +319,8 @@ def main():
 
     def step(t):
         if world > 1 and a.migrate_every > 0 and t % a.migrate_every == 0:
-            halo.migrate(S, margin + rank * a.cells - 1 if rank > 0 else 0,
-                         margin + (rank + 1) * a.cells + 1 if rank + 1 < world else case["grid_n"][2] - 1)
+            halo.migrate(S, margin + rank * cells_z - 1 if rank > 0 else 0,
+                         margin + (rank + 1) * cells_z + 1 if rank + 1 < world else case["grid_n"][2] - 1)
         S.explicit_step(bcs, t, dt)
 
     t = 0
@@ -257,8 +330,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    S.set_resort_interval(0)  # the periodic re-sort is issued explicitly below, inside the timed region
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if i == a.steps // 2:
+            S.resort()  # housekeeping of the hot path: one physical re-sort per K timed steps (library default 1 / 50)
         step(t)
         t += 1
     torch.cuda.synchronize()
@@ -290,38 +366,74 @@ def main():
     ev_overhead = float(kms[5])
     kms[:4] = np.maximum(kms[:4] - ev_overhead, 0.0)
 
+    stirred = None
+    if world == 1 and not a.no_stirred:
+        stirred = stirred_figure(nlps, synth, a, stream)
+
     if rank == 0:
         npart = case["cloud"]["x"].shape[0]
-        # dominant kernel = the P2G scatter kernel group with the largest share
         names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update", "nodal"]
+        kern = ["k_search", "k2_tile", "k3_tile", "k5_tile", None]
         alg = [0, BYTES_3D["S1"] + BYTES_3D["S2"], BYTES_3D["S3"] + BYTES_3D["S4"], BYTES_3D["S5"], 0]
+        # PMC figures of the same command (rocprofv3 passes of tools/profile.sh, committed under profiles/): HBM bytes,
+        # VALU instructions and LDS-array cycles per launch at 1 M particles; scaled by the particle count
+        pmc = {}
+        for fn in ("hbm_traffic.json", "sq_counters.json"):
+            try:
+                pmc.update(json.load(open(os.path.join(ROOT, "profiles", fn))))
+            except Exception:
+                pass
+        per_kernel = {}
+        for i in range(4):
+            t_s = kms[i] * 1e-3
+            if t_s <= 0:
+                continue
+            e = {"kernel_ms": float(kms[i]), "algorithmic_bytes_per_particle": alg[i],
+                 "hbm_frac": npart * alg[i] / t_s / 1e9 / HBM_PEAK_GBS}
+            sq = pmc.get(kern[i] or "", {}) if isinstance(pmc.get(kern[i] or ""), dict) else {}
+            scale = npart / 1.0e6
+            if "valu_insts" in sq:  # SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
+                e["fp64_issue_frac"] = sq["valu_insts"] * scale * 4.0 / (1024 * 2.4e9 * t_s)
+            if "lds_idx_active" in sq:  # SQ_LDS_IDX_ACTIVE (LDS-array cycles, summed over CUs) / (256 CUs x 2.4 GHz x time)
+                e["lds_busy_frac"] = sq["lds_idx_active"] * scale / (256 * 2.4e9 * t_s)
+            fr = {k: e[k] for k in ("hbm_frac", "fp64_issue_frac", "lds_busy_frac") if k in e}
+            e["bound"] = max(fr, key=fr.get).replace("_frac", "").replace("_busy", "")
+            per_kernel[names[i]] = e
         dom = int(np.argmax(kms[:4]))
         achieved = npart * alg[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(names[dom])
-            except Exception:
-                traffic = None
+        traffic = pmc.get(names[dom])
+        if traffic is not None:
+            traffic = traffic * npart / 1.0e6
+        domk = per_kernel.get(names[dom], {})
         out = {
             "metric": "particle-steps/sec (P2G+stress+G2P)", "value": npart * world * a.steps / elapsed,
             "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-D elastic cube impact, %d particles/GPU (%d^3 cells x 8), LME gamma=3, "
+            "config": {"workload": "3-D elastic cube impact, %d particles/GPU (%dx%dx%d cells x 8), LME gamma=3, "
                                    "Neo-Hookean E=1e7 nu=0.3, explicit predictor-corrector step, 1xMI355X per rank; "
-                                   "blocks stacked along z for N>1" % (npart, a.cells),
+                                   "z-slabs for N>1 (%s scaling)" % (npart, cells, cells, cells_z, a.scaling),
                        "particles_total": npart * world, "grid_nodes": int(np.prod(case["grid_n"])),
                        "halo": a.halo if world > 1 else "none",
-                       "halo_overlap": bool(a.overlap) if world > 1 else None},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       "halo_overlap": bool(a.overlap) if world > 1 else None,
+                       "resorts_in_timed_region": 1, "library_default_resort_interval": 50},
+            "roofline": {"bound": domk.get("bound", "hbm"), "kernel": names[dom], "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_particle": alg[dom], "kernel_ms": float(kms[dom]),
                          "event_overhead_ms": ev_overhead,
-                         "note": "3-D LME is FP64-ALU/atomic-bound, not HBM-bound (DESIGN.md); see kernel_ms_all"},
+                         "hbm_frac": domk.get("hbm_frac"), "fp64_issue_frac": domk.get("fp64_issue_frac"),
+                         "lds_busy_frac": domk.get("lds_busy_frac"),
+                         "note": "achieved/peak/frac are the HBM roofline of the dominant kernel (algorithmic bytes / "
+                                 "live kernel time); bound names the LARGEST of the three fractions: hbm, fp64_issue "
+                                 "(SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x time)) and lds "
+                                 "(SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x time)); the SQ counts come from "
+                                 "profiles/sq_counters.json (rocprofv3 PMC passes of this command)"},
             "kernel_ms_all": {names[i]: float(kms[i]) for i in range(5)},
+            "per_kernel": per_kernel,
         }
+        if stirred is not None:
+            out["stirred_ms_per_step"] = stirred["ms_per_step"]
+            out["stirred"] = stirred
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_cells)
         print(json.dumps(out))

@@ -65,12 +65,27 @@ def default_params():
     return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10)
 
 
+_FAST = False
+
+
+def use_fast_build(on=True):
+    """Selects libnlps_oracle_fast.so (the reference's -Ofast -fopenmp flags) for this process: timing only
+    (bench.py's cpu_baseline leg); must be called before the first lib()."""
+    global _FAST
+    assert _LIB is None, "use_fast_build() must come before the library is loaded"
+    _FAST = bool(on)
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "libnlps_oracle.so")
     src = os.path.join(_HERE, "nlps_oracle.c")
-    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libnlps_oracle.so"], stdout=subprocess.DEVNULL)
-    return so
+    out = None
+    for name in ("libnlps_oracle.so", "libnlps_oracle_fast.so"):
+        so = os.path.join(_HERE, name)
+        if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+            subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+        if name == ("libnlps_oracle_fast.so" if _FAST else "libnlps_oracle.so"):
+            out = so
+    return out
 
 
 def lib():
