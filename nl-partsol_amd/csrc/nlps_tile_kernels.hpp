@@ -16,13 +16,20 @@ struct TileCfg;
 // PS = LDS stride between z-planes of the window.  8x8 planes padded to 68 doubles: the 64 possible
 // I0 positions of a tile then spread evenly over the 32 b64 LDS banks (with 64 every z maps to the
 // same bank: 4-way conflicts on every window read / atomic).
+// WA / PSA / NWA: layout of the ACCUMULATOR windows (LDS f64 atomics).  ds_add_f64 serves a wave in four groups of 16
+// consecutive lanes over 16 eight-byte banks: a group is conflict-free iff its 16 slots differ mod 16.  In lattice order
+// a group is one z-plane of the tile, slots bx + WA by (bx, by in 0..3): with rows of 8 the planes by and by + 2 collide
+// (16.1 cycles per wave-instruction per CU measured, tools/lds_atomic_bench.hip), with rows padded to 12 the residues
+// are {0-3, 12-15, 8-11, 4-7}: 8.3 cycles.  The read windows keep rows of 8 (ds_read_b128 is fastest there).
 template <>
 struct TileCfg<3> {
   static constexpr int TB = 4, W = 8, PS = 68, NW = 8 * 68;
+  static constexpr int WA = 12, PSA = 100, NWA = 8 * 100;
 };
 template <>
 struct TileCfg<2> {
   static constexpr int TB = 16, W = 20, PS = 400, NW = 400;
+  static constexpr int WA = 20, PSA = 400, NWA = 400;  // a 16-lane group is one row of 16 consecutive slots already
 };
 
 // A tile's particle list is shared by TILE_SPLIT workgroups (each builds the window, takes every
@@ -128,6 +135,23 @@ __device__ __forceinline__ int window_node(const GridD& g, const int* w0, int id
   return gi + g.n[0] * (gj + g.n[1] * gk);
 }
 
+// the same for a slot of an accumulator window (WA / PSA layout)
+template <int ND>
+__device__ __forceinline__ int window_node_a(const GridD& g, const int* w0, int idx, bool& inside) {
+  constexpr int W = TileCfg<ND>::W, WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA;
+  const int lk = (ND == 3) ? idx / PSA : 0;
+  const int rem = (ND == 3) ? idx % PSA : idx;
+  const int li = rem % WA, lj = rem / WA;
+  const int gi = w0[0] + li, gj = w0[1] + lj, gk = (ND == 3) ? w0[2] + lk : 0;
+  inside = (li < W) && (lj < W) && gi >= 0 && gi < g.n[0] && gj >= 0 && gj < g.n[1] && (ND == 2 || (gk >= 0 && gk < g.n[2]));
+  return gi + g.n[0] * (gj + g.n[1] * gk);
+}
+template <int ND>
+__device__ __forceinline__ int window_base_a(const int* ijk, const int* w0) {
+  constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA;
+  return (ijk[0] - w0[0]) + WA * (ijk[1] - w0[1]) + (ND == 3 ? PSA * (ijk[2] - w0[2]) : 0);
+}
+
 // window-local index of the stencil member (i,j,k) of a particle whose I0 has local index `base`
 template <int ND>
 __device__ __forceinline__ int wl(int base, int i, int j, int k) {
@@ -223,6 +247,76 @@ __global__ void k_fill_order(int np, const int* __restrict__ tile, const int* __
   order[start[tile[p]] + rank[p]] = p;
 }
 
+// Canonical order of a tile's particle list, every step: layer r holds the r-th particle of every closest node that has
+// one, nodes in lattice order (x fastest).  64 consecutive entries (one wave) are then 64 DISTINCT closest nodes in
+// the order for which the window layouts are bank-conflict free (TileCfg, k3_tile), whatever the arrival order of the
+// binning was: the window atomics of the scatters and the window reads of the gathers ran with 25 % (K2), 31 % (K3) and
+// 49 % (K5) of their LDS cycles lost to bank conflicts on the lists as binned (profiles/r01_sq_counters.md).
+// One workgroup per non-empty tile, counting sort in LDS: rank inside the node by an LDS atomic (the order among the
+// particles of one node is the arrival order), position = layer offset + number of earlier nodes that reach the layer.
+template <int ND>
+__global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, int* __restrict__ order) {
+  constexpr int TB = TileCfg<ND>::TB, NN = (ND == 3) ? TB * TB * TB : TB * TB;
+  constexpr int CAP = 4096, LMAX = 32;  // larger tiles / deeper nodes keep the order of the binning
+  __shared__ int cnt[NN];
+  __shared__ unsigned short tbl[LMAX][NN];
+  __shared__ int lsize[LMAX + 1];
+  __shared__ int keys[CAP], pp[CAP];
+  __shared__ int maxc;
+  const int wb = td.range[0] + (int)blockIdx.x;
+  if (wb >= td.range[1]) return;
+  const int tile = td.work[0][wb].x;
+  const int n = td.count[tile];
+  if (n > CAP || n <= 1) return;
+  const int start = td.start[tile];
+  for (int q = threadIdx.x; q < NN; q += 256) cnt[q] = 0;
+  if (threadIdx.x == 0) maxc = 0;
+  __syncthreads();
+  int w0[3];
+  tile_origin<ND>(td, tile, w0);  // window origin = tile origin - 2
+  for (int s = threadIdx.x; s < n; s += 256) {
+    const int p = order[start + s];
+    const int I0 = P.I0[p];
+    const int bx = I0 % g.n[0] - (w0[0] + 2), by = (I0 / g.n[0]) % g.n[1] - (w0[1] + 2);
+    const int bz = (ND == 3) ? I0 / (g.n[0] * g.n[1]) - (w0[2] + 2) : 0;
+    const int node = bx + TB * (by + TB * bz);
+    const int r = atomicAdd(&cnt[node], 1);
+    keys[s] = node | (r << 16);
+    pp[s] = p;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < NN; q += 256) atomicMax(&maxc, cnt[q]);
+  __syncthreads();
+  const int nl = maxc;
+  if (nl > LMAX) return;  // uniform: every thread reads the same maxc
+  // tbl[r][node] = number of earlier nodes that reach layer r; lsize[r] = nodes in layer r
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < nl; r += 4) {
+    int run = 0;
+    for (int q0 = 0; q0 < NN; q0 += 64) {
+      const bool f = cnt[q0 + lane] > r;
+      const unsigned long long m = __ballot(f);
+      tbl[r][q0 + lane] = (unsigned short)(run + (int)__popcll(m & ((1ull << lane) - 1ull)));
+      run += (int)__popcll(m);
+    }
+    if (lane == 0) lsize[r] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int r = 0; r < nl; r++) {
+      const int v = lsize[r];
+      lsize[r] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < n; s += 256) {
+    const int node = keys[s] & 0xFFFF, r = keys[s] >> 16;
+    order[start + lsize[r] + tbl[r][node]] = pp[s];
+  }
+}
+
 // membership bits of row (j,k) into the 125-bit mask
 __device__ __forceinline__ void put_row(u64& mlo, u64& mhi, unsigned bits, int s) {
   if (s + 5 <= 64) mlo |= (u64)bits << s;
@@ -256,9 +350,10 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 template <int ND, bool P2G>
 __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
-  constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
+  constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
+  constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
   constexpr int KN = Lme<ND>::KN;
-  __shared__ double acc[NF * NW];
+  __shared__ double acc[NF * NWA];
   __shared__ unsigned actrow[NROWS];
   const int wb = td.range[2 * (K2_SPLIT - 1)] + (int)blockIdx.x;
   if (wb >= td.range[2 * (K2_SPLIT - 1) + 1]) return;
@@ -270,10 +365,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
   tile_origin<ND>(td, tile, w0);
   for (int r = threadIdx.x; r < NROWS; r += BLK) actrow[r] = 0u;
   if (P2G)
-    for (int idx = threadIdx.x; idx < NW; idx += BLK) {
-#pragma unroll
-      for (int f = 0; f < NF; f++) acc[f * NW + idx] = 0.0;
-    }
+    for (int idx = threadIdx.x; idx < NF * NWA; idx += BLK) acc[idx] = 0.0;
   __syncthreads();
   for (int idx = threadIdx.x; idx < NW; idx += BLK) {
     bool in;
@@ -303,7 +395,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
     const int I0 = P.I0[p];
     c.geom(g, x, I0);
     const int bx = c.ijk[0] - w0[0], by = c.ijk[1] - w0[1], bz = (ND == 3) ? c.ijk[2] - w0[2] : 0;
-    const int base = bx + W * by + (ND == 3 ? PS * bz : 0);
+    const int base = bx + WA * by + (ND == 3 ? PSA * bz : 0);  // slot of I0 in the accumulator window
     const double beta_prev = PF(P, F_BETA, p);
     const double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052
     const double T2 = sqrt_threshold(Ra);                       // sqrt(|l|^2) <= Ra  <=>  |l|^2 <= T2
@@ -434,7 +526,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const double wz = mz * ez5[k];
-      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
+      const int basek = base + (ND == 3 ? PSA * (k - 2) : 0);
 #pragma unroll NLPS_JUNROLL_SCATTER
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
@@ -443,11 +535,11 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
 #pragma unroll
         for (int i = 0; i < 5; i++)
           if ((bits >> i) & 1u) {
-            const int li = basek + (i - 2) + W * (j - 2);
+            const int li = basek + (i - 2) + WA * (j - 2);
             const double v0 = w * c.ex[i];
             atomicAdd(&acc[li], v0);
 #pragma unroll
-            for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NW + li], v0 * dd[a]);
+            for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NWA + li], v0 * dd[a]);
           }
       }
     }
@@ -457,16 +549,16 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
   __syncthreads();
   PH(4)
   if (td.slab) {
-    double* out = td.slab + ((size_t)tile * K2_SPLIT + part) * (NF * NW);
-    for (int q = threadIdx.x; q < NW * NF; q += BLK) out[q] = acc[q];
+    double* out = td.slab + ((size_t)tile * K2_SPLIT + part) * (NF * NWA);
+    for (int q = threadIdx.x; q < NWA * NF; q += BLK) out[q] = acc[q];
     return;
   }
-  for (int q = threadIdx.x; q < NW * NF; q += BLK) {
+  for (int q = threadIdx.x; q < NWA * NF; q += BLK) {
     int f = q % NF, idx = q / NF;
-    double v = acc[f * NW + idx];
+    double v = acc[f * NWA + idx];
     if (v != 0.0) {
       bool in;
-      int node = window_node<ND>(g, w0, idx, in);
+      int node = window_node_a<ND>(g, w0, idx, in);
       if (in) atomic_add_f64(N.nm + (size_t)node * NF + f, v);
     }
   }
@@ -492,7 +584,8 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
   // padded 32-B AoS row put every second node on the same banks (41 % conflict cycles measured).
   __shared__ __attribute__((aligned(16))) double duxy[2 * NW];
   __shared__ double duz[(ND == 3) ? NW : 1];
-  __shared__ double fac[ND * NW];
+  constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
+  __shared__ double fac[ND * NWA];
   const int wb = td.range[2 * (K3_SPLIT - 1)] + (int)blockIdx.x;
   if (wb >= td.range[2 * (K3_SPLIT - 1) + 1]) return;
   const int2 wk = td.work[K3_SPLIT - 1][wb];
@@ -512,9 +605,8 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
       dvxy[RATES ? 2 * idx + 1 : 1] = in ? dVgrid[(size_t)node * ND + 1] : 0.0;
       if (ND == 3) dvz[(RATES && ND == 3) ? idx : 0] = in ? dVgrid[(size_t)node * ND + (2 % ND)] : 0.0;
     }
-#pragma unroll
-    for (int a = 0; a < ND; a++) fac[a * NW + idx] = 0.0;
   }
+  for (int idx = threadIdx.x; idx < ND * NWA; idx += K3_BLK) fac[idx] = 0.0;
   __syncthreads();
   const double2* du2 = reinterpret_cast<const double2*>(duxy);
   const double2* dv2 = reinterpret_cast<const double2*>(dvxy);
@@ -768,10 +860,11 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
         }
         Ba[a] = v;
       }
+      const int basea = window_base_a<ND>(c.ijk, w0);
 #pragma unroll NLPS_KUNROLL_K3S
       for (int k = 0; k < KN; k++) {
         const unsigned pb = plane_bits<ND>(c, k);
-        const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
+        const int basek = basea + (ND == 3 ? PSA * (k - 2) : 0);
         const double wz = Zinv * ez5[k];
         const double ck = (double)(k - 2);
         double cz[ND];
@@ -788,10 +881,10 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
 #pragma unroll
           for (int i = 0; i < 5; i++)
             if ((bits >> i) & 1u) {
-              const int li = basek + (i - 2) + W * (j - 2);
+              const int li = basek + (i - 2) + WA * (j - 2);
               const double we = w * c.ex[i];
 #pragma unroll
-              for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NW + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
+              for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NWA + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
             }
         }
       }
@@ -808,16 +901,16 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
   __syncthreads();
   PH(13)
   if (td.slab) {
-    double* out = td.slab + ((size_t)tile * K3_SPLIT + part) * (ND * NW);
-    for (int qq = threadIdx.x; qq < NW * ND; qq += K3_BLK) out[qq] = fac[qq];
+    double* out = td.slab + ((size_t)tile * K3_SPLIT + part) * (ND * NWA);
+    for (int qq = threadIdx.x; qq < NWA * ND; qq += K3_BLK) out[qq] = fac[qq];
     return;
   }
-  for (int qq = threadIdx.x; qq < NW * ND; qq += K3_BLK) {
+  for (int qq = threadIdx.x; qq < NWA * ND; qq += K3_BLK) {
     int f = qq % ND, idx = qq / ND;
-    double v = fac[f * NW + idx];
+    double v = fac[f * NWA + idx];
     if (v != 0.0) {
       bool in;
-      int node = window_node<ND>(g, w0, idx, in);
+      int node = window_node_a<ND>(g, w0, idx, in);
       if (in) atomic_add_f64(N.force + (size_t)node * ND + f, v);
     }
   }
@@ -828,7 +921,7 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
 // valid iff the tile was launched this step (inside [tile0, tile0 + ntw) and count > 0; part p exists iff count > p BLK).
 template <int ND, int NF, int SPLIT>
 __global__ void k_slab_gather(int a0, int an, int b0, int bn, GridD g, TileD td, double* __restrict__ out) {
-  constexpr int TB = TileCfg<ND>::TB, W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW;
+  constexpr int TB = TileCfg<ND>::TB, W = TileCfg<ND>::WA, PS = TileCfg<ND>::PSA, NW = TileCfg<ND>::NWA;
   int A = blockIdx.x * blockDim.x + threadIdx.x;
   if (A >= an + bn) return;
   A = A < an ? a0 + A : b0 + (A - an);

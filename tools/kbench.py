@@ -21,6 +21,8 @@ ap.add_argument("--cells", type=int, default=50)
 ap.add_argument("--law", default="nh")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--phases", action="store_true")
+ap.add_argument("--no-order", action="store_true")
+ap.add_argument("--stir", type=int, default=0, help="untimed shear steps first (DESIGN.md stirred cloud)")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("NLPS_GPU_LIB", "product")))
 a = ap.parse_args()
 nlps = importlib.import_module("nl-partsol_amd.nlps")
@@ -38,13 +40,31 @@ if a.law != "nh":
         grav = [0.0, 0.0, -9.81]
     if a.law == "mixed":
         case["cloud"]["matidx"] = (np.arange(case["cloud"]["x"].shape[0]) % 3).astype(np.int32)
+if a.stir:
+    x = case["cloud"]["x"]
+    c = x.mean(axis=0)
+    v = np.zeros_like(x)
+    v[:, 0] = 10.0 * (x[:, 2] - c[2]) / (0.5 * a.cells)
+    v[:, 1] = 10.0 * (x[:, 0] - c[0]) / (0.5 * a.cells)
+    v[:, 2] = -3.0
+    case["cloud"]["vel"] = v
+    case["materials"] = [{"type": 0, "E": 1.0e5, "nu": 0.3}]
 nst = a.steps + 10
 S = nlps.Solver(3, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"], nsteps=nst)
 nodes = synth.plane_nodes(case["grid_n"], 2, 0)
 bcs = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nst), dtype=np.int32), "value": np.zeros((3, nst))}])
+if a.no_order:
+    S.L.nlps_gpu_debug_set_tile_ordering.argtypes = [C.c_void_p, C.c_int]
+    S.L.nlps_gpu_debug_set_tile_ordering(S.h, 0)
 S.initialise_shapefun()
 E = max(m["E"] for m in case["materials"])
 dt = 0.1 * case["h"] / np.sqrt(E / 1000.0)
+if a.stir:
+    bcs = nlps.BccSet([])
+    dt = 2e-3
+    S.set_resort_interval(0)
+    for t in range(a.stir):
+        S.explicit_step(bcs, 0, dt)
 for t in range(5):
     S.explicit_step(bcs, t, dt, 0.5, grav)
 if a.phases:
