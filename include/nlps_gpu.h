@@ -206,6 +206,19 @@ int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force
 int nlps_gpu_resort(nlps_gpu *h);
 int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
 
+/* Clouds whose materials follow several laws (Constitutive.c:28-258 dispatches per particle on MatProp.Type): the
+ * fused stress stage runs either as one launch per law of the kernel compiled for that law (mode 1: right when the
+ * materials sit in blocks, nearly every tile of closest nodes then holds one law) or as one kernel that dispatches on
+ * the law at run time (mode 2: right when the laws are interleaved particle by particle).  nlps_gpu_create picks the
+ * mode from the share of tiles that hold more than one law; results are identical. */
+int nlps_gpu_set_law_launch_mode(nlps_gpu *h, int mode);
+
+/* Run-to-run bit-reproducible results ("race detection"): with on != 0 every nodal sum of the fused
+ * explicit step is accumulated in a FIXED order -- the per-tile particle lists are sorted, every wave accumulates into
+ * a window of its own, the windows and the tiles are combined in index order (no floating-point atomics between
+ * workgroups).  Slower than the default path (atomic accumulation in arrival order); same results to rounding. */
+int nlps_gpu_set_deterministic(nlps_gpu *h, int on);
+
 /* ------------------------------------------------------------------ per-dof updates of the implicit driver (a21)
  * Vectors of N_A*d doubles in masked numbering, host (VecGetArray) or device pointers.  alpha = the six Newmark
  * parameters alpha_1..alpha_6 of __compute_Newmark_parameters (U-Newmark-beta.c:497-514). */

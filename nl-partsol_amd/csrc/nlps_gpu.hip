@@ -655,7 +655,7 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 // ------------------------------------------------------------------------------------------------
 template <int ND>
 __global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                            const unsigned char* __restrict__ leaving) {
+                            const unsigned char* __restrict__ leaving, const MatD* __restrict__ mats) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P.np) return;
   if (leaving && leaving[p]) {  // migration: the emigrants sort behind everything that stays
@@ -679,6 +679,8 @@ __global__ void k_sort_keys(PView P, GridD g, TileCnt tc, unsigned long long* __
     kc += mc * (unsigned long long)(ijk[a] > c ? 1 : 0);
     mc *= 2;
   }
+  (void)mats;  // (tile, law, corner type, node) was tried for clouds with several laws: K3's per-law launches load
+               // coalesced, but K2's waves lose their distinct closest nodes (0.25 -> 0.35 ms) -- net loss
   keys[p] = (kt * mc + kc) * mn + kn;
   vals[p] = p;
 }
@@ -789,6 +791,8 @@ struct nlps_gpu {
   MatD* mats_d;
   int nmats;
   int uniform_law;  // material law shared by every particle, or -1
+  int law_present;  // bit l set: some material follows law l
+  bool k3_per_law = true;  // several laws: one K3 launch per law (few mixed tiles) or one run-time-dispatch kernel
   uint8_t* rank1_d;
   nlps_host::StencilTables tab;
 
@@ -1203,8 +1207,15 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   // materials
   h->nmats = nmats;
   h->uniform_law = nmats > 0 ? mats[0].type : -1;
-  for (int i = 1; i < nmats; i++)
+  h->law_present = 0;
+  for (int i = 0; i < nmats; i++) {
     if (mats[i].type != mats[0].type) h->uniform_law = -1;
+    if (mats[i].type < 0 || mats[i].type > 3) {
+      h->err = "material type outside 0..3 (Neo-Hookean, Hencky, Drucker-Prager, Von-Mises)";
+      return 1;
+    }
+    h->law_present |= 1 << mats[i].type;
+  }
   {
     std::vector<MatD> md(nmats);
     for (int i = 0; i < nmats; i++) md[i] = make_mat(mats[i], g.nd);
@@ -1221,6 +1232,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   std::iota(h->perm.begin(), h->perm.end(), 0);
   {
     std::vector<long long> key(np);
+    std::vector<unsigned char> tile_laws(h->uniform_law < 0 ? (size_t)h->ntiles : 0, 0);
     int slab_axis = ND - 1;
     int lo = 1 << 30, hi = -1;
     const int TB = ND == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
@@ -1249,7 +1261,28 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
           hi = std::max(hi, c + 1);
         }
       }
+      const int mi = host->MatIdx ? host->MatIdx[p] : 0;
+      if (mi < 0 || mi >= nmats) {
+        h->err = "MatIdx outside the material table";
+        return 1;
+      }
       key[p] = (kt * mc + kc) * mn + kn;
+      if (h->uniform_law < 0) {  // which laws meet in which tile (decides how K3 treats a cloud with several laws)
+        unsigned char& m = tile_laws[(size_t)kt];
+        m |= (unsigned char)(1 << (mats[mi].type & 3));
+      }
+    }
+    if (h->uniform_law < 0) {
+      size_t used = 0, mixed = 0;
+      for (unsigned char m : tile_laws) {
+        used += m != 0;
+        mixed += (m & (m - 1)) != 0;
+      }
+      // blocks of different materials (a footing on soil): nearly every tile holds one law and K3 runs as one launch of
+      // the single-law kernel per law, each taking its tiles (0 scratch, the speed of the uniform cloud).  Laws
+      // interleaved particle by particle: every launch would touch every tile and every cache line (measured 0.68 ms
+      // against 0.51 ms for the one kernel that dispatches on the law at run time), so that kernel stays for them.
+      h->k3_per_law = used > 0 && 4 * mixed <= used;
     }
     std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     h->slab_lo = std::max(0, lo - 3);
@@ -1347,8 +1380,8 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr) {
   TileCnt tc;
   for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
   tc.count = nullptr;
-  if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving);
-  else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving);
+  if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
+  else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
   HIPCHK(hipGetLastError());
   size_t bytes = h->cub_tmp_bytes;
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
@@ -1500,6 +1533,14 @@ extern "C" int nlps_gpu_migration_commit(nlps_gpu* h, const void* rows_a, int n_
 extern "C" int nlps_gpu_resort(nlps_gpu* h) { return resort(h); }
 extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_set_tile_ordering(nlps_gpu* h, int on) {
   h->tile_ordering = on;  // developer switch (tools/kbench.py --no-order)
+  return 0;
+}
+extern "C" int nlps_gpu_set_law_launch_mode(nlps_gpu* h, int mode) {
+  if (mode != 1 && mode != 2) {
+    h->err = "nlps_gpu_set_law_launch_mode: 1 = one launch per law, 2 = one kernel dispatching on the law";
+    return 1;
+  }
+  h->k3_per_law = mode == 1;
   return 0;
 }
 extern "C" int nlps_gpu_set_deterministic(nlps_gpu* h, int on) {
@@ -2176,20 +2217,36 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
 #define NLPS_K3(NDv, LAWv)                                                                                      \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d, (const double*)nullptr)
+#define NLPS_K3F(NDv, LAWv)                                                                                     \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1, true>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
+                     h->mats_d, h->prm, h->gstatus_d, (const double*)nullptr)
     const int law = h->uniform_law;
     if (ND == 2) {
       if (law == 0) NLPS_K3(2, 0);
       else if (law == 1) NLPS_K3(2, 1);
       else if (law == 2) NLPS_K3(2, 2);
       else if (law == 3) NLPS_K3(2, 3);
-      else NLPS_K3(2, -1);
+      else if (!h->k3_per_law) NLPS_K3(2, -1);
+      else {  // several laws in the cloud: one launch of the single-law kernel per law present
+        if (h->law_present & 1) NLPS_K3F(2, 0);
+        if (h->law_present & 2) NLPS_K3F(2, 1);
+        if (h->law_present & 4) NLPS_K3F(2, 2);
+        if (h->law_present & 8) NLPS_K3F(2, 3);
+      }
     } else {
       if (law == 0) NLPS_K3(3, 0);
       else if (law == 1) NLPS_K3(3, 1);
       else if (law == 2) NLPS_K3(3, 2);
       else if (law == 3) NLPS_K3(3, 3);
-      else NLPS_K3(3, -1);
+      else if (!h->k3_per_law) NLPS_K3(3, -1);
+      else {
+        if (h->law_present & 1) NLPS_K3F(3, 0);
+        if (h->law_present & 2) NLPS_K3F(3, 1);
+        if (h->law_present & 4) NLPS_K3F(3, 2);
+        if (h->law_present & 8) NLPS_K3F(3, 3);
+      }
     }
+#undef NLPS_K3F
 #undef NLPS_K3
   };
   auto launch_k5 = [&](int cls) {

@@ -481,13 +481,19 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
           const double nr = sqrt(aux);
           if (100.0 * 0.5 * (Ra + nr) * fabs(dlr) <= prm.tol_wrapper && dl2 * (Ra * Ra) <= 1.0e-6) {
             Zinv *= fma(0.5, dlr, 1.0);
+            // l(i) = a - h (i - 2) along every axis (Lme::geom): D.l(i) = -dl a + (i - 2) dl h; only the centre
+            // values of l stay live through the iteration
+            const double hh = c.lx[2] - c.lx[3];
+            const double sx = dl[0] * hh, sy = dl[1] * hh, sz = (ND == 3) ? dl[ND - 1] * hh : 0.0;
+            const double bx0 = -dl[0] * c.lx[2], by0 = -dl[1] * c.ly[2], bz0 = (ND == 3) ? -dl[ND - 1] * c.lz[2 % KN] : 0.0;
 #pragma unroll
             for (int i = 0; i < 5; i++) {
-              const double tx = -dl[0] * c.lx[i], ty = -dl[1] * c.ly[i];
+              const double u = (double)(i - 2);
+              const double tx = fma(u, sx, bx0), ty = fma(u, sy, by0);
               c.ex[i] *= fma(tx, fma(tx, fma(tx, 1.0 / 6.0, 0.5), 1.0), 1.0);
               c.ey[i] *= fma(ty, fma(ty, fma(ty, 1.0 / 6.0, 0.5), 1.0), 1.0);
               if (ND == 3) {
-                const double tz = -dl[ND - 1] * c.lz[i % KN];
+                const double tz = fma(u, sz, bz0);
                 c.ez[i % KN] *= fma(tz, fma(tz, fma(tz, 1.0 / 6.0, 0.5), 1.0), 1.0);
               }
             }
@@ -571,7 +577,10 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
 // DF, F_n1, J_n1 with the implicit driver's clamp of J <= 0 (U-Newmark-beta.c:1137-1142).
 // MODE 2: MODE 0 plus the rate tensors dt_DF = sum dV_A (x) grad N_A and dt_F_n1 = dt_DF F_n + DF dt_F_n
 // (compute-Strains.c:48-72, 176-207) from a second gather window dV.
-template <int ND, int LAW, int MODE>
+// FILT (clouds with several laws): the launch handles only the tile's particles whose material follows LAW; they are
+// compacted into an LDS list first, so every lane works and the kernel is the single-law specialisation (one launch per
+// law present; the run-time dispatch over all laws in one kernel needed 436 B of scratch per lane and 0.51 ms).
+template <int ND, int LAW, int MODE, bool FILT = false>
 __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus,
                                                const double* __restrict__ dVgrid) {
@@ -590,8 +599,27 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
   if (wb >= td.range[2 * (K3_SPLIT - 1) + 1]) return;
   const int2 wk = td.work[K3_SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
-  const int cnt = td.count[tile];
+  int cnt = td.count[tile];
   PH_INIT
+  constexpr int SELCAP = FILT ? 4096 : 1;
+  __shared__ int sel[SELCAP];
+  __shared__ int nsel;
+  bool listed = false;  // sel[] holds this launch's particles
+  if (FILT) {
+    const int start0 = td.start[tile];
+    if (threadIdx.x == 0) nsel = 0;
+    __syncthreads();
+    if (cnt <= SELCAP) {
+      for (int s = threadIdx.x; s < cnt; s += K3_BLK) {
+        const int p = td.order[start0 + s];
+        if (mats[P.mat[p]].type == LAW) sel[atomicAdd(&nsel, 1) % SELCAP] = p;
+      }
+      __syncthreads();
+      cnt = nsel;
+      listed = true;
+      if (cnt == 0) return;  // uniform: no particle of this law in the tile
+    }
+  }
   int w0[3];
   tile_origin<ND>(td, tile, w0);
   for (int idx = threadIdx.x; idx < NW; idx += K3_BLK) {
@@ -613,7 +641,8 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
   const int start = td.start[tile];
   PH(8)
   for (int s = part * K3_BLK + threadIdx.x; s < cnt; s += K3_BLK * K3_SPLIT) {
-    const int p = td.order[start + s];
+    const int p = (FILT && listed) ? sel[FILT ? s : 0] : td.order[start + s];
+    if (FILT && !listed && mats[P.mat[p]].type != LAW) continue;  // oversized tile: filter per lane
     Lme<ND> c;
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;

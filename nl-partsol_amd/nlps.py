@@ -66,7 +66,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_nodal_traction_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
+           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_set_law_launch_mode", "nlps_gpu_set_deterministic", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_form_initial_guess", "nlps_gpu_nodal_kinetic_increments", "nlps_gpu_nodal_inertial_forces",
            "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_set_grouped", "nlps_gpu_tangent_coo",
            "nlps_gpu_sparsity_pattern",
@@ -98,6 +98,8 @@ def lib():
         L.nlps_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Grid), C.POINTER(Params),
                                       C.POINTER(Material), C.c_int, C.POINTER(Particles), C.c_int, C.c_void_p]
         L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
+        L.nlps_gpu_set_law_launch_mode.argtypes = [C.c_void_p, C.c_int]
+        L.nlps_gpu_set_deterministic.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.nlps_gpu_set_ghost_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_form_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
@@ -413,6 +415,12 @@ class Solver:
 
     def set_resort_interval(self, n):
         self._chk(self.L.nlps_gpu_set_resort_interval(self.h, int(n)))
+
+    def set_law_launch_mode(self, mode):
+        self._chk(self.L.nlps_gpu_set_law_launch_mode(self.h, int(mode)))
+
+    def set_deterministic(self, on=True):
+        self._chk(self.L.nlps_gpu_set_deterministic(self.h, 1 if on else 0))
 
     def touched_layers(self):
         lo, hi = C.c_int(0), C.c_int(0)

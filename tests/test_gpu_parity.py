@@ -273,10 +273,12 @@ def test_long_flight_index_maps(ndim):
     assert moved[ndim - 1] >= 4.0, "the block has to travel several cells"
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("ndim", [2, 3])
-def test_mixed_materials(ndim):
-    """Three laws in one cloud (MatIdx selects the law per particle, Constitutive.c:28-258): the kernels
-    compiled for run-time dispatch instead of the single-law specialisations."""
+def test_mixed_materials(ndim, mode):
+    """Three laws in one cloud (MatIdx selects the law per particle, Constitutive.c:28-258): mode 2 = the kernel
+    compiled for run-time dispatch, mode 1 = one launch per law of the single-law kernels, each compacting its
+    particles out of every tile list."""
     o = orc()
     n = nlps()
     vel = [0.0, -2.0] if ndim == 2 else [0.0, 0.0, -2.0]
@@ -292,6 +294,7 @@ def test_mixed_materials(ndim):
     dt = 0.1 * case["h"] / np.sqrt(2.0e4 / 1000.0)
     M, P, prm, mats = oracle_setup(case)
     S = gpu_setup(case, nsteps=nsteps)
+    S.set_law_launch_mode(mode)
     stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps, gravity=grav)
     gb = n.BccSet(bcs_list)
     for t in range(nsteps):

@@ -32,14 +32,18 @@ grav = None
 if a.law != "nh":
     dp = synth.drucker_prager_material()
     mats = {"hencky": [{"type": 1, "E": 1.0e7, "nu": 0.3}], "dp": [dp],
-            "mixed": [{"type": 0, "E": 2.0e4, "nu": 0.3}, {"type": 1, "E": 1.0e4, "nu": 0.25}, dp]}[a.law]
+            "mixed": [{"type": 0, "E": 2.0e4, "nu": 0.3}, {"type": 1, "E": 1.0e4, "nu": 0.25}, dp],
+            "layers": [{"type": 0, "E": 2.0e4, "nu": 0.3}, {"type": 1, "E": 1.0e4, "nu": 0.25}, dp]}[a.law]
     case["materials"] = mats
-    if a.law in ("dp", "mixed"):
+    if a.law in ("dp", "mixed", "layers"):
         case["cloud"]["kappa_n"][:] = dp["kappa_0"]
         case["cloud"]["vel"][:] = 0.0
         grav = [0.0, 0.0, -9.81]
-    if a.law == "mixed":
+    if a.law == "mixed":  # laws interleaved particle by particle (worst case)
         case["cloud"]["matidx"] = (np.arange(case["cloud"]["x"].shape[0]) % 3).astype(np.int32)
+    if a.law == "layers":  # three horizontal layers of different materials
+        z = case["cloud"]["x"][:, 2]
+        case["cloud"]["matidx"] = np.minimum(2, ((z - z.min()) / (z.max() - z.min() + 1e-9) * 3).astype(np.int32))
 if a.stir:
     x = case["cloud"]["x"]
     c = x.mean(axis=0)
