@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=16, help="cells per axis of the CPU-baseline sample")
     ap.add_argument("--halo", choices=["p2p", "allreduce"], default="p2p")
+    ap.add_argument("--halo-impl", choices=["c", "torch"], default="c",
+                    help="N > 1: c = the library's own RCCL exchange (nlps_gpu_rccl_attach: ncclSend/ncclRecv on a "
+                         "library-owned stream, no Python in the step); torch = the callback through torch.distributed")
     ap.add_argument("--migrate-every", type=int, default=0,
                     help="N > 1: hand particles whose closest node left the rank's slab to the neighbour every k "
                          "steps (0 = never: the default 25 steps move the cloud by 0.25 cells)")
@@ -294,22 +297,33 @@ def main():
     nodes = synth.plane_nodes(case["grid_n"], 2, 0)
     bcs = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, total_steps), dtype=np.int32),
                         "value": np.zeros((3, total_steps))}])
+    halo_impl = "none"
     if world > 1:
         halo_mod = importlib.import_module("nl-partsol_amd.halo")
         gn = case["grid_n"]
         lo, hi = halo_mod.SlabHalo.layer_ranges(world, cells_z, margin, gn[2])
-        halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)
+        halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)  # migration helper
         nnodes = gn[0] * gn[1] * gn[2]
+        halo_impl = a.halo_impl if backend == "nccl" else "torch"  # the gloo rehearsal has no RCCL
+        if halo_impl == "c":
+            # the library creates its own communicator: rank 0's ncclUniqueId reaches the others through the process group
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.tensor(list(nlps.Solver.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            S.rccl_attach(bytes(uid.cpu().tolist()), rank, world, lo, hi, mode=1 if a.halo == "allreduce" else 0)
+            if a.overlap == 0:
+                S.set_ghost_bands(*halo.ghost_bands(rank), False)
+        else:
+            def exchange(dptr, nfield, elem, kind, phase):
+                return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind, phase)
 
-        def exchange(dptr, nfield, elem, kind, phase):
-            return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind, phase)
-
-        S.set_halo_exchange(exchange)
-        # the three exchanges of a step run behind the tiles that do not touch a ghost band
-        band_lo, band_hi = halo.ghost_bands(rank)
-        S.set_ghost_bands(band_lo, band_hi, a.overlap == 1)
-        # per-step nodal work only on the layers this rank can touch (the grid grows with the rank count)
-        S.set_node_window(lo[rank], hi[rank])
+            S.set_halo_exchange(exchange)
+            # the three exchanges of a step run behind the tiles that do not touch a ghost band
+            band_lo, band_hi = halo.ghost_bands(rank)
+            S.set_ghost_bands(band_lo, band_hi, a.overlap == 1)
+            # per-step nodal work only on the layers this rank can touch (the grid grows with the rank count)
+            S.set_node_window(lo[rank], hi[rank])
     S.initialise_shapefun()
     dt = 0.1 * case["h"] / 100.0  # CFL 0.1, celerity sqrt(E/rho) = 100
 
@@ -414,7 +428,7 @@ def main():
                                    "Neo-Hookean E=1e7 nu=0.3, explicit predictor-corrector step, 1xMI355X per rank; "
                                    "z-slabs for N>1 (%s scaling)" % (npart, cells, cells, cells_z, a.scaling),
                        "particles_total": npart * world, "grid_nodes": int(np.prod(case["grid_n"])),
-                       "halo": a.halo if world > 1 else "none",
+                       "halo": a.halo if world > 1 else "none", "halo_impl": halo_impl,
                        "halo_overlap": bool(a.overlap) if world > 1 else None,
                        "resorts_in_timed_region": 1, "library_default_resort_interval": 50},
             "roofline": {"bound": domk.get("bound", "hbm"), "kernel": names[dom], "achieved": achieved,

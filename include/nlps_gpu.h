@@ -206,6 +206,31 @@ int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force
 int nlps_gpu_resort(nlps_gpu *h);
 int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
 
+/* ------------------------------------------------------------------ multi-GPU: ghost-layer exchange over RCCL, owned by
+ * the library.  One process per GPU; the particles are range-partitioned into slabs along the slowest grid
+ * axis, rank r touches node layers [layer_lo[r], layer_hi[r]] (inclusive, every rank passes the ranges of ALL ranks).
+ * After every nodal scatter of a stage function or of the fused explicit step the layers shared with rank r-1 / r+1
+ * are summed (doubles) or OR-ed (activation flags): ncclSend / ncclRecv of the two contiguous slices on a
+ * library-owned stream, behind the tiles that do not touch a shared layer (mode 0), or one ncclAllReduce of the whole
+ * array (mode 1, BASELINE.json's wording).  librccl.so.1 is dlopen()ed at attach time.
+ * nlps_gpu_rccl_unique_id: rank 0 makes the 128-byte ncclUniqueId, the host driver hands it to the other ranks
+ * (MPI_Bcast, a file, ...).  _attach creates the communicator (ncclCommInitRank, collective), restricts the per-step
+ * nodal work to the rank's layers (nlps_gpu_set_node_window) and declares the shared layers (nlps_gpu_set_ghost_bands);
+ * _attach_comm takes an existing ncclComm_t.  Call before nlps_gpu_initialize_lme.
+ * nlps_gpu_rccl_reduce: implicit driver on several ranks -- a masked vector (device pointer, n doubles: residual,
+ * lumped mass) summed onto `root`, the rank that runs the PETSc solve, or onto all ranks (root < 0). */
+int nlps_gpu_rccl_unique_id(void *id128);
+int nlps_gpu_rccl_attach(nlps_gpu *h, const void *id128, int rank, int world, const int *layer_lo,
+                         const int *layer_hi, int mode);
+int nlps_gpu_rccl_attach_comm(nlps_gpu *h, void *nccl_comm, int rank, int world, const int *layer_lo,
+                              const int *layer_hi, int mode);
+int nlps_gpu_rccl_detach(nlps_gpu *h);
+int nlps_gpu_rccl_reduce(nlps_gpu *h, double *vec, size_t n, int root);
+/* world-size-1 self-test of the exchange (one-GPU boxes): the rank is its own two neighbours -- the lowest three
+ * layers of its range are exchanged with the highest three by ncclSend / ncclRecv to itself; overlap = the two-phase
+ * (side-stream) form. */
+int nlps_gpu_rccl_selftest_exchange(nlps_gpu *h, void *dptr, int nfield, int elem_bytes, int kind, int overlap);
+
 /* Clouds whose materials follow several laws (Constitutive.c:28-258 dispatches per particle on MatProp.Type): the
  * fused stress stage runs either as one launch per law of the kernel compiled for that law (mode 1: right when the
  * materials sit in blocks, nearly every tile of closest nodes then holds one law) or as one kernel that dispatches on

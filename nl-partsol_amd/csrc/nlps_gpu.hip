@@ -16,12 +16,16 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is dlopen()ed when a communicator is attached
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -867,6 +871,7 @@ struct nlps_gpu {
 
   nlps_halo_fn halo;
   void* halo_ctx;
+  struct RcclHalo* rccl = nullptr;  // ghost-layer exchange over RCCL owned by the library (nlps_gpu_rccl_attach)
 
   bool timing;
   hipEvent_t ev[8];
@@ -1554,6 +1559,7 @@ extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
 
 extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   if (!h) return 0;
+  (void)nlps_gpu_rccl_detach(h);
   (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
@@ -1670,7 +1676,306 @@ extern "C" int nlps_gpu_status_flags(nlps_gpu* h, int* flags) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Ghost-layer exchange over RCCL, owned by the library (no Python, no callback).
+// Slab partition along the slowest grid axis: rank r may touch node layers [lo[r], hi[r]]; the layers it shares with
+// rank r-1 / r+1 are one contiguous slice of every grid-numbered nodal array.  An exchange = ncclSend of the slice
+// + ncclRecv of the neighbour's into a receive buffer (one group, two xGMI links busy at once), then slice += buffer
+// (sums) or slice = max(slice, buffer) (flags).  Mode 1 keeps the simple all-reduce of the whole array.
+// Phases (nlps_halo_fn): 0 = in the order of the handle's stream; 1 = on the library's side stream, behind everything
+// queued on the handle's stream so far; 2 = the handle's stream waits for it.
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static const char* rccl_load() {  // nullptr = loaded
+  if (g_rccl.lib) return nullptr;
+  // the soname every ROCm build of RCCL carries: a copy the host process has loaded already (torch's, the MPI
+  // driver's) is reused, otherwise the system one is loaded
+  void* L = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!L) L = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!L) return "librccl.so.1 not found (dlopen)";
+#define NLPS_SYM(field, name)                                  \
+  *(void**)(&g_rccl.field) = dlsym(L, name);                   \
+  if (!g_rccl.field) return "RCCL symbol missing: " name;
+  NLPS_SYM(GetUniqueId, "ncclGetUniqueId")
+  NLPS_SYM(CommInitRank, "ncclCommInitRank")
+  NLPS_SYM(CommDestroy, "ncclCommDestroy")
+  NLPS_SYM(GroupStart, "ncclGroupStart")
+  NLPS_SYM(GroupEnd, "ncclGroupEnd")
+  NLPS_SYM(Send, "ncclSend")
+  NLPS_SYM(Recv, "ncclRecv")
+  NLPS_SYM(AllReduce, "ncclAllReduce")
+  NLPS_SYM(Reduce, "ncclReduce")
+  NLPS_SYM(GetErrorString, "ncclGetErrorString")
+#undef NLPS_SYM
+  g_rccl.lib = L;
+  return nullptr;
+}
+
+struct RcclHalo {
+  ncclComm_t comm = nullptr;
+  bool own_comm = false;
+  int rank = 0, world = 1, mode = 0;  // mode 0: neighbour send/recv, 1: all-reduce of the whole array
+  std::vector<int> lo, hi;            // node layers rank r may touch (inclusive)
+  hipStream_t side = nullptr;
+  void* rbuf[2] = {nullptr, nullptr};  // receive buffers: from rank-1, from rank+1
+  size_t rbuf_bytes[2] = {0, 0};
+  struct Ev {
+    hipEvent_t start = nullptr, done = nullptr;
+    bool pending = false;
+  };
+  std::map<const void*, Ev> ev;  // one pair of events per nodal array, re-recorded every step
+  bool self_loop = false;        // world 1 self-test: the rank is its own two neighbours
+};
+
+template <class T>
+__global__ void k_halo_add(T* __restrict__ a, const T* __restrict__ b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+__global__ void k_halo_max(unsigned char* __restrict__ a, const unsigned char* __restrict__ b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = a[i] > b[i] ? a[i] : b[i];
+}
+
+#define RCCLCHK(call)                                                                                   \
+  do {                                                                                                  \
+    ncclResult_t r_ = (call);                                                                           \
+    if (r_ != ncclSuccess) {                                                                            \
+      h->err = std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?");   \
+      fprintf(stderr, "\033[1;31mError in nlps_gpu (RCCL): %s\033[0m\n", h->err.c_str());               \
+      return 1;                                                                                         \
+    }                                                                                                   \
+  } while (0)
+
+// the exchange itself, in the order of stream s
+static int rccl_exchange_on(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, hipStream_t s) {
+  RcclHalo* R = h->rccl;
+  const int nl = h->g.n[h->nd - 1];
+  const size_t plane = (size_t)h->g.nnodes / nl;
+  const ncclDataType_t dt = elem == 8 ? ncclDouble : ncclUint8;
+  if (R->mode == 1) {
+    if (R->world > 1)
+      RCCLCHK(g_rccl.AllReduce(dptr, dptr, (size_t)h->g.nnodes * nfield, dt, kind == 0 ? ncclSum : ncclMax, R->comm, s));
+    return 0;
+  }
+  struct Part {
+    char* sl;
+    size_t count;
+    int peer, k;
+  } parts[2];
+  int np = 0;
+  for (int k = 0; k < 2; k++) {
+    const int nb = R->rank + (k == 0 ? -1 : 1);
+    int a, b;
+    if (R->self_loop) {  // self-test: the lowest / highest three layers stand for the two shared slices
+      a = k == 0 ? R->lo[0] : std::max(R->lo[0], R->hi[0] - 2);
+      b = k == 0 ? std::min(R->hi[0], R->lo[0] + 2) : R->hi[0];
+    } else {
+      if (nb < 0 || nb >= R->world) continue;
+      a = std::max(R->lo[R->rank], R->lo[nb]);
+      b = std::min(R->hi[R->rank], R->hi[nb]);
+      if (a > b) continue;
+    }
+    const size_t count = (size_t)(b - a + 1) * plane * nfield, bytes = count * elem;
+    if (bytes > R->rbuf_bytes[k]) {
+      HIPCHK(hipDeviceSynchronize());
+      if (R->rbuf[k]) HIPCHK(hipFree(R->rbuf[k]));
+      HIPCHK(hipMalloc(&R->rbuf[k], bytes));
+      R->rbuf_bytes[k] = bytes;
+    }
+    parts[np++] = {(char*)dptr + (size_t)a * plane * nfield * elem, count, R->self_loop ? R->rank : nb, k};
+  }
+  if (np == 0) return 0;
+  RCCLCHK(g_rccl.GroupStart());
+  for (int q = 0; q < np; q++) {
+    // self-test: what goes "down" comes back as what arrives "from above" and vice versa
+    RCCLCHK(g_rccl.Send(parts[q].sl, parts[q].count, dt, parts[q].peer, R->comm, s));
+    RCCLCHK(g_rccl.Recv(R->rbuf[R->self_loop ? 1 - parts[q].k : parts[q].k], parts[q].count, dt, parts[q].peer, R->comm, s));
+  }
+  RCCLCHK(g_rccl.GroupEnd());
+  // after the sends in stream order, so the neighbour got the un-summed slice
+  for (int q = 0; q < np; q++) {
+    const size_t n = parts[q].count;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (elem == 8 && kind == 0)
+      hipLaunchKernelGGL(k_halo_add<double>, dim3(grid), dim3(256), 0, s, (double*)parts[q].sl, (const double*)R->rbuf[parts[q].k], n);
+    else
+      hipLaunchKernelGGL(k_halo_max, dim3(grid), dim3(256), 0, s, (unsigned char*)parts[q].sl, (const unsigned char*)R->rbuf[parts[q].k], n);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int rccl_halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase) {
+  RcclHalo* R = h->rccl;
+  if (R->world == 1 && !R->self_loop) return 0;
+  if (phase == 0) return rccl_exchange_on(h, dptr, nfield, elem, kind, h->stream);
+  RcclHalo::Ev& e = R->ev[dptr];
+  if (!e.start) {
+    HIPCHK(hipEventCreateWithFlags(&e.start, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e.done, hipEventDisableTiming));
+  }
+  if (phase == 1) {
+    HIPCHK(hipEventRecord(e.start, h->stream));
+    HIPCHK(hipStreamWaitEvent(R->side, e.start, 0));
+    if (rccl_exchange_on(h, dptr, nfield, elem, kind, R->side)) return 1;
+    HIPCHK(hipEventRecord(e.done, R->side));
+    e.pending = true;
+    return 0;
+  }
+  if (e.pending) {
+    HIPCHK(hipStreamWaitEvent(h->stream, e.done, 0));
+    e.pending = false;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_rccl_unique_id(void* id128) {
+  if (rccl_load()) return 1;
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return 1;
+  memcpy(id128, &id, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+static int rccl_attach_common(nlps_gpu* h, ncclComm_t comm, bool own, int rank, int world, const int* layer_lo,
+                              const int* layer_hi, int mode) {
+  if (h->rccl) {
+    h->err = "nlps_gpu_rccl_attach: a communicator is attached already (nlps_gpu_rccl_detach first)";
+    return 1;
+  }
+  const int nl = h->g.n[h->nd - 1];
+  if (world < 1 || rank < 0 || rank >= world || (mode != 0 && mode != 1)) {
+    h->err = "nlps_gpu_rccl_attach: bad rank / world / mode";
+    return 1;
+  }
+  RcclHalo* R = new RcclHalo();
+  R->comm = comm;
+  R->own_comm = own;
+  R->rank = rank;
+  R->world = world;
+  R->mode = mode;
+  for (int r = 0; r < world; r++) {
+    const int a = layer_lo ? layer_lo[r] : 0, b = layer_hi ? layer_hi[r] : nl - 1;
+    if (a < 0 || b >= nl || a > b) {
+      delete R;
+      h->err = "nlps_gpu_rccl_attach: layer range outside the grid";
+      return 1;
+    }
+    R->lo.push_back(a);
+    R->hi.push_back(b);
+  }
+  for (int r = 0; r + 2 < world; r++)
+    if (R->hi[r] >= R->lo[r + 2]) {
+      delete R;
+      h->err = "nlps_gpu_rccl_attach: slabs too thin (a rank overlaps its second neighbour)";
+      return 1;
+    }
+  HIPCHK(hipStreamCreateWithFlags(&R->side, hipStreamNonBlocking));
+  h->rccl = R;
+  // ghost bands (layers shared with a neighbour) and the node window follow from the layer ranges
+  const int band_lo = rank > 0 ? std::min(R->hi[rank], R->hi[rank - 1]) : -1;
+  const int band_hi = rank + 1 < world ? std::max(R->lo[rank], R->lo[rank + 1]) : nl;
+  h->band_lo = rank > 0 && R->hi[rank - 1] >= R->lo[rank] ? band_lo : -(1 << 30);
+  h->band_hi = rank + 1 < world && R->lo[rank + 1] <= R->hi[rank] ? band_hi : (1 << 30);
+  h->overlap = world > 1;
+  if (world > 1 && nlps_gpu_set_node_window(h, R->lo[rank], R->hi[rank])) return 1;
+  return 0;
+}
+
+extern "C" int nlps_gpu_rccl_attach(nlps_gpu* h, const void* id128, int rank, int world, const int* layer_lo,
+                                    const int* layer_hi, int mode) {
+  if (const char* e = rccl_load()) {
+    h->err = e;
+    return 1;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  RCCLCHK(g_rccl.CommInitRank(&comm, world, id, rank));
+  if (rccl_attach_common(h, comm, true, rank, world, layer_lo, layer_hi, mode)) {
+    (void)g_rccl.CommDestroy(comm);
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int nlps_gpu_rccl_attach_comm(nlps_gpu* h, void* nccl_comm, int rank, int world, const int* layer_lo,
+                                         const int* layer_hi, int mode) {
+  if (const char* e = rccl_load()) {
+    h->err = e;
+    return 1;
+  }
+  return rccl_attach_common(h, (ncclComm_t)nccl_comm, false, rank, world, layer_lo, layer_hi, mode);
+}
+
+extern "C" int nlps_gpu_rccl_detach(nlps_gpu* h) {
+  RcclHalo* R = h->rccl;
+  if (!R) return 0;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : R->ev) {
+    if (kv.second.start) (void)hipEventDestroy(kv.second.start);
+    if (kv.second.done) (void)hipEventDestroy(kv.second.done);
+  }
+  for (int k = 0; k < 2; k++)
+    if (R->rbuf[k]) (void)hipFree(R->rbuf[k]);
+  if (R->side) (void)hipStreamDestroy(R->side);
+  if (R->own_comm && R->comm) (void)g_rccl.CommDestroy(R->comm);
+  delete R;
+  h->rccl = nullptr;
+  h->overlap = false;
+  h->band_lo = -(1 << 30);
+  h->band_hi = 1 << 30;
+  return 0;
+}
+
+// Implicit driver on several ranks: the masked residual / lumped-mass vector of every rank summed onto
+// the rank that runs the PETSc solve (root >= 0) or onto all ranks (root < 0).  vec: device pointer, n doubles.
+extern "C" int nlps_gpu_rccl_reduce(nlps_gpu* h, double* vec, size_t n, int root) {
+  RcclHalo* R = h->rccl;
+  if (!R) {
+    h->err = "nlps_gpu_rccl_reduce: no communicator attached";
+    return 1;
+  }
+  if (R->world == 1 || n == 0) return 0;
+  if (root < 0) RCCLCHK(g_rccl.AllReduce(vec, vec, n, ncclDouble, ncclSum, R->comm, h->stream));
+  else RCCLCHK(g_rccl.Reduce(vec, vec, n, ncclDouble, ncclSum, root, R->comm, h->stream));
+  return 0;
+}
+
+// World-size-1 self-test of the exchange machinery (a one-GPU box cannot hold two ranks): the rank acts as its own
+// two neighbours, i.e. the lowest three layers of its range are exchanged with the highest three through
+// ncclSend / ncclRecv to itself.  After the call array[low slice] += old array[high slice] and vice versa.
+extern "C" int nlps_gpu_rccl_selftest_exchange(nlps_gpu* h, void* dptr, int nfield, int elem_bytes, int kind, int overlap) {
+  RcclHalo* R = h->rccl;
+  if (!R || R->world != 1) {
+    h->err = "nlps_gpu_rccl_selftest_exchange: needs an attached communicator of world size 1";
+    return 1;
+  }
+  R->self_loop = true;
+  int st = 0;
+  if (overlap) st = rccl_halo(h, dptr, nfield, elem_bytes, kind, 1) || rccl_halo(h, dptr, nfield, elem_bytes, kind, 2);
+  else st = rccl_halo(h, dptr, nfield, elem_bytes, kind, 0);
+  R->self_loop = false;
+  return st;
+}
+
 static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase = 0) {
+  if (h->rccl) return rccl_halo(h, dptr, nfield, elem, kind, phase);
   if (!h->halo) return 0;
   int st = h->halo(h->halo_ctx, dptr, nfield, elem, kind, phase);
   if (st) {
@@ -2160,7 +2465,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // ghost band have produced their part and is waited for only before those tiles need the result; the tiles
   // (and nodes) away from the bands run in between, on the handle's stream, while the exchange proceeds on the
   // callee's stream.  Without overlap each stage is one pass over all tiles and the exchange blocks in place.
-  const bool ov = h->halo && h->overlap;
+  const bool ov = (h->halo || h->rccl) && h->overlap;
   double gv[3] = {0, 0, 0};
   if (gravity)
     for (int a = 0; a < ND; a++) gv[a] = gravity[a];

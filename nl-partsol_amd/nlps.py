@@ -66,7 +66,9 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_nodal_traction_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_set_law_launch_mode", "nlps_gpu_set_deterministic", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
+           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_set_law_launch_mode", "nlps_gpu_set_deterministic",
+           "nlps_gpu_rccl_unique_id", "nlps_gpu_rccl_attach", "nlps_gpu_rccl_attach_comm", "nlps_gpu_rccl_detach",
+           "nlps_gpu_rccl_reduce", "nlps_gpu_rccl_selftest_exchange", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_form_initial_guess", "nlps_gpu_nodal_kinetic_increments", "nlps_gpu_nodal_inertial_forces",
            "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_set_grouped", "nlps_gpu_tangent_coo",
            "nlps_gpu_sparsity_pattern",
@@ -100,6 +102,12 @@ def lib():
         L.nlps_gpu_set_resort_interval.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_set_law_launch_mode.argtypes = [C.c_void_p, C.c_int]
         L.nlps_gpu_set_deterministic.argtypes = [C.c_void_p, C.c_int]
+        L.nlps_gpu_rccl_unique_id.argtypes = [C.c_void_p]
+        L.nlps_gpu_rccl_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int]
+        L.nlps_gpu_rccl_attach_comm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int]
+        L.nlps_gpu_rccl_detach.argtypes = [C.c_void_p]
+        L.nlps_gpu_rccl_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.nlps_gpu_rccl_selftest_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.nlps_gpu_set_ghost_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_form_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
@@ -418,6 +426,31 @@ class Solver:
 
     def set_law_launch_mode(self, mode):
         self._chk(self.L.nlps_gpu_set_law_launch_mode(self.h, int(mode)))
+
+    # ------------------------------------------------------------------ RCCL owned by the library
+    @staticmethod
+    def rccl_unique_id():
+        """128-byte ncclUniqueId (made by rank 0, handed to the other ranks by the host driver)"""
+        buf = (C.c_ubyte * 128)()
+        if lib().nlps_gpu_rccl_unique_id(buf):
+            raise NlpsError("nlps_gpu_rccl_unique_id failed (librccl.so.1 not loadable?)")
+        return bytes(buf)
+
+    def rccl_attach(self, uid, rank, world, layer_lo, layer_hi, mode=0):
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        lo = np.ascontiguousarray(layer_lo, dtype=np.int32)
+        hi = np.ascontiguousarray(layer_hi, dtype=np.int32)
+        self._chk(self.L.nlps_gpu_rccl_attach(self.h, buf, int(rank), int(world), _i(lo), _i(hi), int(mode)))
+
+    def rccl_detach(self):
+        self._chk(self.L.nlps_gpu_rccl_detach(self.h))
+
+    def rccl_reduce(self, dptr, n, root=-1):
+        self._chk(self.L.nlps_gpu_rccl_reduce(self.h, _vp(dptr), int(n), int(root)))
+
+    def rccl_selftest_exchange(self, dptr, nfield, elem_bytes, kind, overlap):
+        self._chk(self.L.nlps_gpu_rccl_selftest_exchange(self.h, _vp(dptr), int(nfield), int(elem_bytes), int(kind),
+                                                         1 if overlap else 0))
 
     def set_deterministic(self, on=True):
         self._chk(self.L.nlps_gpu_set_deterministic(self.h, 1 if on else 0))

@@ -1,0 +1,79 @@
+"""The ghost-layer exchange over RCCL as the LIBRARY does it (nlps_gpu_rccl_attach: ncclCommInitRank, ncclSend /
+ncclRecv on a library-owned stream, add / max kernels, events), without Python in the data path.  A one-GPU box holds one
+rank only, so the wire is exercised with the rank as its own neighbour (nlps_gpu_rccl_selftest_exchange); the world-2 / 3
+partition logic is covered by tests/test_multirank_gloo.py (CPU) and test_multirank_on_one_gpu (callback double)."""
+import numpy as np
+import pytest
+
+from util import assert_close, dirichlet_plane, gpu_setup, make_case, nlps
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_owned_by_the_library_world_1():
+    import torch
+    n = nlps()
+    case = make_case(3, [11, 10, 12], [3, 3, 3], [5, 4, 6], velocity=[0.0, 0.0, -10.0])
+    gn = case["grid_n"]
+    nl, plane = gn[2], gn[0] * gn[1]
+    S = gpu_setup(case, init=False, nsteps=4)
+    uid = n.Solver.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    S.rccl_attach(uid, 0, 1, [0], [nl - 1], mode=0)
+    with pytest.raises(n.NlpsError):
+        S.rccl_attach(uid, 0, 1, [0], [nl - 1])  # one communicator per handle
+    # the wire: lowest three layers <-> highest three layers through ncclSend / ncclRecv to itself
+    rng = np.random.default_rng(0)
+    for overlap in (False, True):
+        for nfield, elem, kind in ((4, 8, 0), (3, 8, 0), (1, 1, 1)):
+            if elem == 8:
+                a = torch.tensor(rng.normal(size=nl * plane * nfield), dtype=torch.float64, device="cuda")
+            else:
+                a = torch.tensor(rng.integers(0, 2, size=nl * plane), dtype=torch.uint8, device="cuda")
+            ref = a.clone()
+            torch.cuda.synchronize()
+            S.rccl_selftest_exchange(a.data_ptr(), nfield, elem, kind, overlap)
+            S.synchronize()
+            torch.cuda.synchronize()
+            m = 3 * plane * nfield
+            lo_old, hi_old = ref[:m].clone(), ref[-m:].clone()
+            if kind == 0:
+                ref[:m] += hi_old
+                ref[-m:] += lo_old
+            else:
+                ref[:m] = torch.maximum(lo_old, hi_old)
+                ref[-m:] = torch.maximum(lo_old, hi_old)
+            assert torch.equal(a, ref), (overlap, nfield, elem, kind)
+    # explicit steps with the communicator attached (no neighbours: nothing to exchange) equal a plain run
+    S.initialise_shapefun()
+    S2 = gpu_setup(case, nsteps=4)
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, 4)])
+    for t in range(3):
+        S.explicit_step(gb, t, 1e-3)
+        S2.explicit_step(gb, t, 1e-3)
+    a, b = S.download_state(), S2.download_state()
+    assert np.array_equal(a["I0"], b["I0"])
+    for k in ("x", "vel", "Stress", "F_n"):
+        assert_close(a[k], b[k], 1e-12, f"{k}: RCCL attached vs plain")
+    # reduce of a masked vector (implicit driver): world 1 = identity
+    v = torch.arange(10, dtype=torch.float64, device="cuda")
+    S.rccl_reduce(v.data_ptr(), 10, root=0)
+    S.rccl_reduce(v.data_ptr(), 10, root=-1)
+    S.synchronize()
+    assert torch.equal(v.cpu(), torch.arange(10, dtype=torch.float64))
+    S.rccl_detach()
+    S.rccl_detach()  # idempotent
+    assert S.status_flags() == 0
+
+
+def test_rccl_all_reduce_mode_world_1():
+    n = nlps()
+    case = make_case(3, [11, 10, 9], [3, 3, 2], [5, 4, 4], velocity=[0.0, 0.0, -10.0])
+    S = gpu_setup(case, init=False, nsteps=2)
+    S.rccl_attach(n.Solver.rccl_unique_id(), 0, 1, [0], [case["grid_n"][2] - 1], mode=1)
+    S.initialise_shapefun()
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, 2)])
+    S.explicit_step(gb, 0, 1e-3)
+    nod = S.explicit_nodal()
+    assert abs(nod["mass"].reshape(-1, 3)[:, 0].sum() / case["cloud"]["mass"].sum() - 1) < 1e-12
+    S.close()
