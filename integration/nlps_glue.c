@@ -4,9 +4,14 @@
  * reference (it includes the reference's own headers; nothing of them is copied here).  It marshals the
  * reference's Particle / Mesh / Material / Boundaries structures (Types.h:14-797) into the plain-pointer
  * structures of the C-ABI, so that U-Newmark-beta.c / U-Static.c can replace their static stage functions by
- * the nlps_gpu_* calls listed in INTEGRATION.md.  It cannot be linked here (the reference needs PETSc and LAPACK);
- * tests/test_abi.py::test_glue_compiles_against_the_reference_headers type-checks it against Types.h in both
- * dimensions whenever the reference tree is present.
+ * the nlps_gpu_* calls listed in INTEGRATION.md.  It cannot be linked into the reference here (the reference needs
+ * PETSc and LAPACK); tests/test_abi.py::test_glue_compiles_against_the_reference_headers compiles it to an object
+ * against the real Types.h in both dimensions whenever the reference tree is present and checks the nlps_gpu_* symbols
+ * it leaves undefined against the library's exports.
+ *
+ * Node numbering: the library indexes every nodal array in LATTICE numbering (x fastest).  A GiD box mesh may number
+ * its nodes differently, so the glue keeps canon[file node] = lattice node (nlps_host_lattice_from_nodes) and maps
+ * I0, the Dirichlet node lists, h_avg and Nodes2Mask through it, both ways.
  *
  *   cc -std=gnu99 [-DUSE_PLAINSTRAIN] -I<nl-partsol>/src -I<this repo>/include -c nlps_glue.c
  */
@@ -31,33 +36,53 @@ static int nlps_glue_law(const Material *M) {
   return -1;
 }
 
-/* The GramsBox lattice behind FEM_Mesh.Coordinates: nodes per axis and origin (x fastest numbering is checked
- * by nlps_gpu_create against h_avg / the stencil tables). */
-static int nlps_glue_lattice(const Mesh *FEM_Mesh, nlps_grid *g) {
+/* what the binding keeps between calls */
+typedef struct {
+  nlps_gpu *gpu;
+  int N;          /* FEM_Mesh.NumNodesMesh */
+  int identity;   /* the mesh file already numbers its nodes x fastest */
+  int *canon;     /* [N] file node -> lattice node */
+  int *file_of;   /* [N] lattice node -> file node */
+  int *I0_l;      /* [NumGP] closest nodes in lattice numbering (upload / download staging) */
+  double *h_avg_l; /* [N] FEM_Mesh.h_avg in lattice numbering */
+} nlps_glue;
+
+void nlps_glue_free(nlps_glue *G) {
+  if (G == NULL) return;
+  if (G->gpu) nlps_gpu_destroy(G->gpu);
+  free(G->canon);
+  free(G->file_of);
+  free(G->I0_l);
+  free(G->h_avg_l);
+  memset(G, 0, sizeof *G);
+}
+
+/* The GramsBox lattice behind FEM_Mesh.Coordinates: spacing, nodes per axis, origin and the node map.  Fails loudly
+ * when the background mesh is not a structured lattice (such meshes stay on the CPU path). */
+static int nlps_glue_lattice(nlps_glue *G, const Mesh *FEM_Mesh, nlps_grid *g) {
   const int Ndim = NumberDimensions;
   const int N = FEM_Mesh->NumNodesMesh;
-  const double h = FEM_Mesh->DeltaX;
-  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  for (int i = 0; i < Ndim; i++) lo[i] = hi[i] = FEM_Mesh->Coordinates.nM[0][i];
-  for (int A = 1; A < N; A++)
-    for (int i = 0; i < Ndim; i++) {
-      const double x = FEM_Mesh->Coordinates.nM[A][i];
-      if (x < lo[i]) lo[i] = x;
-      if (x > hi[i]) hi[i] = x;
-    }
-  long total = 1;
+  G->N = N;
+  G->canon = (int *)malloc((size_t)N * sizeof(int));
+  G->file_of = (int *)malloc((size_t)N * sizeof(int));
+  G->h_avg_l = (double *)malloc((size_t)N * sizeof(double));
+  if (G->canon == NULL || G->file_of == NULL || G->h_avg_l == NULL) return EXIT_FAILURE;
+  memset(g, 0, sizeof *g);
   g->ndim = Ndim;
-  g->h = h;
-  g->h_avg = FEM_Mesh->h_avg;
-  for (int i = 0; i < 3; i++) {
-    g->n[i] = i < Ndim ? (int)floor((hi[i] - lo[i]) / h + 0.5) + 1 : 1;
-    g->origin[i] = i < Ndim ? lo[i] : 0.0;
-    total *= g->n[i];
-  }
-  if (total != N) {
-    fprintf(stderr, "" RED "nlps_glue: the background mesh is not a structured lattice of spacing DeltaX" RESET "\n");
+  /* Coordinates.nV is the contiguous [N][Ndim] storage of the Matrix (MatrixOp.c:128-181) */
+  if (nlps_host_lattice_from_nodes(Ndim, N, FEM_Mesh->Coordinates.nV, &g->h, g->n, g->origin, G->canon) != 0) {
+    fprintf(stderr, "" RED "nlps_glue: the background mesh is not a structured lattice: %s" RESET "\n",
+            nlps_host_io_last_error());
     return EXIT_FAILURE;
   }
+  G->identity = 1;
+  for (int A = 0; A < N; A++) {
+    if (G->canon[A] < 0 || G->canon[A] >= N) return EXIT_FAILURE;
+    G->file_of[G->canon[A]] = A;
+    G->identity &= (G->canon[A] == A);
+    G->h_avg_l[G->canon[A]] = FEM_Mesh->h_avg[A];
+  }
+  g->h_avg = G->h_avg_l;
   return EXIT_SUCCESS;
 }
 
@@ -100,9 +125,10 @@ static nlps_particles nlps_glue_particles(Particle MPM_Mesh) {
 }
 
 /* after initialise_shapefun__MeshTools__ (driver-nl-partsol.c:344): upload everything once */
-int nlps_glue_create(nlps_gpu **GPU, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Params Parameters_Solver) {
+int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Params Parameters_Solver) {
   nlps_grid g;
-  if (nlps_glue_lattice(&FEM_Mesh, &g) == EXIT_FAILURE) return EXIT_FAILURE;
+  memset(G, 0, sizeof *G);
+  if (nlps_glue_lattice(G, &FEM_Mesh, &g) == EXIT_FAILURE) return EXIT_FAILURE;
   /* snapshot of the globals the level-A functions read implicitly (Globals.h:33-58) */
   nlps_params prm = {gamma_LME, TOL_zero_LME, TOL_wrapper_LME, max_iter_LME, TOL_Radial_Returning,
                      Max_Iterations_Radial_Returning};
@@ -133,15 +159,24 @@ int nlps_glue_create(nlps_gpu **GPU, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_
     mats[m].delta_voce = M->delta_Hardening_Voce;
   }
   nlps_particles p = nlps_glue_particles(MPM_Mesh);
-  const int STATUS = nlps_gpu_create(GPU, &g, &prm, mats, Nmat, &p, Parameters_Solver.NumTimeStep, NULL);
+  /* closest nodes in lattice numbering */
+  G->I0_l = (int *)malloc((size_t)(p.np > 0 ? p.np : 1) * sizeof(int));
+  if (G->I0_l == NULL) {
+    free(mats);
+    return EXIT_FAILURE;
+  }
+  for (int q = 0; q < p.np; q++) G->I0_l[q] = G->canon[MPM_Mesh.I0[q]];
+  p.I0 = G->I0_l;
+  const int STATUS = nlps_gpu_create(&G->gpu, &g, &prm, mats, Nmat, &p, Parameters_Solver.NumTimeStep, NULL);
   free(mats);
-  if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", *GPU ? nlps_gpu_last_error(*GPU) : "nlps_gpu_create");
+  if (STATUS != EXIT_SUCCESS)
+    fprintf(stderr, "" RED "%s" RESET "\n", G->gpu ? nlps_gpu_last_error(G->gpu) : "nlps_gpu_create");
   return STATUS;
 }
 
-/* FEM_Mesh.Bounds (Types.h:296-351) flattened to the value[k*NumTimeStep + t] layout of nlps_bcc.
- * The caller frees bcc[i].value and bcc. */
-nlps_bcc *nlps_glue_boundaries(Mesh FEM_Mesh, int NumTimeStep, int *nbcc) {
+/* FEM_Mesh.Bounds (Types.h:296-351) flattened to the value[k*NumTimeStep + t] layout of nlps_bcc, node lists in
+ * lattice numbering.  The caller frees bcc[i].nodes, bcc[i].value and bcc. */
+nlps_bcc *nlps_glue_boundaries(const nlps_glue *G, Mesh FEM_Mesh, int NumTimeStep, int *nbcc) {
   const int NumBounds = FEM_Mesh.Bounds.NumBounds;
   nlps_bcc *bcc = (nlps_bcc *)calloc((size_t)(NumBounds > 0 ? NumBounds : 1), sizeof(nlps_bcc));
   if (bcc == NULL) return NULL;
@@ -151,8 +186,11 @@ nlps_bcc *nlps_glue_boundaries(Mesh FEM_Mesh, int NumTimeStep, int *nbcc) {
     if (value == NULL) return NULL;
     for (int k = 0; k < L->Dim; k++)
       for (int t = 0; t < NumTimeStep && t < L->Value[k].Num; t++) value[(size_t)k * NumTimeStep + t] = L->Value[k].Fx[t];
+    int *nodes = (int *)malloc((size_t)(L->NumNodes > 0 ? L->NumNodes : 1) * sizeof(int));
+    if (nodes == NULL) return NULL;
+    for (int q = 0; q < L->NumNodes; q++) nodes[q] = G->canon[L->Nodes[q]];
     bcc[i].nnodes = L->NumNodes;
-    bcc[i].nodes = L->Nodes;
+    bcc[i].nodes = nodes;
     bcc[i].dim = L->Dim;
     bcc[i].dir = L->Dir; /* Dir[k*NumTimeStep + t], Nodes-Tools.c:130 */
     bcc[i].value = value;
@@ -163,9 +201,10 @@ nlps_bcc *nlps_glue_boundaries(Mesh FEM_Mesh, int NumTimeStep, int *nbcc) {
 
 /* get_active_nodes__MeshTools__ + get_active_dofs__MeshTools__ (U-Newmark-beta.c:205-209): the Mask structures
  * the host still needs for the PETSc sizes.  Nodes2Mask arrays are malloc'd like the reference's (caller frees). */
-int nlps_glue_masks(nlps_gpu *GPU, Mesh FEM_Mesh, const nlps_bcc *bcc, int nbcc, int TimeStep, Mask *ActiveNodes,
+int nlps_glue_masks(const nlps_glue *G, Mesh FEM_Mesh, const nlps_bcc *bcc, int nbcc, int TimeStep, Mask *ActiveNodes,
                     Mask *ActiveDOFs) {
   const int Ndim = NumberDimensions;
+  nlps_gpu *GPU = G->gpu;
   int Nactivenodes = 0, Nfree = 0;
   ActiveNodes->Nodes2Mask = (int *)malloc((size_t)FEM_Mesh.NumNodesMesh * sizeof(int));
   ActiveDOFs->Nodes2Mask = (int *)malloc((size_t)FEM_Mesh.NumNodesMesh * Ndim * sizeof(int));
@@ -175,15 +214,35 @@ int nlps_glue_masks(nlps_gpu *GPU, Mesh FEM_Mesh, const nlps_bcc *bcc, int nbcc,
     fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(GPU));
     return EXIT_FAILURE;
   }
+  if (!G->identity) { /* the library's Nodes2Mask is indexed by lattice node: back to the mesh file's numbering.  The
+                         masked indices themselves (and with them every masked Vec) keep the library's order. */
+    int *tmp = (int *)malloc((size_t)G->N * sizeof(int));
+    if (tmp == NULL) return EXIT_FAILURE;
+    memcpy(tmp, ActiveNodes->Nodes2Mask, (size_t)G->N * sizeof(int));
+    for (int A = 0; A < G->N; A++) ActiveNodes->Nodes2Mask[A] = tmp[G->canon[A]];
+    free(tmp);
+  }
   ActiveNodes->Nactivenodes = Nactivenodes;
   ActiveDOFs->Nactivenodes = Nfree;
   return EXIT_SUCCESS;
 }
 
 /* before particle_results_vtk__InOutFun__ (U-Newmark-beta.c:409) or any host-side use of MPM_Mesh.Phi */
-int nlps_glue_download(nlps_gpu *GPU, Particle MPM_Mesh) {
+int nlps_glue_download(const nlps_glue *G, Particle MPM_Mesh) {
   nlps_particles p = nlps_glue_particles(MPM_Mesh);
-  const int STATUS = nlps_gpu_download_state(GPU, &p);
-  if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(GPU));
+  p.I0 = G->I0_l;
+  const int STATUS = nlps_gpu_download_state(G->gpu, &p);
+  if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(G->gpu));
+  for (int q = 0; q < p.np && STATUS == EXIT_SUCCESS; q++) MPM_Mesh.I0[q] = G->file_of[G->I0_l[q]];
   return STATUS;
+}
+
+/* U-Static.c:1380-1470, __update_Particles(dU, MPM_Mesh, FEM_Mesh, ActiveNodes): the roll of the internal variables
+ * and x_GC, dis += sum_A N_pA dU_A; the quasi-static driver has no velocities to update (NULL rate vectors). */
+int nlps_glue_update_particles_static(const nlps_glue *G, const double *dU /* VecGetArrayRead(dU) */) {
+  if (nlps_gpu_roll_state(G->gpu) != EXIT_SUCCESS || nlps_gpu_update_kinetics(G->gpu, 1.0, dU, NULL, NULL, NULL) != EXIT_SUCCESS) {
+    fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(G->gpu));
+    return EXIT_FAILURE;
+  }
+  return EXIT_SUCCESS;
 }

@@ -60,10 +60,12 @@ def test_no_gpu_means_failure_not_fallback():
         n.Solver(2, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"])
 
 
-def test_glue_compiles_against_the_reference_headers():
+def test_glue_compiles_against_the_reference_headers(tmp_path):
     """integration/nlps_glue.c is the binding a maintainer adds to the reference.  It includes the
     reference's own Types.h / Globals.h, so wherever the reference tree is present (this container; not the GPU
-    box) it is type-checked against the real Particle / Mesh / Material / Boundaries declarations, in 2-D and 3-D."""
+    box) it is COMPILED TO AN OBJECT against the real Particle / Mesh / Material / Boundaries declarations, in 2-D
+    and 3-D, and every nlps_* symbol the object leaves undefined must be an export of the library (the reference
+    itself cannot be linked here: PETSc, LAPACK)."""
     import shutil
     import subprocess
     import pytest
@@ -71,9 +73,39 @@ def test_glue_compiles_against_the_reference_headers():
     if not os.path.isdir(ref) or shutil.which("gcc") is None:
         pytest.skip("reference tree or gcc not available here")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for dim in (["-DUSE_PLAINSTRAIN"], []):
-        cmd = ["gcc", "-std=gnu99", "-fsyntax-only", "-Werror=implicit-function-declaration",
+    n = nlps()
+    for k, dim in enumerate((["-DUSE_PLAINSTRAIN"], [])):
+        obj = str(tmp_path / ("nlps_glue_%d.o" % k))
+        cmd = ["gcc", "-std=gnu99", "-c", "-Werror=implicit-function-declaration",
                "-Werror=incompatible-pointer-types", "-Werror=int-conversion"] + dim + \
-              ["-I" + ref, "-I" + os.path.join(root, "include"), os.path.join(root, "integration", "nlps_glue.c")]
+              ["-I" + ref, "-I" + os.path.join(root, "include"), os.path.join(root, "integration", "nlps_glue.c"), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
+        syms = subprocess.run(["nm", "-u", obj], capture_output=True, text=True).stdout.split()
+        used = sorted(x for x in syms if x.startswith("nlps_"))
+        assert "nlps_gpu_create" in used and "nlps_host_lattice_from_nodes" in used and "nlps_gpu_update_kinetics" in used
+        for name in used:
+            assert name in n.SYMBOLS, name + " is used by the glue but not exported by the library"
+        defined = subprocess.run(["nm", "--defined-only", obj], capture_output=True, text=True).stdout
+        for name in ("nlps_glue_create", "nlps_glue_boundaries", "nlps_glue_masks", "nlps_glue_download",
+                     "nlps_glue_update_particles_static", "nlps_glue_free"):
+            assert name in defined
+
+
+def test_c_caller_links_against_the_library(tmp_path):
+    """tests/c/abi_step.c (plain C99, no Python in the way) compiles and LINKS against libnlps_gpu.so; the GPU test
+    test_gpu_c_caller.py runs it."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "nl-partsol_amd", "csrc")
+    nlps().lib()
+    exe = str(tmp_path / "abi_step")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "tests", "c", "abi_step.c"), "-o", exe, "-L" + libdir, "-lnlps_gpu",
+                        "-Wl,-rpath," + libdir, "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert os.path.exists(os.path.join(root, "tests", "golden", "nh3d_abi.bin"))
