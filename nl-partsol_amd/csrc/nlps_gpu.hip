@@ -2015,6 +2015,8 @@ static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 bound
   td.tile0 = h->tile0;
   td.ntw = h->ntw;
   td.slab = h->deterministic ? h->slab_d : nullptr;
+  td.slab_n = 1;
+  td.slab_slot = 0;
   td.work[0] = h->work1_d;
   td.work[1] = h->work2_d;
   td.range = h->nwork_d + 4 * cls;
@@ -2044,6 +2046,12 @@ static NodeRanges node_ranges(nlps_gpu* h, int part) {
 
 static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm) {
   TileD td = tile_view(h, cls);
+  if (h->deterministic && p2g) {  // one wave per tile, sorted list, slab flush (nlps_gpu_set_deterministic)
+    const dim3 grid1(h->ntw), blk1(64);
+    if (h->nd == 2) hipLaunchKernelGGL((k2_tile<2, true, 64, 1>), grid1, blk1, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    else hipLaunchKernelGGL((k2_tile<3, true, 64, 1>), grid1, blk1, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
+    return;
+  }
   const dim3 grid(h->ntw * K2_SPLIT), blk(BLK);
   if (h->nd == 2) {
     if (p2g) hipLaunchKernelGGL((k2_tile<2, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
@@ -2073,10 +2081,14 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
                      h->band_hi, h->work1_d, h->work2_d, h->nwork_d);
   hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                      h->order_d);
-  if (h->tile_ordering) {
+  if (h->deterministic) {
     TileD td = tile_view(h, 0);
-    if (h->nd == 2) hipLaunchKernelGGL(k_tile_order<2>, dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
-    else hipLaunchKernelGGL(k_tile_order<3>, dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
+    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
+    else hipLaunchKernelGGL((k_tile_order<3, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
+  } else if (h->tile_ordering) {
+    TileD td = tile_view(h, 0);
+    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
+    else hipLaunchKernelGGL((k_tile_order<3, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -2472,7 +2484,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   const bool det = h->deterministic;
   if (det && !h->slab_d) {
     const size_t NWs = ND == 3 ? TileCfg<3>::NWA : TileCfg<2>::NWA;
-    const size_t per_tile = std::max<size_t>((size_t)K2_SPLIT * (1 + ND), (size_t)K3_SPLIT * ND) * NWs;
+    const size_t per_tile = std::max<size_t>((size_t)(1 + ND), (size_t)4 * ND) * NWs;  // K2: one slab; K3: one per law
     HIPCHK(hipMalloc((void**)&h->slab_d, (size_t)h->ntiles * per_tile * sizeof(double)));
   }
   // second half of the P2G flush: per node, the window slabs of the tiles that hold it (part: node ranges as below)
@@ -2480,15 +2492,16 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     const NodeRanges r = node_ranges(h, part);
     if (!det || r.an + r.bn == 0) return;
     TileD td = tile_view(h, 0);
-    if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 3, K2_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.nm);
-    else hipLaunchKernelGGL((k_slab_gather<3, 4, K2_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.nm);
+    if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 3>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.nm);
+    else hipLaunchKernelGGL((k_slab_gather<3, 4>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.nm);
   };
   auto gather_force = [&](int part) {
     const NodeRanges r = node_ranges(h, part);
     if (!det || r.an + r.bn == 0) return;
     TileD td = tile_view(h, 0);
-    if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 2, K3_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
-    else hipLaunchKernelGGL((k_slab_gather<3, 3, K3_SPLIT>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
+    td.slab_n = __builtin_popcount(h->law_present);
+    if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 2>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
+    else hipLaunchKernelGGL((k_slab_gather<3, 3>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
   };
   auto nodal_dU = [&](int part) {
     const NodeRanges r = node_ranges(h, part);
@@ -2522,6 +2535,30 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
 #define NLPS_K3(NDv, LAWv)                                                                                      \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d, (const double*)nullptr)
+#define NLPS_K3D(NDv, LAWv)                                                                                     \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1, true, 64>), dim3(h->ntw), dim3(64), 0, h->stream, h->P, h->g, h->N, td, \
+                     h->mats_d, h->prm, h->gstatus_d, (const double*)nullptr)
+    if (det) {  // one wave per tile and per law present, particles in list order, one slab per (tile, law)
+      td.slab_n = __builtin_popcount(h->law_present);
+      td.slab_slot = -1;
+      for (int l = 0; l < 4; l++) {
+        if (!(h->law_present & (1 << l))) continue;
+        td.slab_slot++;
+        if (ND == 2) {
+          if (l == 0) NLPS_K3D(2, 0);
+          else if (l == 1) NLPS_K3D(2, 1);
+          else if (l == 2) NLPS_K3D(2, 2);
+          else NLPS_K3D(2, 3);
+        } else {
+          if (l == 0) NLPS_K3D(3, 0);
+          else if (l == 1) NLPS_K3D(3, 1);
+          else if (l == 2) NLPS_K3D(3, 2);
+          else NLPS_K3D(3, 3);
+        }
+      }
+      return;
+    }
+#undef NLPS_K3D
 #define NLPS_K3F(NDv, LAWv)                                                                                     \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1, true>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
                      h->mats_d, h->prm, h->gstatus_d, (const double*)nullptr)

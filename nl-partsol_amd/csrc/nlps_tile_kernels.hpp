@@ -67,6 +67,7 @@ struct TileD {
   // an inter-tile summation order that never changes -- measured 7 % slower per step than the atomic flush (the
   // no-return atomics hide behind the other workgroups' arithmetic, the gather is two more passes over the grid).
   double* slab;
+  int slab_n, slab_slot;  // slabs per tile (one per law launched on the tile) and the slot this launch writes
   const int* start;
   const int* count;
   const int* order;
@@ -254,7 +255,9 @@ __global__ void k_fill_order(int np, const int* __restrict__ tile, const int* __
 // 49 % (K5) of their LDS cycles lost to bank conflicts on the lists as binned (profiles/r01_sq_counters.md).
 // One workgroup per non-empty tile, counting sort in LDS: rank inside the node by an LDS atomic (the order among the
 // particles of one node is the arrival order), position = layer offset + number of earlier nodes that reach the layer.
-template <int ND>
+// EXACT (deterministic mode): rank inside the node = number of the node's particles with a smaller slot index, not
+// the arrival order of the LDS atomics: the list is then a function of the particle arrays alone.
+template <int ND, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, int* __restrict__ order) {
   constexpr int TB = TileCfg<ND>::TB, NN = (ND == 3) ? TB * TB * TB : TB * TB;
   constexpr int CAP = 4096, LMAX = 32;  // larger tiles / deeper nodes keep the order of the binning
@@ -285,6 +288,15 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
     pp[s] = p;
   }
   __syncthreads();
+  if (EXACT) {
+    for (int s = threadIdx.x; s < n; s += 256) {
+      const int node = keys[s] & 0xFFFF, p = pp[s];
+      int r = 0;
+      for (int q = 0; q < n; q++) r += ((keys[q] & 0xFFFF) == node && pp[q] < p) ? 1 : 0;  // LDS broadcast reads
+      keys[s] = node | (r << 16);  // only this thread's own entries change: the node bits the others read stay
+    }
+    __syncthreads();
+  }
   for (int q = threadIdx.x; q < NN; q += 256) atomicMax(&maxc, cnt[q]);
   __syncthreads();
   const int nl = maxc;
@@ -347,27 +359,29 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 // ------------------------------------------------------------------------------------------------
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
-template <int ND, bool P2G>
-__global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
+// NT / SPLIT: threads per workgroup and workgroups per tile.  The default is (BLK, K2_SPLIT); deterministic mode runs one
+// wave per tile (64, 1): the sorted tile list is then accumulated in list order by a single instruction stream.
+template <int ND, bool P2G, int NT = BLK, int SPLIT = K2_SPLIT>
+__global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES)) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
                                                double gamma_nm, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
   constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
   constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NWA];
   __shared__ unsigned actrow[NROWS];
-  const int wb = td.range[2 * (K2_SPLIT - 1)] + (int)blockIdx.x;
-  if (wb >= td.range[2 * (K2_SPLIT - 1) + 1]) return;
-  const int2 wk = td.work[K2_SPLIT - 1][wb];
+  const int wb = td.range[2 * (SPLIT - 1)] + (int)blockIdx.x;
+  if (wb >= td.range[2 * (SPLIT - 1) + 1]) return;
+  const int2 wk = td.work[SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
   const int cnt = td.count[tile];
   PH_INIT
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int r = threadIdx.x; r < NROWS; r += BLK) actrow[r] = 0u;
+  for (int r = threadIdx.x; r < NROWS; r += NT) actrow[r] = 0u;
   if (P2G)
-    for (int idx = threadIdx.x; idx < NF * NWA; idx += BLK) acc[idx] = 0.0;
+    for (int idx = threadIdx.x; idx < NF * NWA; idx += NT) acc[idx] = 0.0;
   __syncthreads();
-  for (int idx = threadIdx.x; idx < NW; idx += BLK) {
+  for (int idx = threadIdx.x; idx < NW; idx += NT) {
     bool in;
     int row, col;
     int node = window_node<ND>(g, w0, idx, in, &row, &col);
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
   __syncthreads();
   const int start = td.start[tile];
   PH(0)
-  for (int s = part * BLK + threadIdx.x; s < cnt; s += BLK * K2_SPLIT) {
+  for (int s = part * NT + threadIdx.x; s < cnt; s += NT * SPLIT) {
     const int p = td.order[start + s];
     Lme<ND> c;
     double x[ND], lam[ND];
@@ -555,11 +569,11 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
   __syncthreads();
   PH(4)
   if (td.slab) {
-    double* out = td.slab + ((size_t)tile * K2_SPLIT + part) * (NF * NWA);
-    for (int q = threadIdx.x; q < NWA * NF; q += BLK) out[q] = acc[q];
+    double* out = td.slab + ((size_t)tile * td.slab_n + td.slab_slot) * (NF * NWA);  // slab mode runs SPLIT = 1
+    for (int q = threadIdx.x; q < NWA * NF; q += NT) out[q] = acc[q];
     return;
   }
-  for (int q = threadIdx.x; q < NWA * NF; q += BLK) {
+  for (int q = threadIdx.x; q < NWA * NF; q += NT) {
     int f = q % NF, idx = q / NF;
     double v = acc[f * NWA + idx];
     if (v != 0.0) {
@@ -580,8 +594,8 @@ __global__ __launch_bounds__(BLK, ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES) vo
 // FILT (clouds with several laws): the launch handles only the tile's particles whose material follows LAW; they are
 // compacted into an LDS list first, so every lane works and the kernel is the single-law specialisation (one launch per
 // law present; the run-time dispatch over all laws in one kernel needed 436 B of scratch per lane and 0.51 ms).
-template <int ND, int LAW, int MODE, bool FILT = false>
-__global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
+__global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus,
                                                const double* __restrict__ dVgrid) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
@@ -610,19 +624,46 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
     if (threadIdx.x == 0) nsel = 0;
     __syncthreads();
     if (cnt <= SELCAP) {
-      for (int s = threadIdx.x; s < cnt; s += K3_BLK) {
-        const int p = td.order[start0 + s];
-        if (mats[P.mat[p]].type == LAW) sel[atomicAdd(&nsel, 1) % SELCAP] = p;
+      // ordered compaction (the selected particles keep the order of the tile list: runs of memory-consecutive
+      // particles stay together, and the accumulation order is a function of the list alone)
+      __shared__ int wcnt[NT / 64];
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (int s0 = 0; s0 < cnt; s0 += NT) {  // uniform trip count
+        const int s = s0 + threadIdx.x;
+        int p = -1;
+        bool f = false;
+        if (s < cnt) {
+          p = td.order[start0 + s];
+          f = mats[P.mat[p]].type == LAW;
+        }
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wcnt[wave] = (int)__popcll(m);
+        __syncthreads();
+        int base = nsel, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+          if (w < wave) base += wcnt[w];
+          tot += wcnt[w];
+        }
+        if (f) sel[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = p;
+        __syncthreads();
+        if (threadIdx.x == 0) nsel += tot;
+        __syncthreads();
       }
-      __syncthreads();
       cnt = nsel;
       listed = true;
-      if (cnt == 0) return;  // uniform: no particle of this law in the tile
+      if (cnt == 0) {  // uniform: no particle of this law in the tile (its slab must still read as zeros)
+        if (MODE == 1 && td.slab) {
+          double* out = td.slab + ((size_t)tile * td.slab_n + td.slab_slot) * (ND * TileCfg<ND>::NWA);
+          for (int qq = threadIdx.x; qq < TileCfg<ND>::NWA * ND; qq += NT) out[qq] = 0.0;
+        }
+        return;
+      }
     }
   }
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int idx = threadIdx.x; idx < NW; idx += K3_BLK) {
+  for (int idx = threadIdx.x; idx < NW; idx += NT) {
     bool in;
     int node = window_node<ND>(g, w0, idx, in);
     duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
@@ -634,13 +675,13 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
       if (ND == 3) dvz[(RATES && ND == 3) ? idx : 0] = in ? dVgrid[(size_t)node * ND + (2 % ND)] : 0.0;
     }
   }
-  for (int idx = threadIdx.x; idx < ND * NWA; idx += K3_BLK) fac[idx] = 0.0;
+  for (int idx = threadIdx.x; idx < ND * NWA; idx += NT) fac[idx] = 0.0;
   __syncthreads();
   const double2* du2 = reinterpret_cast<const double2*>(duxy);
   const double2* dv2 = reinterpret_cast<const double2*>(dvxy);
   const int start = td.start[tile];
   PH(8)
-  for (int s = part * K3_BLK + threadIdx.x; s < cnt; s += K3_BLK * K3_SPLIT) {
+  for (int s = part * NT + threadIdx.x; s < cnt; s += NT * K3_SPLIT) {
     const int p = (FILT && listed) ? sel[FILT ? s : 0] : td.order[start + s];
     if (FILT && !listed && mats[P.mat[p]].type != LAW) continue;  // oversized tile: filter per lane
     Lme<ND> c;
@@ -930,11 +971,11 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
   __syncthreads();
   PH(13)
   if (td.slab) {
-    double* out = td.slab + ((size_t)tile * K3_SPLIT + part) * (ND * NWA);
-    for (int qq = threadIdx.x; qq < NWA * ND; qq += K3_BLK) out[qq] = fac[qq];
+    double* out = td.slab + ((size_t)tile * td.slab_n + td.slab_slot) * (ND * NWA);
+    for (int qq = threadIdx.x; qq < NWA * ND; qq += NT) out[qq] = fac[qq];
     return;
   }
-  for (int qq = threadIdx.x; qq < NWA * ND; qq += K3_BLK) {
+  for (int qq = threadIdx.x; qq < NWA * ND; qq += NT) {
     int f = qq % ND, idx = qq / ND;
     double v = fac[f * NWA + idx];
     if (v != 0.0) {
@@ -947,8 +988,8 @@ __global__ __launch_bounds__(K3_BLK, ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)
 
 // Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)
 // in a fixed order and writes out[node][NF]: the second half of the P2G flush (see TileD::slab).  A tile's slab is
-// valid iff the tile was launched this step (inside [tile0, tile0 + ntw) and count > 0; part p exists iff count > p BLK).
-template <int ND, int NF, int SPLIT>
+// valid iff the tile was launched this step (inside [tile0, tile0 + ntw) and count > 0); it then holds td.slab_n slabs.
+template <int ND, int NF>
 __global__ void k_slab_gather(int a0, int an, int b0, int bn, GridD g, TileD td, double* __restrict__ out) {
   constexpr int TB = TileCfg<ND>::TB, W = TileCfg<ND>::WA, PS = TileCfg<ND>::PSA, NW = TileCfg<ND>::NWA;
   int A = blockIdx.x * blockDim.x + threadIdx.x;
@@ -972,10 +1013,8 @@ __global__ void k_slab_gather(int a0, int an, int b0, int bn, GridD g, TileD td,
         const int cnt = td.count[t];
         if (cnt <= 0) continue;
         const int idx = (ijk[0] - (tx * TB - 2)) + W * (ijk[1] - (ty * TB - 2)) + (ND == 3 ? PS * (ijk[2] - (tz * TB - 2)) : 0);
-#pragma unroll
-        for (int part = 0; part < SPLIT; part++) {
-          if (part > 0 && cnt <= part * BLK) break;
-          const double* src = td.slab + ((size_t)t * SPLIT + part) * (NF * NW) + idx;
+        for (int q = 0; q < td.slab_n; q++) {
+          const double* src = td.slab + ((size_t)t * td.slab_n + q) * (NF * NW) + idx;
 #pragma unroll
           for (int f = 0; f < NF; f++) s[f] += src[f * NW];
         }
