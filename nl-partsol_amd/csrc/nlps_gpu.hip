@@ -1379,7 +1379,9 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
 }
 
 // Physical re-sort of every particle array by (tile of I0, corner type, I0 in tile).
-static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr) {
+// live_only: called at the head of an explicit step -- the fields that step rewrites in full before anything reads them
+// (d_dis, the n+1 slots of F and b_e, DF, tau, J_n+1, W, kappa_n+1, eps_n+1: 43 of the 89 components) are not moved.
+static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live_only = false) {
   const int np = h->P.np;
   if (np == 0) return 0;
   TileCnt tc;
@@ -1400,8 +1402,23 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr) {
     HIPCHK(hipMalloc((void**)&h->Pd_alt, (size_t)NFD * npad * sizeof(double)));
     HIPCHK(hipMemsetAsync(h->Pd_alt, 0, (size_t)NFD * npad * sizeof(double), h->stream));
   }
-  hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (nf + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
-                     h->Pd_alt, (const double*)h->P.d, idx, np, npad, nf);
+  if (live_only && !h->level_b_fields) {
+    // contiguous runs of live components (enum at the top of this file; F and b_e by their current n slots)
+    const int fn = fFN(h->P), ben = fBEN(h->P);
+    const int runs[][2] = {{F_X, 12}, {fn, 9}, {ben, 9}, {F_JN, 1}, {F_RHO, 3}, {F_KN, 1}, {F_EN, 1}, {F_LAM, 10}};
+    for (auto& r : runs)
+      hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (r[1] + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
+                         h->Pd_alt + (size_t)r[0] * npad, (const double*)h->P.d + (size_t)r[0] * npad, idx, np, npad, r[1]);
+    if (h->nd == 2) {  // the zz slots of F_n+1 and DF are never written by the 2-D kernels (they stay 1 from the upload)
+      const int zz[2] = {fFN1(h->P) + 4, F_DF + 4};
+      for (int f : zz)
+        hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), 1), dim3(BLK), 0, h->stream, h->Pd_alt + (size_t)f * npad,
+                           (const double*)h->P.d + (size_t)f * npad, idx, np, npad, 1);
+    }
+  } else {
+    hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (nf + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
+                       h->Pd_alt, (const double*)h->P.d, idx, np, npad, nf);
+  }
   std::swap(h->P.d, h->Pd_alt);
   int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
   for (int* a : iarr) {
@@ -1554,6 +1571,7 @@ extern "C" int nlps_gpu_set_deterministic(nlps_gpu* h, int on) {
 }
 extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
   h->resort_every = every_n_steps;
+  h->steps_since_sort = 0;  // the interval counts from this call
   return 0;
 }
 
@@ -2469,7 +2487,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   if (nbcc > 0 && check_step(h, step, "nlps_gpu_explicit_step")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
   if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
-    if (resort(h)) return 1;
+    if (resort(h, nullptr, true)) return 1;
   }
   h->steps_since_sort++;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));

@@ -37,7 +37,7 @@ struct TileCfg<2> {
 // units shorten the partially filled last round of workgroups (tail) without changing the data flow.
 // Measured at 1 M particles: pays for K2 (0.42 -> 0.39 ms), costs for K3 (double window load + flush).
 #ifndef NLPS_K2_SPLIT
-#define NLPS_K2_SPLIT 2
+#define NLPS_K2_SPLIT 1  // r02: 1 and 2 are equal at 1 M particles (0.242 / 0.243 ms), 1 is 2 % faster at 8 M and halves the flush
 #endif
 // workgroup sizes of the tile kernels (K2 keeps BLK: its work list splits tiles at BLK particles).  Measured at 1 M
 // particles: K3 with 64 / 128 / 256 / 512 threads 0.402 / 0.327 / 0.312 / 0.338 ms, K5 with 128 / 256 / 512 0.097 / 0.100 / 0.111 ms.

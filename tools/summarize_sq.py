@@ -9,12 +9,14 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ["k_search", "k2_tile", "k3_tile", "k5_tile"]
+PREFIX = {"k_search": "void k_search<3", "k2_tile": "void k2_tile<3, true", "k3_tile": "void k3_tile<3, 0, 1",
+          "k5_tile": "void k5_tile<3"}  # the 3-D instantiations of the explicit step (Neo-Hookean bench cloud)
 WAVES = 1000000 / 64.0  # particle-waves of the bench workload
 val, dur = {}, {}
 for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         for k in KERNELS:
-            if r["Kernel_Name"].startswith("void %s<3" % k) and "false" not in r["Kernel_Name"]:
+            if r["Kernel_Name"].startswith(PREFIX[k]):
                 # the last launch of every kernel wins (rows are in dispatch order)
                 val[(k, r["Counter_Name"])] = float(r["Counter_Value"])
                 dur[(k, r["Counter_Name"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
