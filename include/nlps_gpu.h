@@ -65,6 +65,7 @@ typedef struct {
   int max_iter_lme;        /* max_iter_LME     (10)    */
   double tol_radial_returning;   /* TOL_Radial_Returning            */
   int max_iter_radial_returning; /* Max_Iterations_Radial_Returning */
+  int driver_eigenerosion;       /* Driver_EigenErosion (Globals.h): the damage hooks of the level-B stages (0 = off) */
 } nlps_params;
 
 /* Material, Types.h:359-458 (members read by the three laws) */
@@ -75,6 +76,7 @@ typedef struct {
   double kappa_0, exponent_ortiz, eps_0 /* Plastic_Strain_0 */, p_ref /* ReferencePressure */;
   /* Von-Mises (Von-Mises.c:246-253): sigma_y = kappa_0, Hardening_modulus, theta / K_0 / K_inf / delta _Hardening_Voce */
   double hardening_modulus, theta_voce, K0_voce, Kinf_voce, delta_voce;
+  double Ceps, Gf; /* eigenerosion (Constitutive/Fracture/EigenErosion.c:63-64): normalising constant, Griffith energy */
 } nlps_material;
 
 /* Particle fields, Types.h:184-283 / 548-623: HOST pointers to the reference's row-major arrays
@@ -107,6 +109,8 @@ typedef struct {
   double *dt_DF;        /* [np][T]  optional */
   double *C_ep;         /* [np][ndim*ndim] download only: elastoplastic tangent moduli (Drucker-Prager, Von-Mises) */
   double *Back_stress;  /* [np][3] optional (0): principal back stress of Von-Mises (Phi.Back_stress), in/out */
+  double *Damage_n;     /* [np] optional (0): Phi.Damage_n  (eigenerosion, driver_eigenerosion != 0) */
+  double *Damage_n1;    /* [np] optional (Damage_n): Phi.Damage_n1 */
 } nlps_particles;
 
 /* Dirichlet boundary = Load of FEM_Mesh.Bounds (Types.h:296-351), flattened:

@@ -121,6 +121,8 @@ static nlps_particles nlps_glue_particles(Particle MPM_Mesh) {
   p.dt_DF = MPM_Mesh.Phi.dt_DF.nV;
   p.C_ep = MPM_Mesh.Phi.C_ep.nV;
   p.Back_stress = MPM_Mesh.Phi.Back_stress.nV;
+  p.Damage_n = MPM_Mesh.Phi.Damage_n;
+  p.Damage_n1 = MPM_Mesh.Phi.Damage_n1;
   return p;
 }
 
@@ -131,7 +133,7 @@ int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Pa
   if (nlps_glue_lattice(G, &FEM_Mesh, &g) == EXIT_FAILURE) return EXIT_FAILURE;
   /* snapshot of the globals the level-A functions read implicitly (Globals.h:33-58) */
   nlps_params prm = {gamma_LME, TOL_zero_LME, TOL_wrapper_LME, max_iter_LME, TOL_Radial_Returning,
-                     Max_Iterations_Radial_Returning};
+                     Max_Iterations_Radial_Returning, Driver_EigenErosion ? 1 : 0};
   const int Nmat = MPM_Mesh.NumberMaterials;
   nlps_material *mats = (nlps_material *)calloc((size_t)Nmat, sizeof(nlps_material));
   if (mats == NULL) return EXIT_FAILURE;
@@ -157,6 +159,8 @@ int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Pa
     mats[m].K0_voce = M->K_0_Hardening_Voce;
     mats[m].Kinf_voce = M->K_inf_Hardening_Voce;
     mats[m].delta_voce = M->delta_Hardening_Voce;
+    mats[m].Ceps = M->Ceps;
+    mats[m].Gf = M->Gf;
   }
   nlps_particles p = nlps_glue_particles(MPM_Mesh);
   /* closest nodes in lattice numbering */

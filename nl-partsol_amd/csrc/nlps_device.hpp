@@ -38,6 +38,7 @@ struct MatD {
   double alpha_F, alpha_Q, beta_dp;  // Drucker-Prager.c:362-375
   double kappa_0, exp_param, eps_0, p_ref;
   double H, theta, K_0, K_inf, delta;  // Von-Mises.c:246-253 (sigma_y = kappa_0)
+  double Ceps, Gf;                     // eigenerosion (EigenErosion.c:63-64)
 };
 
 struct ParamsD {

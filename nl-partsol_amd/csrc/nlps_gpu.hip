@@ -53,7 +53,8 @@ enum {
   F_BACK = 86,  // principal back stress (Von-Mises), 3 components
   F_CEP = 89,   // C_ep[ndim*ndim] (Drucker-Prager / Von-Mises tangent moduli, implicit driver only)
   F_DTFN = 98, F_DTFN1 = 107, F_DTDF = 116,  // rate tensors (level-B compatibility with dU_dt)
-  NFD = 125
+  F_DMG = 125, F_DMG1 = 126,                 // Damage_n, Damage_n1 (eigenerosion, level B only)
+  NFD = 127
 };
 
 struct PView {
@@ -69,6 +70,7 @@ struct PView {
   int* tile;  // tile of I0 (per-step binning)
   int* rank;  // arrival rank inside the tile
   int flip;   // 1: the n / n+1 slots of F and b_e are swapped (the explicit step rolls them by renaming)
+  int erosion;  // Driver_EigenErosion: the damage hooks of the level-B stages are on
 };
 #define PF(P, f, p) ((P).d[(size_t)(f) * (P).npad + (size_t)(p)])
 // first component of F_n, F_n+1, b_e,n, b_e,n+1 under the current renaming
@@ -445,12 +447,88 @@ __device__ __forceinline__ bool force_operator(double* B, const double* tau, con
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Eigenerosion: the damage part of __nodal_internal_forces, U-Newmark-beta.c:1313-1331 ->
+// compute_damage__Constitutive__ (Constitutive.c:385-435) -> Eigenerosion__Constitutive__ (EigenErosion.c:29-117).
+// The epsilon-neighbourhood Beps[p] (Beps.c:16-80: particles q whose closest node lies in the 1-ring of I0_p, within
+// Ceps * DeltaX of p) is not stored: the particles are sorted by closest node once per call (first/last = the run of
+// every node in `sorted`) and every particle walks the <= 3^d runs around its own closest node.  x_GC does not change
+// between the search and the force stage, so this is the list the reference built after its search -- except for
+// particles that have not moved by more than 1e-6 since the start, whose list the reference freezes (Beps.c:30-36).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_node_ranges(int np, const unsigned long long* __restrict__ keys, int* __restrict__ first,
+                              int* __restrict__ last) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  const unsigned long long k = keys[i];
+  if (i == 0 || keys[i - 1] != k) first[k] = i;
+  if (i == np - 1 || keys[i + 1] != k) last[k] = i + 1;
+}
+
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_damage(PView P, GridD g, const MatD* __restrict__ mats, const int* __restrict__ first,
+                                                const int* __restrict__ last, const int* __restrict__ sorted,
+                                                double DeltaX) {
+  const int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  constexpr int T = (ND == 2) ? 5 : 9;
+  const double Dn = PF(P, F_DMG, p);
+  double Dn1 = PF(P, F_DMG1, p);
+  double tau[ND * ND], z, w[3] = {0.0, 0.0, 0.0}, v[ND * ND];
+  load_block<ND>(P, F_TAU, p, tau, z);
+  sym_eigen<ND>(w, v, tau);  // ascending like dsyev: w[0] is the smallest principal Kirchhoff stress
+  if (Dn < 1.0 && w[0] > 0.0) {
+    const MatD m = mats[P.mat[p]];
+    const double eps = m.Ceps * DeltaX;
+    double xp[ND];
+#pragma unroll
+    for (int a = 0; a < ND; a++) xp[a] = PF(P, F_X + a, p);
+    const double V_p = PF(P, F_VOL0, p) * PF(P, F_JN1, p);
+    double sum_V = V_p, sum_VW = V_p * PF(P, F_W, p);
+    const int I0 = P.I0[p];
+    const int i0 = I0 % g.n[0], j0 = (I0 / g.n[0]) % g.n[1], k0 = I0 / (g.n[0] * g.n[1]);
+    for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
+      for (int dj = -1; dj <= 1; dj++)
+        for (int di = -1; di <= 1; di++) {
+          const int i = i0 + di, j = j0 + dj, k = k0 + dk;
+          if (i < 0 || i >= g.n[0] || j < 0 || j >= g.n[1] || (ND == 3 && (k < 0 || k >= g.n[2]))) continue;
+          const int A = i + g.n[0] * (j + g.n[1] * k);
+          for (int s = first[A]; s < last[A]; s++) {
+            const int q = sorted[s];
+            double d2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < ND; a++) {
+              const double d = xp[a] - PF(P, F_X + a, q);
+              d2 += d * d;
+            }
+            if (sqrt(d2) <= eps) {  // q = p included, like the reference's list
+              const double V_q = PF(P, F_VOL0, q) * PF(P, F_JN1, q);
+              sum_V += V_q;
+              if (PF(P, F_DMG, q) < 1.0) sum_VW += V_q * PF(P, F_W, q);
+            }
+          }
+        }
+    const double G_p = (m.Ceps * DeltaX / sum_V) * sum_VW;
+    if (G_p > m.Gf) {
+      Dn1 = 1.0;
+      PF(P, F_DMG1, p) = 1.0;
+    }
+  }
+  const double sc = 1.0 - Dn1;  // kirchhoff_p[i] *= (1 - Damage_n1[p]), in place (:1321-1330)
+#pragma unroll
+  for (int s = 0; s < T; s++) PF(P, F_TAU + s, p) = PF(P, F_TAU + s, p) * sc;
+}
+
 // __constitutive_update (U-Newmark-beta.c:1208-1242)
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict__ mats, ParamsD prm,
                                                 int* __restrict__ gstatus) {
   int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
+  if (P.erosion && PF(P, F_DMG, p) == 1.0) {  // failed particle: U-Newmark-beta.c:1218-1224
+    PF(P, F_W, p) = 0.0;
+    return;
+  }
   double Fn1[ND * ND], DF[ND * ND], tau[ND * ND], z;
   load_block<ND>(P, fFN1(P), p, Fn1, z);
   load_block<ND>(P, F_DF, p, DF, z);
@@ -486,6 +564,7 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
   PF(P, F_RHO, p) = PF(P, F_MASS, p) / (PF(P, F_VOL0, p) * J);
   PF(P, F_KN, p) = PF(P, F_KN1, p);
   PF(P, F_EN, p) = PF(P, F_EN1, p);
+  if (P.erosion) PF(P, F_DMG, p) = PF(P, F_DMG1, p);  // U-Newmark-beta.c:1950-1953
   constexpr int T = (ND == 2) ? 5 : 9;
 #pragma unroll
   for (int s = 0; s < T; s++) {
@@ -847,6 +926,7 @@ struct nlps_gpu {
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists (k_tile_scan)
+  int *dmg_first_d = nullptr, *dmg_last_d = nullptr;  // eigenerosion: run of every node in the I0-sorted particle list
   double* slab_d = nullptr; // P2G window slabs [ntiles][K2_SPLIT][1+ND][NW] (TileD::slab), deterministic mode only
   bool deterministic = false;
   // canonical (layer, closest node) order of every tile list each step (k_tile_order).  OFF: measured at 1 M particles it
@@ -934,6 +1014,8 @@ static MatD make_mat(const nlps_material& m, int nd) {
   d.K_0 = m.K0_voce;
   d.K_inf = m.Kinf_voce;
   d.delta = m.delta_voce;
+  d.Ceps = m.Ceps;
+  d.Gf = m.Gf;
   return d;
 }
 
@@ -1177,6 +1259,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->prm.max_iter_lme = prm->max_iter_lme;
   h->prm.tol_radial = prm->tol_radial_returning;
   h->prm.max_iter_radial = prm->max_iter_radial_returning;
+  h->P.erosion = prm->driver_eigenerosion != 0;
 
   h->tab = nlps_host::build_tables(g.nd);
   HIPCHK(hipMalloc((void**)&h->rank1_d, 27 * 27));
@@ -1343,6 +1426,9 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     if (upload_field(h, F_BETA, 1, host->Beta, 1, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_LAMP, ND, host->lambda, ND, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_BACK, 3, host->Back_stress, 3, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_DMG, 1, host->Damage_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_DMG1, 1, host->Damage_n1 ? host->Damage_n1 : host->Damage_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (h->P.erosion) h->level_b_fields = true;  // the damage fields travel with the re-sort
     if (host->dt_F_n || host->dt_F_n1 || host->dt_DF) h->level_b_fields = true;
     if (host->dt_F_n && upload_field(h, F_DTFN, T, host->dt_F_n, T, tmp, nullptr, 0.0)) return 1;
     if (host->dt_F_n1 && upload_field(h, F_DTFN1, T, host->dt_F_n1, T, tmp, nullptr, 0.0)) return 1;
@@ -1582,7 +1668,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1640,6 +1726,8 @@ extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
   if (download_field(h, F_DTDF, T, o->dt_DF, T, tmp)) return 1;
   if (download_field(h, F_CEP, ND * ND, o->C_ep, ND * ND, tmp)) return 1;
   if (download_field(h, F_BACK, 3, o->Back_stress, 3, tmp)) return 1;
+  if (download_field(h, F_DMG, 1, o->Damage_n, 1, tmp)) return 1;
+  if (download_field(h, F_DMG1, 1, o->Damage_n1, 1, tmp)) return 1;
   if (o->I0) {
     std::vector<int> it(np);
     HIPCHK(hipMemcpy(it.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
@@ -2342,6 +2430,23 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
   if (need_masks(h, "nlps_gpu_internal_forces")) return 1;
   if (materialise_roll(h)) return 1;
   int ND = h->nd;
+  if (h->P.erosion && h->P.np > 0) {  // damage of every particle, then its Kirchhoff stress scaled in place (:1313-1331)
+    const int np = h->P.np;
+    const size_t nn = (size_t)h->g.nnodes;
+    if (!h->dmg_first_d) {
+      HIPCHK(hipMalloc((void**)&h->dmg_first_d, nn * sizeof(int)));
+      HIPCHK(hipMalloc((void**)&h->dmg_last_d, nn * sizeof(int)));
+    }
+    HIPCHK(hipMemsetAsync(h->dmg_first_d, 0, nn * sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->dmg_last_d, 0, nn * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_tangent_keys, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->skey_d, h->sval_d);
+    size_t bytes = h->cub_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 32,
+                                              h->stream));
+    hipLaunchKernelGGL(k_node_ranges, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->skey2_d, h->dmg_first_d, h->dmg_last_d);
+    LAUNCH_ND((k_damage<2>), (k_damage<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->sval2_d, h->g.h);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
   {
     TileD td = tile_view(h);
@@ -2484,6 +2589,11 @@ __global__ void k_null_bracket(PView, GridD, NView, TileD, const MatD*, ParamsD,
 extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc, int step, double dt, double gamma_nm,
                                       const double* gravity) {
   int ND = h->nd;
+  if (h->P.erosion) {
+    h->err = "nlps_gpu_explicit_step: the eigenerosion hooks exist in the level-B stages only (the reference defines them in "
+             "U-Newmark-beta.c / U-Static.c; its explicit drivers are stubs)";
+    return 1;
+  }
   if (nbcc > 0 && check_step(h, step, "nlps_gpu_explicit_step")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
   if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {

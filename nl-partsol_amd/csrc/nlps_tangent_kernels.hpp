@@ -15,6 +15,13 @@
 // Dirichlet rows/columns reduced to the identity (MatZeroRowsColumnsIS, :1822).
 #pragma once
 
+// Vol_0 of the particle; with the damage drivers on the stiffness density is scaled by (1 - Damage_n1)
+// (U-Newmark-beta.c:1757-1764) and it enters every block linearly with Vol_0
+__device__ __forceinline__ double tangent_vol(const PView& P, int p) {
+  const double V0 = PF(P, F_VOL0, p);
+  return P.erosion ? V0 * (1.0 - PF(P, F_DMG1, p)) : V0;
+}
+
 template <int ND>
 struct TanCfg {
   static constexpr int S = (ND == 3) ? 729 : 81;    // stencil offsets per row node
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(64) void k_tangent_nh(PView P, GridD g, const MatD*
     nn += (int)__popcll(bal);
   }
   __syncthreads();
-  const double Jp = PF(P, F_JN1, p), sqrJ = Jp * Jp, V0 = PF(P, F_VOL0, p);
+  const double Jp = PF(P, F_JN1, p), sqrJ = Jp * Jp, V0 = tangent_vol(P, p);
   const double c0 = m.lame * sqrJ, c1 = m.G - 0.5 * m.lame * (sqrJ - 1);  // Neo-Hookean.c:107-110
   for (int q = lane; q < nn * nn; q += 64) {
     const int A = q / nn, B = q - A * nn;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
       }
       if (lane == 0) {
         law_of[jj] = m.type;
-        sp_V0[jj] = ok ? PF(P, F_VOL0, p) : 0.0;
+        sp_V0[jj] = ok ? tangent_vol(P, p) : 0.0;
       }
 #pragma unroll
       for (int i = 0; i < 5; i++)
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
           tab[wave][5][i] = (ND == 3) ? c.lz[i % KN] : 0.0;
         }
       if (lane == 0) {
-        const double Jp = PF(P, F_JN1, p), sqrJ = Jp * Jp, V0 = ok ? PF(P, F_VOL0, p) : 0.0;
+        const double Jp = PF(P, F_JN1, p), sqrJ = Jp * Jp, V0 = ok ? tangent_vol(P, p) : 0.0;
         coef[jj][0] = V0 * (m.lame * sqrJ);                       // Neo-Hookean.c:107-110
         coef[jj][1] = V0 * (m.G - 0.5 * m.lame * (sqrJ - 1));
         coef[jj][2] = V0 * m.G;

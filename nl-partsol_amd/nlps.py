@@ -30,7 +30,7 @@ class Grid(C.Structure):
 class Params(C.Structure):
     _fields_ = [("gamma_lme", C.c_double), ("tol_zero_lme", C.c_double), ("tol_wrapper_lme", C.c_double),
                 ("max_iter_lme", C.c_int), ("tol_radial_returning", C.c_double),
-                ("max_iter_radial_returning", C.c_int)]
+                ("max_iter_radial_returning", C.c_int), ("driver_eigenerosion", C.c_int)]
 
 
 class Material(C.Structure):
@@ -38,7 +38,7 @@ class Material(C.Structure):
                 ("psi_deg", C.c_double), ("kappa_0", C.c_double), ("exponent_ortiz", C.c_double),
                 ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
                 ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
-                ("delta_voce", C.c_double)]
+                ("delta_voce", C.c_double), ("Ceps", C.c_double), ("Gf", C.c_double)]
 
 
 _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e_n1", "J_n", "J_n1", "rho",
@@ -48,7 +48,7 @@ _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e
 class Particles(C.Structure):
     _fields_ = ([("np", C.c_int)] + [(k, _dp) for k in _PD] +
                 [("MatIdx", _ip), ("I0", _ip), ("lambda_", _dp), ("Beta", _dp), ("dt_F_n", _dp), ("dt_F_n1", _dp),
-                 ("dt_DF", _dp), ("C_ep", _dp), ("Back_stress", _dp)])
+                 ("dt_DF", _dp), ("C_ep", _dp), ("Back_stress", _dp), ("Damage_n", _dp), ("Damage_n1", _dp)])
 
 
 class Bcc(C.Structure):
@@ -151,7 +151,7 @@ def lib():
 
 
 def default_params():
-    return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10)
+    return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10, 0)
 
 
 def host_stencil_tables(ndim):
@@ -230,14 +230,15 @@ class Solver:
                                float(m.get("exponent_ortiz", 1.0)), float(m.get("eps_0", 1.0)),
                                float(m.get("p_ref", 0.0)), float(m.get("hardening_modulus", 0.0)),
                                float(m.get("theta_voce", 1.0)), float(m.get("K0_voce", 0.0)),
-                               float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)))
+                               float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)),
+                               float(m.get("Ceps", 0.0)), float(m.get("Gf", 0.0)))
         self._host = {}
         hp = Particles()
         hp.np = self.np
         keymap = {"x_GC": "x", "dis": "dis", "vel": "vel", "acc": "acc", "F_n": "F_n", "b_e_n": "b_e_n",
                   "J_n": "J_n", "rho": "rho", "mass": "mass", "Vol_0": "vol0", "Kappa_n": "kappa_n",
                   "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta", "dt_F_n": "dt_F_n",
-                  "Back_stress": "back_stress"}
+                  "Back_stress": "back_stress", "Damage_n": "damage_n"}
         for ck, k in keymap.items():
             if k in cloud and cloud[k] is not None:
                 a = np.ascontiguousarray(cloud[k], dtype=np.float64)
@@ -358,7 +359,7 @@ class Solver:
              "Kappa_n": np.zeros(n), "Kappa_n1": np.zeros(n), "EPS_n": np.zeros(n), "EPS_n1": np.zeros(n),
              "lambda_": np.zeros((n, d)), "Beta": np.zeros(n), "dt_F_n": np.zeros((n, T)),
              "dt_F_n1": np.zeros((n, T)), "dt_DF": np.zeros((n, T)), "C_ep": np.zeros((n, d * d)),
-             "Back_stress": np.zeros((n, 3))}
+             "Back_stress": np.zeros((n, 3)), "Damage_n": np.zeros(n), "Damage_n1": np.zeros(n)}
         if fields is not None:
             alias = {"x": "x_GC", "lambda": "lambda_", "beta": "Beta"}
             want = {alias.get(k, k) for k in fields}

@@ -1278,6 +1278,116 @@ int orc_constitutive(orc_particles *P, const orc_material *mats, const orc_param
   return STATUS;
 }
 
+static const double *g_tangent_damage = NULL;
+void orc_set_tangent_damage(const double *damage_n1) { g_tangent_damage = damage_n1; }
+
+/* ======================================================================================
+ * Eigenerosion
+ * ====================================================================================== */
+/* compute_Beps__Constitutive__, Constitutive/Fracture/Beps.c:16-80.  List_Particles_Node[A] holds the particles whose
+ * closest node is A, pushed for p = 0 .. Np-1 (LME.c:126-129, 962-964; push prepends, ChainOp.c:163-182), i.e. in
+ * DESCENDING p; the walk goes over NodalLocality_0[I0_p] in chain order and that list, and every hit is pushed
+ * (prepended) onto Beps[p]: the array below is Beps[p] in chain order = the reverse of the walk.  A particle whose
+ * total displacement is <= 1e-6 keeps its list unless `initialize`. */
+int orc_compute_beps(int *beps_n, int *beps, int stride, const orc_particles *P, const orc_mesh *M,
+                     const orc_material *mats, int initialize) {
+  int np = P->np, ndim = M->ndim, STATUS = 0;
+  /* List_Particles_Node as CSR (descending p inside a node) */
+  int *cnt = (int *)calloc((size_t)M->nnodes + 1, sizeof(int));
+  int *lst = (int *)malloc(sizeof(int) * (size_t)(np > 0 ? np : 1));
+  for (int p = 0; p < np; p++) cnt[P->I0[p] + 1]++;
+  for (int A = 0; A < M->nnodes; A++) cnt[A + 1] += cnt[A];
+  int *fill = (int *)calloc((size_t)M->nnodes, sizeof(int));
+  for (int p = np - 1; p >= 0; p--) lst[cnt[P->I0[p]] + fill[P->I0[p]]++] = p;
+  for (int p = 0; p < np; p++) {
+    const double *dis_p = &P->dis[p * ndim];
+    double nd2 = 0.0;
+    for (int i = 0; i < ndim; i++) nd2 += dis_p[i] * dis_p[i];
+    if (!(sqrt(nd2) > 0.000001 || initialize)) continue; /* :30-36 */
+    const double eps_distance_p = mats[P->matidx[p]].Ceps * M->h; /* :39-42 */
+    const double *xp = &P->x[p * ndim];
+    int tmp[4096], nt = 0;
+    const int I0_p = P->I0[p];
+    for (int a = M->r1_ptr[I0_p]; a < M->r1_ptr[I0_p + 1]; a++) { /* :49-52 */
+      const int A = M->r1[a];
+      for (int s = cnt[A]; s < cnt[A + 1]; s++) { /* :56-70 */
+        const int q = lst[s];
+        const double *xq = &P->x[q * ndim];
+        double d2 = 0.0;
+        for (int i = 0; i < ndim; i++) d2 += (xp[i] - xq[i]) * (xp[i] - xq[i]);
+        if (sqrt(d2) <= eps_distance_p && nt < 4096) tmp[nt++] = q;
+      }
+    }
+    if (nt > stride) {
+      STATUS = 1;
+      nt = stride;
+    }
+    beps_n[p] = nt;
+    for (int a = 0; a < nt; a++) beps[(size_t)p * stride + a] = tmp[nt - 1 - a];
+  }
+  free(cnt);
+  free(lst);
+  free(fill);
+  return STATUS;
+}
+
+/* __constitutive_update with the damage drivers on, U-Newmark-beta.c:1208-1242: a failed particle (Damage_n == 1)
+ * gets W = 0 and keeps its stress */
+int orc_constitutive_eroded(orc_particles *P, const orc_material *mats, const orc_params *prm, const double *damage_n) {
+  int STATUS = 0;
+  int T = P->T;
+  for (int p = 0; p < P->np; p++) {
+    if (damage_n[p] == 1.0) {
+      P->W[p] = 0.0;
+      continue;
+    }
+    const orc_material *mat = &mats[P->matidx[p]];
+    double dummyb[9], dk, de;
+    int st = orc_stress_one(P->ndim, mat, prm, &P->F_n1[p * T], &P->DF[p * T], P->J_n1[p],
+                            P->b_e_n ? &P->b_e_n[p * T] : dummyb, P->kappa_n ? P->kappa_n[p] : 0.0,
+                            P->eps_n ? P->eps_n[p] : 0.0, &P->stress[p * T], &P->W[p],
+                            P->b_e_n1 ? &P->b_e_n1[p * T] : dummyb, P->kappa_n1 ? &P->kappa_n1[p] : &dk,
+                            P->eps_n1 ? &P->eps_n1[p] : &de, P->C_ep ? &P->C_ep[p * P->ndim * P->ndim] : NULL,
+                            P->back_stress ? &P->back_stress[p * 3] : NULL);
+    if (st) STATUS |= 1;
+  }
+  return STATUS;
+}
+
+/* The damage part of __nodal_internal_forces (U-Newmark-beta.c:1313-1331): for every particle
+ * compute_damage__Constitutive__ (Constitutive.c:385-435) -> Eigenerosion__Constitutive__ (EigenErosion.c:29-117),
+ * then the Kirchhoff stress of the particle is scaled IN PLACE by (1 - Damage_n1[p]).  The neighbours enter through
+ * J_n1, Vol_0, W and Damage_n only, none of which the loop modifies, so the particle order does not matter. */
+int orc_eigenerosion_hook(double *damage_n1, const double *damage_n, orc_particles *P, const orc_material *mats,
+                          const int *beps_n, const int *beps, int stride, double DeltaX) {
+  const int ndim = P->ndim, T = P->T;
+  int STATUS = 0;
+  for (int p = 0; p < P->np; p++) {
+    const orc_material *mat = &mats[P->matidx[p]];
+    double *Stress_p = &P->stress[p * T];
+    double eigval[3] = {0.0, 0.0, 0.0}, eigvec[9], blk[9];
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) blk[i * ndim + j] = Stress_p[i * ndim + j];
+    if (orc_sym_eigen(eigval, eigvec, blk, ndim)) STATUS = 1; /* ascending, like dsyev (TensorLib.c:172-228) */
+    if (ndim == 2) eigval[2] = Stress_p[4];
+    if ((damage_n[p] < 1.0) && (eigval[0] > 0.0)) {
+      const double Ceps_p = mat->Ceps, Gf_p = mat->Gf;
+      const double V_p = P->vol0[p] * P->J_n1[p];
+      double sum_V = V_p, sum_V_x_W = V_p * P->W[p];
+      for (int a = 0; a < beps_n[p]; a++) {
+        const int q = beps[(size_t)p * stride + a];
+        const double V_q = P->vol0[q] * P->J_n1[q];
+        sum_V += V_q;
+        if (damage_n[q] < 1.0) sum_V_x_W += V_q * P->W[q];
+      }
+      const double G_p = (Ceps_p * DeltaX / sum_V) * sum_V_x_W;
+      if (G_p > Gf_p) damage_n1[p] = 1.0;
+    }
+    for (int i = 0; i < T; i++) Stress_p[i] *= (1.0 - damage_n1[p]);
+  }
+  return STATUS;
+}
+
 /* __nodal_internal_forces, U-Newmark-beta.c:1257-1374 + push_forward_dN__MeshTools__,
  * Shape-Functions.c:405-448 */
 int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,
@@ -1463,6 +1573,8 @@ int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lu
         dN1[A * ndim + i] = s;
       }
     double V0_p = P->vol0[p];
+    /* U-Newmark-beta.c:1757-1764: Stiffness_density_p *= (1 - Damage_n1[p]); the density enters linearly with V0 */
+    if (g_tangent_damage) V0_p *= (1.0 - g_tangent_damage[p]);
     const int *conn = &P->list[(size_t)p * ORC_MAXNB];
     for (int A = 0; A < nn; A++) {
       int Mask_node_A = nodes2mask[conn[A]];

@@ -73,6 +73,7 @@ typedef struct {
   /* Von-Mises (Plasticity/Von-Mises.c:246-253): sigma_y = kappa_0 */
   double hardening_modulus;     /* Hardening_modulus */
   double theta_voce, K0_voce, Kinf_voce, delta_voce; /* *_Hardening_Voce */
+  double Ceps, Gf;              /* eigenerosion: normalising constant and critical energy release rate */
 } orc_material;
 
 /* Globals snapshot: Globals.h:21,33-58; defaults InOutFun/Read_GramsShapeFun.c:100-104 */
@@ -142,6 +143,17 @@ int orc_tangent_matrix(double *K, int *pattern, double alpha_1, const double *lu
                        const orc_mesh *M, const orc_material *mats, const int *nodes2mask, const int *dofs2mask,
                        int nactive);
 void orc_roll_state(orc_particles *P);
+
+/* ---- eigenerosion: Constitutive/Fracture/Beps.c:16-80, EigenErosion.c:29-117 and the hooks of
+ * U-Newmark-beta.c:1218-1224 (__constitutive_update skips failed particles), :1313-1331 (damage + stress scaling inside
+ * __nodal_internal_forces), :1757-1764 (stiffness density scaled), :1950-1953 (roll of the damage field).
+ * beps_n[np], beps[np][stride]: the epsilon-neighbourhoods as arrays in chain order (push prepends). */
+int orc_compute_beps(int *beps_n, int *beps, int stride, const orc_particles *P, const orc_mesh *M,
+                     const orc_material *mats, int initialize);
+int orc_constitutive_eroded(orc_particles *P, const orc_material *mats, const orc_params *prm, const double *damage_n);
+int orc_eigenerosion_hook(double *damage_n1, const double *damage_n, orc_particles *P, const orc_material *mats,
+                          const int *beps_n, const int *beps, int stride, double DeltaX);
+void orc_set_tangent_damage(const double *damage_n1); /* NULL = off: orc_tangent_matrix scales by (1 - damage) */
 int orc_update_kinetics(double alpha_blend, const double *dU, const double *Un_dt,
                         const double *dU_dt, const double *dU_dt2, orc_particles *P,
                         const orc_mesh *M, const int *nodes2mask);

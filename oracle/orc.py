@@ -42,7 +42,7 @@ class Material(C.Structure):
                 ("psi_deg", C.c_double), ("kappa_0", C.c_double), ("exponent_ortiz", C.c_double),
                 ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
                 ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
-                ("delta_voce", C.c_double)]
+                ("delta_voce", C.c_double), ("Ceps", C.c_double), ("Gf", C.c_double)]
 
 
 class Params(C.Structure):
@@ -212,8 +212,37 @@ def make_materials(mats):
                           float(m.get("exponent_ortiz", 1.0)), float(m.get("eps_0", 1.0)),
                           float(m.get("p_ref", 0.0)), float(m.get("hardening_modulus", 0.0)),
                           float(m.get("theta_voce", 1.0)), float(m.get("K0_voce", 0.0)),
-                          float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)))
+                          float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)),
+                          float(m.get("Ceps", 0.0)), float(m.get("Gf", 0.0)))
     return arr
+
+
+BEPS_STRIDE = 1024
+
+
+def compute_beps(P, M, mats, beps=None, initialize=True):
+    """compute_Beps__Constitutive__: (beps_n[np], beps[np][BEPS_STRIDE]) in chain order"""
+    if beps is None:
+        beps = (np.zeros(P.np, dtype=np.int32), np.full((P.np, BEPS_STRIDE), -1, dtype=np.int32))
+    st = lib().orc_compute_beps(_i(beps[0]), _i(beps[1]), BEPS_STRIDE, C.byref(P.c), M.ptr, mats, 1 if initialize else 0)
+    assert st == 0
+    return beps
+
+
+def constitutive_eroded(P, mats, prm, damage_n):
+    return lib().orc_constitutive_eroded(C.byref(P.c), mats, C.byref(prm), _d(damage_n))
+
+
+def eigenerosion_hook(damage_n1, damage_n, P, mats, beps, DeltaX):
+    f = lib().orc_eigenerosion_hook
+    f.argtypes = [_dp, _dp, C.POINTER(CParticles), C.POINTER(Material), _ip, _ip, C.c_int, C.c_double]
+    return f(_d(damage_n1), _d(damage_n), C.byref(P.c), mats, _i(beps[0]), _i(beps[1]), BEPS_STRIDE, float(DeltaX))
+
+
+def set_tangent_damage(damage_n1):
+    f = lib().orc_set_tangent_damage
+    f.argtypes = [_dp]
+    f(_d(damage_n1) if damage_n1 is not None else None)
 
 
 class BccSet:
