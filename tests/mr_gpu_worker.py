@@ -30,8 +30,13 @@ def main():
     import torch
     import torch.distributed as dist
     import util
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # NLPS_MR_BACKEND=nccl (boxes with one GPU per rank): RCCL driven by the library itself (nlps_gpu_rccl_attach)
+    rccl = os.environ.get("NLPS_MR_BACKEND", "gloo") == "nccl"
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0)
+    if rccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     nlps = util.nlps()
     synth = util.synth
     halo_mod = importlib.import_module("nl-partsol_amd.halo")
@@ -48,12 +53,21 @@ def main():
     nnodes = int(np.prod(gn))
     lo, hi = halo_mod.SlabHalo.layer_ranges(world, CELLS, MARGIN, gn[ND - 1], reach=3)
     halo = halo_mod.SlabHalo(torch, dist, rank, world, nnodes // gn[ND - 1], gn[ND - 1], lo, hi)
-    S.set_halo_exchange(lambda dptr, nfield, elem, kind, phase: halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem,
-                                                                                 kind, phase))
-    S.set_node_window(lo[rank], hi[rank])
     overlap = os.environ.get("NLPS_OVERLAP", "1") == "1"
     band_lo, band_hi = halo.ghost_bands(rank)
-    S.set_ghost_bands(band_lo, band_hi, overlap)  # exchanges behind the interior tiles (two-phase callback)
+    if rccl:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(nlps.Solver.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        S.rccl_attach(bytes(uid.cpu().tolist()), rank, world, lo, hi, mode=0)  # sets the node window and the bands
+        if not overlap:
+            S.set_ghost_bands(band_lo, band_hi, False)
+    else:
+        S.set_halo_exchange(lambda dptr, nfield, elem, kind, phase: halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem,
+                                                                                     kind, phase))
+        S.set_node_window(lo[rank], hi[rank])
+        S.set_ghost_bands(band_lo, band_hi, overlap)  # exchanges behind the interior tiles (two-phase callback)
     S.set_resort_interval(2)
     S.initialise_shapefun()
     gb = nlps.BccSet([bc])

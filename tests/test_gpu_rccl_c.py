@@ -77,3 +77,23 @@ def test_rccl_all_reduce_mode_world_1():
     nod = S.explicit_nodal()
     assert abs(nod["mass"].reshape(-1, 3)[:, 0].sum() / case["cloud"]["mass"].sum() - 1) < 1e-12
     S.close()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, 1), (2, 0)])
+def test_partitioned_vs_whole_over_rccl(world, overlap):
+    """Boxes with one GPU per rank only (skipped on the one-GPU test box): tests/mr_gpu_worker.py with backend nccl --
+    every rank on its own card, the ghost layers exchanged by the library's own RCCL path, partitioned result against
+    one solver holding the whole cloud (index maps bit for bit, fields to 1e-11)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from util import free_port
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs (one per rank)" % world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(root, "tests", "mr_gpu_worker.py")]
+    env = dict(os.environ, NLPS_OVERLAP=str(overlap), NLPS_NDIM="3", NLPS_MR_BACKEND="nccl")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
