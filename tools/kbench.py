@@ -22,6 +22,7 @@ ap.add_argument("--law", default="nh")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--phases", action="store_true")
 ap.add_argument("--no-order", action="store_true")
+ap.add_argument("--det", action="store_true", help="deterministic mode")
 ap.add_argument("--stir", type=int, default=0, help="untimed shear steps first (DESIGN.md stirred cloud)")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("NLPS_GPU_LIB", "product")))
 a = ap.parse_args()
@@ -60,6 +61,8 @@ bcs = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nst), dtype=np.
 if a.no_order:
     S.L.nlps_gpu_debug_set_tile_ordering.argtypes = [C.c_void_p, C.c_int]
     S.L.nlps_gpu_debug_set_tile_ordering(S.h, 0)
+if a.det:
+    S.set_deterministic(True)
 S.initialise_shapefun()
 E = max(m["E"] for m in case["materials"])
 dt = 0.1 * case["h"] / np.sqrt(E / 1000.0)
