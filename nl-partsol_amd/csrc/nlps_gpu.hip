@@ -934,7 +934,8 @@ struct nlps_gpu {
   // on the stirred cloud of DESIGN.md (0.945 vs 1.004 ms) -- less than what the periodic physical re-sort recovers
   int tile_ordering = 0;
   int band_lo = -(1 << 30), band_hi = 1 << 30;  // ghost bands: layers <= band_lo and >= band_hi are shared with neighbours
-  bool overlap = false;     // overlap the halo exchanges with the interior tiles (needs bands + a two-phase callback)
+  int overlap = 0;          // halo exchanges: 0 blocking in place; 1 behind the interior tiles of the NEXT stage (split
+                            // launches, two-phase callback); 2 behind the interior tiles of the SAME launch (library RCCL only)
   unsigned long long* phase_d = nullptr;
   double* vec_d = nullptr;  // scratch pool for host vectors of the a21 per-dof updates
   size_t vec_cap = 0;
@@ -952,6 +953,7 @@ struct nlps_gpu {
   nlps_halo_fn halo;
   void* halo_ctx;
   struct RcclHalo* rccl = nullptr;  // ghost-layer exchange over RCCL owned by the library (nlps_gpu_rccl_attach)
+  bool rccl_wait_value = false;     // the attached exchange can be released through signal memory (overlap mode 2)
 
   bool timing;
   hipEvent_t ev[8];
@@ -1154,7 +1156,11 @@ extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_phases(nlps
 extern "C" int nlps_gpu_set_ghost_bands(nlps_gpu* h, int band_lo, int band_hi, int overlap) {
   h->band_lo = band_lo;
   h->band_hi = band_hi;
-  h->overlap = overlap != 0;
+  if (overlap == 2 && !h->rccl_wait_value) {
+    h->err = "nlps_gpu_set_ghost_bands: overlap 2 needs the library's RCCL path (nlps_gpu_rccl_attach)";
+    return 1;
+  }
+  h->overlap = overlap;
   return 0;
 }
 
@@ -1845,7 +1851,27 @@ struct RcclHalo {
   };
   std::map<const void*, Ev> ev;  // one pair of events per nodal array, re-recorded every step
   bool self_loop = false;        // world 1 self-test: the rank is its own two neighbours
+  // single-launch overlap (TileD::sig_flag): counters in device memory, flags in signal memory, one pair per stage
+  unsigned* sig_cnt = nullptr;   // [2]
+  unsigned* sig_flag[2] = {nullptr, nullptr};
+  unsigned sig_seq = 0;
+  bool can_wait_value = false;
 };
+
+// Holds the exchange stream until the boundary tiles of the launch in flight on the handle's stream have published
+// `seq` (tile_signal).  One lane polls an agent-scope load with s_sleep in between; it occupies one wave slot of one CU
+// and depends on nothing but the flag, and it gives up after ~1 s so that a launch that never happens cannot hang it
+// (hipStreamWaitValue32 does the same through the host: measured 55 us from the store to the next command, against
+// a few us for this kernel).
+__global__ void k_wait_flag(const unsigned* __restrict__ flag, unsigned seq, int* __restrict__ gstatus) {
+  if (threadIdx.x != 0) return;
+  for (long long it = 0; it < 20000000ll; it++) {
+    const unsigned v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(v - seq) >= 0) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  atomicOr(gstatus, ST_HALO);  // timed out: reported like a particle outside the node window
+}
 
 template <class T>
 __global__ void k_halo_add(T* __restrict__ a, const T* __restrict__ b, size_t n) {
@@ -1928,7 +1954,7 @@ static int rccl_exchange_on(nlps_gpu* h, void* dptr, int nfield, int elem, int k
 
 static int rccl_halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase) {
   RcclHalo* R = h->rccl;
-  if (R->world == 1 && !R->self_loop) return 0;
+  // (a rank without neighbours still goes through the stream choreography: that is how a one-GPU box rehearses it)
   if (phase == 0) return rccl_exchange_on(h, dptr, nfield, elem, kind, h->stream);
   RcclHalo::Ev& e = R->ev[dptr];
   if (!e.start) {
@@ -1938,6 +1964,14 @@ static int rccl_halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, in
   if (phase == 1) {
     HIPCHK(hipEventRecord(e.start, h->stream));
     HIPCHK(hipStreamWaitEvent(R->side, e.start, 0));
+    if (rccl_exchange_on(h, dptr, nfield, elem, kind, R->side)) return 1;
+    HIPCHK(hipEventRecord(e.done, R->side));
+    e.pending = true;
+    return 0;
+  }
+  if (phase == 3 || phase == 4) {  // start behind the boundary tiles of the launch that is in flight (stage 0 = K2, 1 = K3)
+    const int stage = phase - 3;
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, R->side, R->sig_flag[stage], R->sig_seq, h->gstatus_d);
     if (rccl_exchange_on(h, dptr, nfield, elem, kind, R->side)) return 1;
     HIPCHK(hipEventRecord(e.done, R->side));
     e.pending = true;
@@ -1992,13 +2026,23 @@ static int rccl_attach_common(nlps_gpu* h, ncclComm_t comm, bool own, int rank, 
       return 1;
     }
   HIPCHK(hipStreamCreateWithFlags(&R->side, hipStreamNonBlocking));
+  {
+    bool ok = hipMalloc((void**)&R->sig_cnt, 2 * sizeof(unsigned)) == hipSuccess &&
+              hipMemset(R->sig_cnt, 0, 2 * sizeof(unsigned)) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++)
+      ok = hipMalloc((void**)&R->sig_flag[k], 8) == hipSuccess && hipMemset(R->sig_flag[k], 0, 8) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    R->can_wait_value = ok;
+  }
   h->rccl = R;
+  h->rccl_wait_value = R->can_wait_value;
   // ghost bands (layers shared with a neighbour) and the node window follow from the layer ranges
   const int band_lo = rank > 0 ? std::min(R->hi[rank], R->hi[rank - 1]) : -1;
   const int band_hi = rank + 1 < world ? std::max(R->lo[rank], R->lo[rank + 1]) : nl;
   h->band_lo = rank > 0 && R->hi[rank - 1] >= R->lo[rank] ? band_lo : -(1 << 30);
   h->band_hi = rank + 1 < world && R->lo[rank + 1] <= R->hi[rank] ? band_hi : (1 << 30);
-  h->overlap = world > 1;
+  // 2: one launch per stage, the exchange released by the boundary tiles through signal memory; 1: split launches
+  h->overlap = world > 1 ? (R->can_wait_value ? 2 : 1) : 0;
   if (world > 1 && nlps_gpu_set_node_window(h, R->lo[rank], R->hi[rank])) return 1;
   return 0;
 }
@@ -2037,13 +2081,17 @@ extern "C" int nlps_gpu_rccl_detach(nlps_gpu* h) {
     if (kv.second.start) (void)hipEventDestroy(kv.second.start);
     if (kv.second.done) (void)hipEventDestroy(kv.second.done);
   }
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 2; k++) {
     if (R->rbuf[k]) (void)hipFree(R->rbuf[k]);
+    if (R->sig_flag[k]) (void)hipFree(R->sig_flag[k]);
+  }
+  if (R->sig_cnt) (void)hipFree(R->sig_cnt);
   if (R->side) (void)hipStreamDestroy(R->side);
   if (R->own_comm && R->comm) (void)g_rccl.CommDestroy(R->comm);
   delete R;
   h->rccl = nullptr;
-  h->overlap = false;
+  h->rccl_wait_value = false;
+  h->overlap = 0;
   h->band_lo = -(1 << 30);
   h->band_hi = 1 << 30;
   return 0;
@@ -2123,6 +2171,9 @@ static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 bound
   td.slab = h->deterministic ? h->slab_d : nullptr;
   td.slab_n = 1;
   td.slab_slot = 0;
+  td.sig_cnt = nullptr;
+  td.sig_flag = nullptr;
+  td.sig_seq = 0;
   td.work[0] = h->work1_d;
   td.work[1] = h->work2_d;
   td.range = h->nwork_d + 4 * cls;
@@ -2150,8 +2201,17 @@ static NodeRanges node_ranges(nlps_gpu* h, int part) {
   return {lo * plane, (il - lo) * plane, ih * plane, (hi + 1 - ih) * plane};
 }
 
-static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm) {
+// arms the boundary-done signal of a single-launch stage (overlap mode 2): stage 0 = K2, 1 = K3
+static void arm_signal(nlps_gpu* h, TileD& td, int stage) {
+  RcclHalo* R = h->rccl;
+  td.sig_cnt = R->sig_cnt + stage;
+  td.sig_flag = R->sig_flag[stage];
+  td.sig_seq = ++R->sig_seq;
+}
+
+static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm, bool signal = false) {
   TileD td = tile_view(h, cls);
+  if (signal) arm_signal(h, td, 0);
   if (h->deterministic && p2g) {  // one wave per tile, sorted list, slab flush (nlps_gpu_set_deterministic)
     const dim3 grid1(h->ntw), blk1(64);
     if (h->nd == 2) hipLaunchKernelGGL((k2_tile<2, true, 64, 1>), grid1, blk1, 0, h->stream, h->P, h->g, h->N, td, h->prm, dt, gamma_nm, h->gstatus_d);
@@ -2171,7 +2231,7 @@ static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm
 // S1: closest-node update + 1-ring activation + binning of the particles to I0-tiles, then lists, beta and the
 // Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`).  With `overlap` the exchange of the active
 // flags runs behind the tiles that do not touch a ghost band.
-static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, bool overlap = false) {
+static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, int overlap = 0) {
   int np = h->P.np;
   LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
             h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0);
@@ -2198,10 +2258,13 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  if (overlap) {
+  if (overlap == 1) {
     launch_k2(h, p2g, 2, dt, gamma_nm);
     if (halo(h, h->N.active, 1, 1, 1, 2)) return 1;
     launch_k2(h, p2g, 1, dt, gamma_nm);
+  } else if (overlap == 2) {  // the flags travelled behind the binning kernels; one launch, boundary tiles first
+    if (halo(h, h->N.active, 1, 1, 1, 2)) return 1;
+    launch_k2(h, p2g, 0, dt, gamma_nm, true);
   } else {
     launch_k2(h, p2g, 0, dt, gamma_nm);
   }
@@ -2605,7 +2668,8 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // ghost band have produced their part and is waited for only before those tiles need the result; the tiles
   // (and nodes) away from the bands run in between, on the handle's stream, while the exchange proceeds on the
   // callee's stream.  Without overlap each stage is one pass over all tiles and the exchange blocks in place.
-  const bool ov = (h->halo || h->rccl) && h->overlap;
+  const bool ov2 = h->rccl && h->overlap == 2 && !h->deterministic;  // one launch per stage, exchange behind its interior tiles
+  const bool ov = !ov2 && (h->halo || h->rccl) && h->overlap;
   double gv[3] = {0, 0, 0};
   if (gravity)
     for (int a = 0; a < ND; a++) gv[a] = gravity[a];
@@ -2658,8 +2722,11 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2]);
     else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2]);
   };
-  auto launch_k3 = [&](int cls) {
+  auto launch_k3 = [&](int cls, bool signal = false) {
     TileD td = tile_view(h, cls);
+    if (signal) {  // several laws: only the last launch releases the exchange (launches of one stream run in order)
+      if (h->uniform_law >= 0 || !h->k3_per_law) arm_signal(h, td, 1);
+    }
 #define NLPS_K3(NDv, LAWv)                                                                                      \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, h->mats_d, \
                      h->prm, h->gstatus_d, (const double*)nullptr)
@@ -2698,10 +2765,15 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else if (law == 3) NLPS_K3(2, 3);
       else if (!h->k3_per_law) NLPS_K3(2, -1);
       else {  // several laws in the cloud: one launch of the single-law kernel per law present
-        if (h->law_present & 1) NLPS_K3F(2, 0);
-        if (h->law_present & 2) NLPS_K3F(2, 1);
-        if (h->law_present & 4) NLPS_K3F(2, 2);
-        if (h->law_present & 8) NLPS_K3F(2, 3);
+        const int last = 31 - __builtin_clz((unsigned)h->law_present);
+        for (int l = 0; l < 4; l++) {
+          if (!(h->law_present & (1 << l))) continue;
+          if (signal && l == last) arm_signal(h, td, 1);
+          if (l == 0) NLPS_K3F(2, 0);
+          else if (l == 1) NLPS_K3F(2, 1);
+          else if (l == 2) NLPS_K3F(2, 2);
+          else NLPS_K3F(2, 3);
+        }
       }
     } else {
       if (law == 0) NLPS_K3(3, 0);
@@ -2710,10 +2782,15 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else if (law == 3) NLPS_K3(3, 3);
       else if (!h->k3_per_law) NLPS_K3(3, -1);
       else {
-        if (h->law_present & 1) NLPS_K3F(3, 0);
-        if (h->law_present & 2) NLPS_K3F(3, 1);
-        if (h->law_present & 4) NLPS_K3F(3, 2);
-        if (h->law_present & 8) NLPS_K3F(3, 3);
+        const int last = 31 - __builtin_clz((unsigned)h->law_present);
+        for (int l = 0; l < 4; l++) {
+          if (!(h->law_present & (1 << l))) continue;
+          if (signal && l == last) arm_signal(h, td, 1);
+          if (l == 0) NLPS_K3F(3, 0);
+          else if (l == 1) NLPS_K3F(3, 1);
+          else if (l == 2) NLPS_K3F(3, 2);
+          else NLPS_K3F(3, 3);
+        }
       }
     }
 #undef NLPS_K3F
@@ -2735,8 +2812,25 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   };
   // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel; the nodal accumulators of
   // the node window are reset by k_step_clear inside search_and_lists)
-  if (search_and_lists(h, false, true, dt, gamma_nm, ov)) return 1;
+  if (search_and_lists(h, false, true, dt, gamma_nm, ov2 ? 2 : (ov ? 1 : 0))) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
+  if (ov2) {
+    // mode 2: K2 is in flight as ONE launch; its boundary tiles release the exchange of the shared layers of nm, which
+    // runs beside its interior tiles; the handle's stream picks the result up before the nodal kernel
+    if (halo(h, h->N.nm, 1 + ND, 8, 0, 3)) return 1;
+    if (halo(h, h->N.nm, 1 + ND, 8, 0, 2)) return 1;
+    nodal_dU(0);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    launch_k3(0, true);
+    HIPCHK(hipGetLastError());
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
+    if (halo(h, h->N.force, ND, 8, 0, 4)) return 1;
+    if (halo(h, h->N.force, ND, 8, 0, 2)) return 1;
+    nodal_accel(0);
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    launch_k5(0);
+    HIPCHK(hipGetLastError());
+  } else {
   // with ghost bands the shared layers are gathered first (only boundary tiles reach them) and go on their way
   // while the rest is summed
   gather_nm(ov ? 2 : 0);
@@ -2775,6 +2869,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     launch_k5(0);
   }
   HIPCHK(hipGetLastError());
+  }  // !ov2
   h->P.flip ^= 1;  // F_n <- F_n+1, b_e,n <- b_e,n+1 by renaming
   h->rolled = true;
   if (h->timing) {

@@ -81,7 +81,39 @@ struct TileD {
   // only the "boundary" ones or only the "interior" ones (overlap of the halo exchange with interior work).
   const int* range;
   unsigned long long* phase;  // -DNLPS_PHASE_TIMING=1 only: per-phase wave-cycle sums (developer profiling)
+  // Single-launch overlap of the halo exchange (multi-GPU): the work list holds the boundary tiles first; every boundary
+  // workgroup counts itself on sig_cnt after its flush, the last one publishes sig_seq on sig_flag, on which the
+  // library's exchange stream waits (k_wait_flag): the exchange of the shared layers then runs beside the interior
+  // tiles of the SAME launch.  nullptr = off.
+  unsigned* sig_cnt;
+  unsigned* sig_flag;
+  unsigned sig_seq;
 };
+
+// see TileD::sig_flag.  nb = number of boundary workgroups of this launch (device-side, from k_tile_scan's ranges);
+// called by all threads of a workgroup after its global flush
+__device__ __forceinline__ void tile_signal(const TileD& td, int wb, int nb) {
+  if (!td.sig_flag || wb >= nb) return;
+  // producer side of the hand-off (MI355X_MICROARCH.md, "Valid forms"): every wave drains its own flush atomics,
+  // the workgroup meets, ONE lane releases at agent scope and counts (256 threads fencing cost 2-4x one lane's, per
+  // workgroup, and 900 boundary workgroups do this)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = atomicAdd(td.sig_cnt, 1u);
+    if (old == (unsigned)nb - 1u) {
+      atomicExch(td.sig_cnt, 0u);  // ready for the next launch
+      __hip_atomic_store(td.sig_flag, td.sig_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// a launch without boundary tiles still has to release the waiting stream
+__device__ __forceinline__ void tile_signal_empty(const TileD& td, int nb) {
+  if (td.sig_flag && nb == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(td.sig_flag, td.sig_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Developer profiling: wall-clock cycles per kernel phase, summed per wave (slot spread over 1024 rows to keep
 // the atomics off one address).  Compiled out by default.
@@ -370,6 +402,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
   __shared__ double acc[NF * NWA];
   __shared__ unsigned actrow[NROWS];
   const int wb = td.range[2 * (SPLIT - 1)] + (int)blockIdx.x;
+  const int nbnd = td.sig_flag ? td.range[4 + 2 * (SPLIT - 1) + 1] : 0;  // boundary workgroups come first (cls 0 view)
+  tile_signal_empty(td, nbnd);
   if (wb >= td.range[2 * (SPLIT - 1) + 1]) return;
   const int2 wk = td.work[SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
@@ -582,6 +616,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
       if (in) atomic_add_f64(N.nm + (size_t)node * NF + f, v);
     }
   }
+  tile_signal(td, wb, nbnd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,6 +645,8 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
   constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
   __shared__ double fac[ND * NWA];
   const int wb = td.range[2 * (K3_SPLIT - 1)] + (int)blockIdx.x;
+  const int nbnd = (MODE == 1 && td.sig_flag) ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;
+  if (MODE == 1) tile_signal_empty(td, nbnd);
   if (wb >= td.range[2 * (K3_SPLIT - 1) + 1]) return;
   const int2 wk = td.work[K3_SPLIT - 1][wb];
   const int tile = wk.x, part = wk.y;
@@ -657,6 +694,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
           double* out = td.slab + ((size_t)tile * td.slab_n + td.slab_slot) * (ND * TileCfg<ND>::NWA);
           for (int qq = threadIdx.x; qq < TileCfg<ND>::NWA * ND; qq += NT) out[qq] = 0.0;
         }
+        if (MODE == 1) tile_signal(td, wb, nbnd);
         return;
       }
     }
@@ -984,6 +1022,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
       if (in) atomic_add_f64(N.force + (size_t)node * ND + f, v);
     }
   }
+  tile_signal(td, wb, nbnd);
 }
 
 // Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)

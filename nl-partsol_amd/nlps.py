@@ -528,7 +528,8 @@ class Solver:
         self.num_particles()
 
     def set_ghost_bands(self, band_lo, band_hi, overlap=True):
-        self._chk(self.L.nlps_gpu_set_ghost_bands(self.h, int(band_lo), int(band_hi), 1 if overlap else 0))
+        """overlap: False / 0 blocking exchanges, True / 1 split launches, 2 one launch per stage (library RCCL only)"""
+        self._chk(self.L.nlps_gpu_set_ghost_bands(self.h, int(band_lo), int(band_hi), int(overlap)))
 
     def set_node_window(self, layer_lo, layer_hi):
         self._chk(self.L.nlps_gpu_set_node_window(self.h, int(layer_lo), int(layer_hi)))

@@ -97,3 +97,34 @@ def test_partitioned_vs_whole_over_rccl(world, overlap):
     env = dict(os.environ, NLPS_OVERLAP=str(overlap), NLPS_NDIM="3", NLPS_MR_BACKEND="nccl")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0 and "MULTIRANK_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_overlap_choreographies_world_1(mode):
+    """The two overlapped forms of the explicit step with the library's exchange attached (no neighbour, so nothing moves,
+    but every launch split / signal / stream wait runs): 1 = boundary and interior tiles as separate launches, 2 = ONE
+    launch per stage whose boundary tiles release the exchange stream through signal memory (hipStreamWaitValue32).
+    Ghost bands inside the cloud make both tile classes non-empty; results must equal a plain run."""
+    n = nlps()
+    case = make_case(3, [14, 13, 24], [3, 3, 3], [8, 7, 18], velocity=[0.0, 0.0, -10.0])
+    nl = case["grid_n"][2]
+    S = gpu_setup(case, init=False, nsteps=5)
+    S.rccl_attach(n.Solver.rccl_unique_id(), 0, 1, [0], [nl - 1], mode=0)
+    lo, hi = S.touched_layers()
+    S.set_ghost_bands(lo + 5, hi - 5, mode)
+    S.set_resort_interval(2)
+    S.initialise_shapefun()
+    P = gpu_setup(case, nsteps=5)
+    P.set_resort_interval(2)
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, 5)])
+    for t in range(5):
+        S.explicit_step(gb, t, 1e-3)
+        P.explicit_step(gb, t, 1e-3)
+    a, b = S.download_state(), P.download_state()
+    assert S.status_flags() == 0
+    assert np.array_equal(a["I0"], b["I0"])
+    for k in ("x", "vel", "Stress", "F_n"):
+        assert_close(a[k], b[k], 1e-12, f"{k}: overlap mode {mode} vs plain")
+    na, nb = S.explicit_nodal(), P.explicit_nodal()
+    for k in ("mass", "force", "accel"):
+        assert_close(na[k], nb[k], 1e-11, f"nodal {k}: overlap mode {mode} vs plain")
