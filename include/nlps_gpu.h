@@ -304,8 +304,12 @@ int nlps_gpu_set_halo_exchange(nlps_gpu *h, nlps_halo_fn fn, void *ctx);
  * of ranks.  A particle that leaves the window raises status flag 16.  Default: the whole grid. */
 int nlps_gpu_set_node_window(nlps_gpu *h, int layer_lo, int layer_hi);
 /* Ghost bands of this rank: node layers <= band_lo and >= band_hi (slab axis) are shared with a neighbouring
- * rank (pass band_lo < 0 / band_hi >= n_layers for "none").  overlap != 0: explicit_step orders its work so that
- * every halo exchange runs behind the tiles and nodes that do not touch a band (two-phase callback above). */
+ * rank (pass band_lo < 0 / band_hi >= n_layers for "none").  overlap: 0 = every exchange blocks in place; 1 =
+ * explicit_step launches the tiles that touch a band and the others separately and every exchange runs behind the
+ * interior tiles of the next stage (two-phase callback above, or the library's RCCL path); 2 = ONE launch per stage
+ * with the boundary tiles first: the last of them releases the library's exchange stream through a device flag and
+ * the exchange runs beside the interior tiles of the same launch (library RCCL path only; what nlps_gpu_rccl_attach
+ * selects for world > 1). */
 int nlps_gpu_set_ghost_bands(nlps_gpu *h, int band_lo, int band_hi, int overlap);
 /* Range of node layers along the slab axis this rank's particles may touch (5^d stencil reach). */
 int nlps_gpu_touched_layers(nlps_gpu *h, int *lo, int *hi);
