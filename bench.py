@@ -63,13 +63,14 @@ def parse():
 
 
 def build_case(rank, world, cells, margin=5, cells_z=None):
-    """Rank's block: cells x cells x cells_z cells (8 particles each) at z-offset rank * cells_z of a grid that holds
-    `world` such blocks plus a margin."""
+    """Rank's block: cells x cells x cells_z[rank] cells (8 particles each), stacked along z in a grid that holds the
+    blocks of all ranks plus a margin.  cells_z: one thickness for all ranks or a list (unequal slabs)."""
     synth = importlib.import_module("nl-partsol_amd.synth")
     cells_z = cells if cells_z is None else cells_z
-    gc = [cells + 2 * margin, cells + 2 * margin, cells_z * world + 2 * margin]
-    lo = [margin, margin, margin + cells_z * rank]
-    cloud = synth.make_cloud(3, gc, lo, [cells, cells, cells_z], h=1.0, jitter=0.05, seed=12345 + rank,
+    cz = list(cells_z) if hasattr(cells_z, "__len__") else [int(cells_z)] * world
+    gc = [cells + 2 * margin, cells + 2 * margin, sum(cz) + 2 * margin]
+    lo = [margin, margin, margin + sum(cz[:rank])]
+    cloud = synth.make_cloud(3, gc, lo, [cells, cells, cz[rank]], h=1.0, jitter=0.05, seed=12345 + rank,
                              velocity=[0.0, 0.0, -10.0])
     return {"ndim": 3, "cells": gc, "grid_n": synth.grid_nodes(gc), "origin": [0.0, 0.0, 0.0], "h": 1.0,
             "cloud": cloud, "materials": [{"type": 0, "E": 1.0e7, "nu": 0.3}], "block_lo": lo}
@@ -280,9 +281,9 @@ def main():
     cells, cells_z = a.cells, a.cells
     if a.scaling == "strong":  # one cube of --particles-total particles, z-slabs of equal thickness
         cells = int(round((a.particles_total / 8.0) ** (1.0 / 3.0)))
-        if cells % world:
-            raise SystemExit("--scaling strong: %d cell layers do not split evenly over %d ranks" % (cells, world))
-        cells_z = cells // world
+        if cells < 8 * world:
+            raise SystemExit("--scaling strong: %d cell layers are too few for %d ranks" % (cells, world))
+        cells_z = [cells // world + (1 if r < cells % world else 0) for r in range(world)]  # 100 layers / 8 = 13,13,13,13,12,...
     case = build_case(rank, world, cells, margin, cells_z)
     total_steps = a.steps + a.warmup + 1
     # One real (non-default) HIP stream shared by the library's kernels and the torch ops of the halo callback:
@@ -332,8 +333,9 @@ def main():
 
     def step(t):
         if world > 1 and a.migrate_every > 0 and t % a.migrate_every == 0:
-            halo.migrate(S, margin + rank * cells_z - 1 if rank > 0 else 0,
-                         margin + (rank + 1) * cells_z + 1 if rank + 1 < world else case["grid_n"][2] - 1)
+            cz = list(cells_z) if hasattr(cells_z, "__len__") else [cells_z] * world
+            halo.migrate(S, margin + sum(cz[:rank]) - 1 if rank > 0 else 0,
+                         margin + sum(cz[:rank + 1]) + 1 if rank + 1 < world else case["grid_n"][2] - 1)
         S.explicit_step(bcs, t, dt)
 
     t = 0
@@ -383,6 +385,12 @@ def main():
     if world == 1 and not a.no_stirred:
         stirred = stirred_figure(nlps, synth, a, stream)
 
+    # particles of the whole job (ranks may hold slabs of unequal thickness)
+    npart_total = case["cloud"]["x"].shape[0]
+    if world > 1:
+        nt = torch.tensor([npart_total], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
+        npart_total = int(nt.item())
     if rank == 0:
         npart = case["cloud"]["x"].shape[0]
         names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update", "nodal"]
@@ -419,14 +427,15 @@ def main():
             traffic = traffic * npart / 1.0e6
         domk = per_kernel.get(names[dom], {})
         out = {
-            "metric": "particle-steps/sec (P2G+stress+G2P)", "value": npart * world * a.steps / elapsed,
+            "metric": "particle-steps/sec (P2G+stress+G2P)", "value": npart_total * a.steps / elapsed,
             "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D elastic cube impact, %d particles/GPU (%dx%dx%d cells x 8), LME gamma=3, "
                                    "Neo-Hookean E=1e7 nu=0.3, explicit predictor-corrector step, 1xMI355X per rank; "
-                                   "z-slabs for N>1 (%s scaling)" % (npart, cells, cells, cells_z, a.scaling),
-                       "particles_total": npart * world, "grid_nodes": int(np.prod(case["grid_n"])),
+                                   "z-slabs for N>1 (%s scaling)" % (npart, cells, cells, case["cells"][2] - 2 * margin if world == 1 else
+                                                                      (cells_z[0] if hasattr(cells_z, "__len__") else cells_z), a.scaling),
+                       "particles_total": npart_total, "grid_nodes": int(np.prod(case["grid_n"])),
                        "halo": a.halo if world > 1 else "none", "halo_impl": halo_impl,
                        "halo_overlap": bool(a.overlap) if world > 1 else None,
                        "resorts_in_timed_region": 1, "library_default_resort_interval": 50},

@@ -23,9 +23,12 @@ class SlabHalo:
     @staticmethod
     def layer_ranges(world, cells_per_rank, margin, nlayers, reach=4):
         """Rank r owns cells [margin + r*c, margin + (r+1)*c): its closest nodes lie on the node planes
-        of those cells, the 5^d stencil reaches 2 planes further, `reach` >= 2 adds room for drift."""
-        lo = [max(0, margin + r * cells_per_rank - reach) for r in range(world)]
-        hi = [min(nlayers - 1, margin + (r + 1) * cells_per_rank + reach) for r in range(world)]
+        of those cells, the 5^d stencil reaches 2 planes further, `reach` >= 2 adds room for drift.
+        cells_per_rank may be a list (slabs of unequal thickness: a cube whose layers do not divide evenly)."""
+        cz = list(cells_per_rank) if hasattr(cells_per_rank, "__len__") else [int(cells_per_rank)] * world
+        start = [margin + sum(cz[:r]) for r in range(world + 1)]
+        lo = [max(0, start[r] - reach) for r in range(world)]
+        hi = [min(nlayers - 1, start[r + 1] + reach) for r in range(world)]
         return lo, hi
 
     def overlap(self, a, b):

@@ -911,26 +911,29 @@ def test_migration_between_ranks_on_one_gpu(world):
     assert r.returncode == 0 and "MIGRATION_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def test_bench_multi_rank_path_rehearsal():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_multi_rank_path_rehearsal(scaling):
     """bench.py --gpus 2 end to end (slab clouds, shared stream, halo callback with overlap, node window, ghost
     bands, barrier + max-over-ranks timing, JSON line) with two ranks on the one card of the test box; gloo stands
-    in for RCCL (NLPS_BENCH_BACKEND), the real launch is the driver's on an 8-GPU node."""
+    in for RCCL (NLPS_BENCH_BACKEND), the real launch is the driver's on an 8-GPU node.  strong: ONE cube of 17^3 cells
+    split into slabs of 9 and 8 layers (the uneven split of 100 layers over 8 ranks in small)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = free_port()
+    extra = ["--cells", "16"] if scaling == "weak" else ["--scaling", "strong", "--particles-total", str(8 * 17 ** 3)]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "2", "--cells", "16", "--no-cpu-baseline"]
+           "--warmup", "2", "--no-cpu-baseline"] + extra
     env = dict(os.environ, NLPS_BENCH_BACKEND="gloo", NLPS_BENCH_DEVICE="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["config"]["particles_total"] == 2 * 16 ** 3 * 8
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
+    assert out["config"]["particles_total"] == (2 * 16 ** 3 * 8 if scaling == "weak" else 8 * 17 ** 3)
 
 
 @pytest.mark.parametrize("ndim", [2, 3])
