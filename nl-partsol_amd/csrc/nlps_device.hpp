@@ -109,6 +109,15 @@ struct ParamsD {
 #ifndef NLPS_JUNROLL_MASK
 #define NLPS_JUNROLL_MASK 5  // neighbourhood-mask rows unrolled: no run-time index into ly2[] (8 selects per row); K2 0.294 -> 0.282 ms
 #endif
+#ifndef NLPS_K3_TWOPASS
+#define NLPS_K3_TWOPASS 1  // K3: gather pass and moments pass separately (see k3_tile)
+#endif
+#ifndef NLPS_K3_DIRECT
+#define NLPS_K3_DIRECT 1  // K3 gather without plane partial sums (see k3_tile)
+#endif
+#ifndef NLPS_K3_WAVES_NH
+#define NLPS_K3_WAVES_NH 3  // fused 3-D Neo-Hookean K3 (two-pass gather): 0.294 -> 0.267 ms at 1 M particles
+#endif
 #ifndef NLPS_K3_WAVES
 #define NLPS_K3_WAVES 2  // Hencky / Drucker-Prager need > 256 VGPRs otherwise (1 wave/SIMD: 0.54 -> 0.37 ms at 2)
 #endif

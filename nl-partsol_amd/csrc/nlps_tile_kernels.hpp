@@ -629,8 +629,14 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
 // FILT (clouds with several laws): the launch handles only the tile's particles whose material follows LAW; they are
 // compacted into an LDS list first, so every lane works and the kernel is the single-law specialisation (one launch per
 // law present; the run-time dispatch over all laws in one kernel needed 436 B of scratch per lane and 0.51 ms).
+// waves per SIMD the register budget is set for: the fused 3-D Neo-Hookean stage fits three (two-pass gather), the
+// spectral and plastic laws need the registers of two (Hencky at three: 192 B of scratch and 4 % slower)
+template <int ND, int LAW, int MODE>
+struct K3Waves {
+  static constexpr int value = ND == 2 ? NLPS_K3_WAVES_2D : ((MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN) ? NLPS_K3_WAVES_NH : NLPS_K3_WAVES);
+};
 template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
-__global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NLPS_K3_WAVES)) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+__global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value))) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus,
                                                const double* __restrict__ dVgrid) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
@@ -741,8 +747,87 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
     for (int a = 0; a < ND * ND; a++) G[a] = 0.0;
 #pragma unroll
     for (int a = 0; a < (RATES ? ND * ND : 1); a++) Gv[a] = 0.0;
+    // TWOPASS (3-D, no rate tensors): the gather of dU (LDS reads; G, U) and the moments (no memory traffic; Z, r, J)
+    // run as two passes over the rows, each with its own masked weights.  The two live sets never overlap -- 12 + 17
+    // doubles of accumulators and row temporaries in the first, 10 + 14 in the second, instead of 37 + 25 at once --
+    // which is what lets the elastic laws run at three waves per SIMD; it costs ~350 more VALU instructions a particle.
+    // (the level-B modes keep the single pass: with and without rate tensors they must give the same F bit for bit)
+    // and the laws that stay at two waves per SIMD keep it too: there the second set of masked weights only costs)
+    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN;
+    if (TWOPASS) {
+#pragma unroll 1
+      for (int k = 0; k < KN; k++) {
+        const unsigned pb = plane_bits<ND>(c, k);
+        const int basek = base + PS * (k - 2);
+        const double zd0 = ez5[k], zd1 = zd0 * (double)(k - 2);
+#pragma unroll NLPS_JUNROLL_K3
+        for (int j = 0; j < 5; j++) {
+          const unsigned bits = (pb >> (5 * j)) & 31u;
+          double m[5], R0[ND], R1[ND];
+#pragma unroll
+          for (int a = 0; a < ND; a++) R0[a] = R1[a] = 0.0;
+#pragma unroll
+          for (int i = 0; i < 5; i++) m[i] = masked_weight(c.ex[i], bits, i);
+          const double mu[5] = {-2.0 * m[0], -m[1], 0.0, m[3], 2.0 * m[4]};
+#pragma unroll
+          for (int i = 0; i < 5; i++) {
+            const int li = basek + (i - 2) + W * (j - 2);
+            const double2 u01 = du2[li];
+            const double u2 = duz[(ND == 3) ? li : 0];
+            const double uu[3] = {u01.x, u01.y, u2};
+#pragma unroll
+            for (int a = 0; a < ND; a++) {
+              R0[a] = fma(m[i], uu[a], R0[a]);
+              if (i != 2) R1[a] = fma(mu[i], uu[a], R1[a]);
+            }
+          }
+          const double y0 = ey5[j];
+          const double w00 = y0 * zd0, w10 = (y0 * (double)(j - 2)) * zd0, w01 = y0 * zd1;
+#pragma unroll
+          for (int a = 0; a < ND; a++) {
+            G[a * ND + 0] = fma(w00, R1[a], G[a * ND + 0]);
+            G[a * ND + 1] = fma(w10, R0[a], G[a * ND + 1]);
+            G[a * ND + (2 % ND)] = fma(w01, R0[a], G[a * ND + (2 % ND)]);
+            U[a] = fma(w00, R0[a], U[a]);
+          }
+        }
+      }
+#pragma unroll 1
+      for (int k = 0; k < KN; k++) {
+        const unsigned pb = plane_bits<ND>(c, k);
+        double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const unsigned bits = (pb >> (5 * j)) & 31u;
+          const double m0 = masked_weight(c.ex[0], bits, 0), m1 = masked_weight(c.ex[1], bits, 1),
+                       m2 = masked_weight(c.ex[2], bits, 2), m3 = masked_weight(c.ex[3], bits, 3),
+                       m4 = masked_weight(c.ex[4], bits, 4);
+          const double s13 = m1 + m3, s04 = m0 + m4;
+          const double A0 = m2 + s13 + s04, A1 = fma(2.0, m4 - m0, m3 - m1), A2 = fma(4.0, s04, s13);
+          const double cj = (double)(j - 2);
+          const double y0 = ey5[j], y1 = y0 * cj, y2 = y1 * cj;
+          P00 = fma(y0, A0, P00);
+          P10 = fma(y0, A1, P10);
+          P20 = fma(y0, A2, P20);
+          P01 = fma(y1, A0, P01);
+          P11 = fma(y1, A1, P11);
+          P02 = fma(y2, A0, P02);
+        }
+        const double z0 = ez5[k], ck = (double)(k - 2), z1 = z0 * ck, z2 = z1 * ck;
+        Z = fma(z0, P00, Z);
+        rx = fma(z0, P10, rx);
+        ry = fma(z0, P01, ry);
+        rz = fma(z1, P00, rz);
+        Jxx = fma(z0, P20, Jxx);
+        Jxy = fma(z0, P11, Jxy);
+        Jxz = fma(z1, P10, Jxz);
+        Jyy = fma(z0, P02, Jyy);
+        Jyz = fma(z1, P01, Jyz);
+        Jzz = fma(z2, P00, Jzz);
+      }
+    }
 #pragma unroll NLPS_KUNROLL_K3G
-    for (int k = 0; k < KN; k++) {
+    for (int k = 0; k < (TWOPASS ? 0 : KN); k++) {
       const unsigned pb = plane_bits<ND>(c, k);
       const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
       double P00 = 0.0, P10 = 0.0, P20 = 0.0, P01 = 0.0, P11 = 0.0, P02 = 0.0;
@@ -750,6 +835,10 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
       double Hx[ND], Hy[ND], Hz[ND];  // the same for the velocity increments (RATES)
 #pragma unroll
       for (int a = 0; a < ND; a++) Gx[a] = Gy[a] = Gz[a] = Hx[a] = Hy[a] = Hz[a] = 0.0;
+      // DIRECT (3-D, no rate tensors): every row goes straight into the totals with its y*z weight -- 15 doubles of
+      // plane partials less to keep alive (the kernel then fits three waves per SIMD), for 5 more FMAs per row
+      constexpr bool DIRECT = (NLPS_K3_DIRECT != 0) && ND == 3 && MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN;
+      const double zd0 = ez5[k], zd1 = zd0 * (double)(k - 2), zd2 = zd1 * (double)(k - 2);
 #pragma unroll NLPS_JUNROLL_K3
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
@@ -791,6 +880,27 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
         const double A2 = fma(4.0, s04, s13);                  // sum e u^2
         const double cj = (double)(j - 2);
         const double y0 = ey5[j], y1 = y0 * cj, y2 = y1 * cj;
+        if (DIRECT) {
+          const double w00 = y0 * zd0, w10 = y1 * zd0, w20 = y2 * zd0, w01 = y0 * zd1, w11 = y1 * zd1, w02 = y0 * zd2;
+          Z = fma(w00, A0, Z);
+          rx = fma(w00, A1, rx);
+          ry = fma(w10, A0, ry);
+          rz = fma(w01, A0, rz);
+          Jxx = fma(w00, A2, Jxx);
+          Jxy = fma(w10, A1, Jxy);
+          Jxz = fma(w01, A1, Jxz);
+          Jyy = fma(w20, A0, Jyy);
+          Jyz = fma(w11, A0, Jyz);
+          Jzz = fma(w02, A0, Jzz);
+#pragma unroll
+          for (int a = 0; a < ND; a++) {
+            G[a * ND + 0] = fma(w00, R1[a], G[a * ND + 0]);
+            G[a * ND + 1] = fma(w10, R0[a], G[a * ND + 1]);
+            G[a * ND + (2 % ND)] = fma(w01, R0[a], G[a * ND + (2 % ND)]);
+            U[a] = fma(w00, R0[a], U[a]);
+          }
+          continue;
+        }
         P00 = fma(y0, A0, P00);
         P10 = fma(y0, A1, P10);
         P20 = fma(y0, A2, P20);
@@ -809,7 +919,9 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K3_WAVES_2D : NL
           }
         }
       }
-      if (ND == 3) {
+      if (DIRECT) {
+        // totals already updated row by row
+      } else if (ND == 3) {
         const double z0 = ez5[k], ck = (double)(k - 2), z1 = z0 * ck, z2 = z1 * ck;
         Z = fma(z0, P00, Z);
         rx = fma(z0, P10, rx);
