@@ -929,10 +929,12 @@ struct nlps_gpu {
   int *dmg_first_d = nullptr, *dmg_last_d = nullptr;  // eigenerosion: run of every node in the I0-sorted particle list
   double* slab_d = nullptr; // P2G window slabs [ntiles][K2_SPLIT][1+ND][NW] (TileD::slab), deterministic mode only
   bool deterministic = false;
-  // canonical (layer, closest node) order of every tile list each step (k_tile_order).  OFF: measured at 1 M particles it
-  // costs 17 us per step, changes nothing on a freshly sorted cloud (its lists are in that order already) and gains 6 %
-  // on the stirred cloud of DESIGN.md (0.945 vs 1.004 ms) -- less than what the periodic physical re-sort recovers
-  int tile_ordering = 0;
+  // canonical (layer, closest node) order of every tile list each step (k_tile_order) for the LDS-atomic-bound K2 and
+  // K3; the memory-bound K5 keeps the lists as binned.  13 us per step at 1 M particles.  A freshly sorted cloud has its
+  // lists in that order already (0.685 vs 0.677 ms/step), but once particles have changed closest node -- 45 steps into
+  // the bench cloud's fall -- K2 runs 0.231 instead of 0.300 ms and K3 0.260 instead of 0.304, and the stirred cloud of
+  // DESIGN.md 0.84 instead of 0.95 ms/step
+  int tile_ordering = 1;
   int band_lo = -(1 << 30), band_hi = 1 << 30;  // ghost bands: layers <= band_lo and >= band_hi are shared with neighbours
   int overlap = 0;          // halo exchanges: 0 blocking in place; 1 behind the interior tiles of the NEXT stage (split
                             // launches, two-phase callback); 2 behind the interior tiles of the SAME launch (library RCCL only)
@@ -949,6 +951,7 @@ struct nlps_gpu {
   long long knnz_blocks = -1;
   bool tangent_grouped = true;  // one workgroup per closest node (false: one wave per particle, kept for comparison)
   int* order_d;
+  int* order2_d = nullptr;  // canonical tile lists (k_tile_order), allocated on first use
 
   nlps_halo_fn halo;
   void* halo_ctx;
@@ -1266,6 +1269,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->prm.tol_radial = prm->tol_radial_returning;
   h->prm.max_iter_radial = prm->max_iter_radial_returning;
   h->P.erosion = prm->driver_eigenerosion != 0;
+  if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
 
   h->tab = nlps_host::build_tables(g.nd);
   HIPCHK(hipMalloc((void**)&h->rank1_d, 27 * 27));
@@ -1674,7 +1678,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2180,7 +2184,8 @@ static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 bound
   td.phase = h->phase_d;
   td.start = h->tile_start_d;
   td.count = h->tile_count_d;
-  td.order = h->order_d;
+  td.order_m = h->order_d;
+  td.order = (h->tile_ordering || h->deterministic) ? h->order2_d : h->order_d;
   return td;
 }
 
@@ -2247,14 +2252,18 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
                      h->band_hi, h->work1_d, h->work2_d, h->nwork_d);
   hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                      h->order_d);
+  if ((h->deterministic || h->tile_ordering) && !h->order2_d) {
+    HIPCHK(hipMalloc((void**)&h->order2_d, h->P.npad * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->order2_d, 0, h->P.npad * sizeof(int), h->stream));
+  }
   if (h->deterministic) {
     TileD td = tile_view(h, 0);
-    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
-    else hipLaunchKernelGGL((k_tile_order<3, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
+    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+    else hipLaunchKernelGGL((k_tile_order<3, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
   } else if (h->tile_ordering) {
     TileD td = tile_view(h, 0);
-    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
-    else hipLaunchKernelGGL((k_tile_order<3, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, h->order_d);
+    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+    else hipLaunchKernelGGL((k_tile_order<3, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));

@@ -70,7 +70,8 @@ struct TileD {
   int slab_n, slab_slot;  // slabs per tile (one per law launched on the tile) and the slot this launch writes
   const int* start;
   const int* count;
-  const int* order;
+  const int* order;   // tile lists: canonical (layer, closest node) order when per-tile ordering is on (K2, K3)
+  const int* order_m; // tile lists as binned: runs of memory-consecutive particles (K5 and the level-B gathers)
   // compacted work lists (k_tile_scan): work[S-1][b] = (tile, part) for the b-th workgroup of a kernel that
   // splits a tile's particles over S workgroups, only for non-empty (tile, part) pairs; nwork[S-1] entries.
   // Consecutive workgroups go to different XCDs, so a compacted list spreads the populated tiles evenly over
@@ -289,10 +290,12 @@ __global__ void k_fill_order(int np, const int* __restrict__ tile, const int* __
 // particles of one node is the arrival order), position = layer offset + number of earlier nodes that reach the layer.
 // EXACT (deterministic mode): rank inside the node = number of the node's particles with a smaller slot index, not
 // the arrival order of the LDS atomics: the list is then a function of the particle arrays alone.
+// order_in: the tile lists as binned (runs of memory-consecutive particles: what the memory-bound K5 wants);
+// order_out: the same lists in canonical order (what the LDS-atomic-bound K2 and K3 want); may alias order_in.
 template <int ND, bool EXACT = false>
-__global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, int* __restrict__ order) {
+__global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, const int* order_in, int* order) {
   constexpr int TB = TileCfg<ND>::TB, NN = (ND == 3) ? TB * TB * TB : TB * TB;
-  constexpr int CAP = 4096, LMAX = 32;  // larger tiles / deeper nodes keep the order of the binning
+  constexpr int CAP = EXACT ? 4096 : 1536, LMAX = 32;  // larger tiles / deeper nodes keep the order of the binning
   __shared__ int cnt[NN];
   __shared__ unsigned short tbl[LMAX][NN];
   __shared__ int lsize[LMAX + 1];
@@ -302,15 +305,19 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
   if (wb >= td.range[1]) return;
   const int tile = td.work[0][wb].x;
   const int n = td.count[tile];
-  if (n > CAP || n <= 1) return;
   const int start = td.start[tile];
+  if (n > CAP || n <= 1) {  // keeps the order of the binning
+    if (order_in != order)
+      for (int s = threadIdx.x; s < n; s += 256) order[start + s] = order_in[start + s];
+    return;
+  }
   for (int q = threadIdx.x; q < NN; q += 256) cnt[q] = 0;
   if (threadIdx.x == 0) maxc = 0;
   __syncthreads();
   int w0[3];
   tile_origin<ND>(td, tile, w0);  // window origin = tile origin - 2
   for (int s = threadIdx.x; s < n; s += 256) {
-    const int p = order[start + s];
+    const int p = order_in[start + s];
     const int I0 = P.I0[p];
     const int bx = I0 % g.n[0] - (w0[0] + 2), by = (I0 / g.n[0]) % g.n[1] - (w0[1] + 2);
     const int bz = (ND == 3) ? I0 / (g.n[0] * g.n[1]) - (w0[2] + 2) : 0;
@@ -332,7 +339,11 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
   for (int q = threadIdx.x; q < NN; q += 256) atomicMax(&maxc, cnt[q]);
   __syncthreads();
   const int nl = maxc;
-  if (nl > LMAX) return;  // uniform: every thread reads the same maxc
+  if (nl > LMAX) {  // uniform: every thread reads the same maxc
+    if (order_in != order)
+      for (int s = threadIdx.x; s < n; s += 256) order[start + s] = pp[s];
+    return;
+  }
   // tbl[r][node] = number of earlier nodes that reach layer r; lsize[r] = nodes in layer r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = wave; r < nl; r += 4) {
@@ -1203,7 +1214,7 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
   const double2* a2 = reinterpret_cast<const double2*>(axy);
   const int start = td.start[tile];
   for (int s = part * K5_BLK + threadIdx.x; s < cnt; s += K5_BLK * K5_SPLIT) {
-    const int p = td.order[start + s];
+    const int p = td.order_m[start + s];
     Lme<ND> c;
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
@@ -1305,7 +1316,7 @@ __global__ __launch_bounds__(BLK) void kb_p2g_tile(PView P, GridD g, TileD td, d
   __syncthreads();
   const int start = td.start[tile];
   for (int s = threadIdx.x; s < cnt; s += BLK) {
-    const int p = td.order[start + s];
+    const int p = td.order_m[start + s];
     Lme<ND> c;
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
@@ -1371,7 +1382,7 @@ __global__ __launch_bounds__(BLK) void kb_fint_tile(PView P, GridD g, TileD td, 
   __syncthreads();
   const int start = td.start[tile];
   for (int s = threadIdx.x; s < cnt; s += BLK) {
-    const int p = td.order[start + s];
+    const int p = td.order_m[start + s];
     Lme<ND> c;
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
@@ -1455,7 +1466,7 @@ __global__ __launch_bounds__(BLK) void kb_kinetics_tile(PView P, GridD g, TileD 
   const double2* win2 = reinterpret_cast<const double2*>(win);
   const int start = td.start[tile];
   for (int s = threadIdx.x; s < cnt; s += BLK) {
-    const int p = td.order[start + s];
+    const int p = td.order_m[start + s];
     Lme<ND> c;
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
