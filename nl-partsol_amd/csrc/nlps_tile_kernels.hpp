@@ -566,26 +566,31 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
     }
     if (NumIter >= prm.max_iter_lme) st |= ST_NEWTON;
     PH(2)
-    P.nn[p] = nn;
-    P.mlo[p] = mlo;
-    P.mhi[p] = mhi;
-    PF(P, F_BETA, p) = beta;
+    // The accesses below use their own copy of the particle index, opaque to the optimiser: it otherwise forms the
+    // 64-bit addresses of all these components at the top of the loop and carries them (two VGPRs each) through the
+    // mask build and the Newton iteration -- the 11 doubles K2 used to spill
+    int pl = p;
+    asm volatile("" : "+v"(pl));
+    P.nn[pl] = nn;
+    P.mlo[pl] = mlo;
+    P.mhi[pl] = mhi;
+    PF(P, F_BETA, pl) = beta;
 #pragma unroll
-    for (int a = 0; a < ND; a++) PF(P, F_LAM + a, p) = lam[a];
+    for (int a = 0; a < ND; a++) PF(P, F_LAM + a, pl) = lam[a];
     if (st) {
-      atomicOr(&P.status[p], st);
+      atomicOr(&P.status[pl], st);
       atomicOr(gstatus, st);
     }
     if (!P2G) continue;  // local_search__LME__ alone stops here (LME.c:895-1015)
     double dd[ND];
 #pragma unroll
     for (int a = 0; a < ND; a++) {
-      double v = PF(P, F_VEL + a, p), ac = PF(P, F_ACC + a, p);
+      double v = PF(P, F_VEL + a, pl), ac = PF(P, F_ACC + a, pl);
       dd[a] = dt * v + 0.5 * dsqr(dt) * ac;
-      PF(P, F_DDIS + a, p) = dd[a];
-      PF(P, F_VEL + a, p) = v + (1 - gamma_nm) * dt * ac;
+      PF(P, F_DDIS + a, pl) = dd[a];
+      PF(P, F_VEL + a, pl) = v + (1 - gamma_nm) * dt * ac;
     }
-    const double mz = PF(P, F_MASS, p) * Zinv;
+    const double mz = PF(P, F_MASS, pl) * Zinv;
     NLPS_YZ_LOCALS(c);
 #pragma unroll NLPS_KUNROLL_K2S
     for (int k = 0; k < KN; k++) {
@@ -978,6 +983,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
       }
     }
     PH(10)
+    // from here on the particle index is a copy the optimiser cannot see through: the 64-bit addresses of the ~40
+    // components read and written below would otherwise be formed at the top of the loop and carried through the gather
+    int pl = p;
+    asm volatile("" : "+v"(pl));
     const double Zinv = 1.0 / Z;
     // index moments -> moments of l = a - h u (a = l of the centre node): J = h^2 (<u u> - <u><u>), the a-terms cancel;
     // G[a][m] = sum e dU_a l_m = a_m sum e dU_a - h sum e dU_a u_m
@@ -1022,7 +1031,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
         for (int m = 0; m < ND; m++) v = fma(G[i * ND + m] * Zinv, Jm1[j * ND + m], v);
         DF[i * ND + j] = ((i == j) ? 1.0 : 0.0) - v;
       }
-    load_block<ND>(P, fFN(P), p, Fn, fzz);
+    load_block<ND>(P, fFN(P), pl, Fn, fzz);
 #pragma unroll
     for (int i = 0; i < ND; i++)
 #pragma unroll
@@ -1037,9 +1046,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
       st |= ST_JACOBIAN;  // fatal in the explicit scheme (U-Verlet.c:608-613), clamped in the implicit one
       if (MODE != 1) Jn1 = 0.0;
     }
-    store_block<ND>(P, F_DF, p, DF, 0.0, false);
-    store_block<ND>(P, fFN1(P), p, Fn1, 0.0, false);
-    PF(P, F_JN1, p) = Jn1;
+    store_block<ND>(P, F_DF, pl, DF, 0.0, false);
+    store_block<ND>(P, fFN1(P), pl, Fn1, 0.0, false);
+    PF(P, F_JN1, pl) = Jn1;
     if (RATES) {
       double dDF[ND * ND], dFn[ND * ND], dFn1[ND * ND], zz;
 #pragma unroll
@@ -1051,7 +1060,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
           for (int m = 0; m < ND; m++) v = fma(Gv[(i * ND + m) % (RATES ? ND * ND : 1)] * Zinv, Jm1[j * ND + m], v);
           dDF[i * ND + j] = -v;
         }
-      load_block<ND>(P, F_DTFN, p, dFn, zz);
+      load_block<ND>(P, F_DTFN, pl, dFn, zz);
 #pragma unroll
       for (int i = 0; i < ND; i++)
 #pragma unroll
@@ -1061,22 +1070,22 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
           for (int k2 = 0; k2 < ND; k2++) a2 += dDF[i * ND + k2] * Fn[k2 * ND + j] + DF[i * ND + k2] * dFn[k2 * ND + j];
           dFn1[i * ND + j] = a2;
         }
-      store_block<ND>(P, F_DTDF, p, dDF, 0.0, false);
-      store_block<ND>(P, F_DTFN1, p, dFn1, 0.0, false);
+      store_block<ND>(P, F_DTDF, pl, dDF, 0.0, false);
+      store_block<ND>(P, F_DTFN1, pl, dFn1, 0.0, false);
     }
     if (MODE != 1) {
       if (st) {
-        atomicOr(&P.status[p], st);
+        atomicOr(&P.status[pl], st);
         atomicOr(gstatus, st);
       }
       continue;
     }
-    PF(P, F_RHO, p) = PF(P, F_RHO, p) / det<ND>(DF);  // U-Verlet.c:630-632
+    PF(P, F_RHO, pl) = PF(P, F_RHO, pl) / det<ND>(DF);  // U-Verlet.c:630-632
 #pragma unroll
-    for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, p) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
+    for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, pl) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
     double tau[ND * ND], B[ND * ND];
-    st |= stress_update<ND, LAW>(P, p, mats, prm, Fn1, DF, Jn1, tau);
-    const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, p), -1.0);
+    st |= stress_update<ND, LAW>(P, pl, mats, prm, Fn1, DF, Jn1, tau);
+    const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), -1.0);
     PH(11)
     if (fo_ok) {
       // pass 2: -f_A = p_A * (B l_A) with l = a - h u:  B l = B a - h (B[.][x] u_i + B[.][y] v_j + B[.][z] w_k)
