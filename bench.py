@@ -311,10 +311,20 @@ def main():
             if rank == 0:
                 uid = torch.tensor(list(nlps.Solver.rccl_unique_id()), dtype=torch.uint8, device="cuda")
             dist.broadcast(uid, 0)
-            S.rccl_attach(bytes(uid.cpu().tolist()), rank, world, lo, hi, mode=1 if a.halo == "allreduce" else 0)
-            if a.overlap == 0:
-                S.set_ghost_bands(*halo.ghost_bands(rank), False)
-        else:
+            ok = 1
+            try:
+                S.rccl_attach(bytes(uid.cpu().tolist()), rank, world, lo, hi, mode=1 if a.halo == "allreduce" else 0)
+                if a.overlap == 0:
+                    S.set_ghost_bands(*halo.ghost_bands(rank), False)
+            except Exception as e:  # e.g. librccl.so.1 not loadable on some rank
+                print("rank %d: nlps_gpu_rccl_attach failed (%r)" % (rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:  # all ranks fall back together to the callback through torch.distributed
+                S.rccl_detach()
+                halo_impl = "torch"
+        if halo_impl == "torch":
             def exchange(dptr, nfield, elem, kind, phase):
                 return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind, phase)
 
