@@ -42,7 +42,9 @@ enum {
   NLPS_MAT_NEO_HOOKEAN = 0,   /* "Neo-Hookean-Wriggers", Hyperelastic/Neo-Hookean.c:38-85 */
   NLPS_MAT_HENCKY = 1,        /* "Hencky",               Hyperelastic/Hencky.c:40-94       */
   NLPS_MAT_DRUCKER_PRAGER = 2, /* "Drucker-Prager",      Plasticity/Drucker-Prager.c:319-613 */
-  NLPS_MAT_VON_MISES = 3       /* "Von-Mises",           Plasticity/Von-Mises.c:212-392 */
+  NLPS_MAT_VON_MISES = 3,      /* "Von-Mises",           Plasticity/Von-Mises.c:212-392 */
+  NLPS_MAT_MATSUOKA_NAKAI = 4, /* "Matsuoka-Nakai",      Plasticity/Matsuoka-Nakai.c:300-700 */
+  NLPS_MAT_LADE_DUNCAN = 5     /* "Lade-Duncan",         Plasticity/Lade-Duncan.c:290-692 */
 };
 
 /* Structured background grid (GramsBox mesh, InOutFun/Read_GramsBox.c:54): Q4 / H8 lattice, nodes
@@ -77,6 +79,11 @@ typedef struct {
   /* Von-Mises (Von-Mises.c:246-253): sigma_y = kappa_0, Hardening_modulus, theta / K_0 / K_inf / delta _Hardening_Voce */
   double hardening_modulus, theta_voce, K0_voce, Kinf_voce, delta_voce;
   double Ceps, Gf; /* eigenerosion (Constitutive/Fracture/EigenErosion.c:63-64): normalising constant, Griffith energy */
+  /* Matsuoka-Nakai / Lade-Duncan (Matsuoka-Nakai.c:330-341): Cohesion, alpha_Hardening_Borja, a_Hardening_Borja[3];
+   * they also read phi_deg; Kappa_n starts at kappa_0 and EPS_n of Matsuoka-Nakai at eps_0 (caller's arrays,
+   * Generate-One-Phase-Analysis.c:620-626).  Their readers set TOL_Radial_Returning / Max_Iterations_Radial_Returning
+   * to 1e-10 / 20 (Matsuoka-Nakai) and 1e-14 / 10 (Lade-Duncan): nlps_params carries them */
+  double cohesion, alpha_borja, a_borja[3];
 } nlps_material;
 
 /* Particle fields, Types.h:184-283 / 548-623: HOST pointers to the reference's row-major arrays

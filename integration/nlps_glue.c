@@ -33,6 +33,8 @@ static int nlps_glue_law(const Material *M) {
   if (strcmp(M->Type, "Hencky") == 0) return NLPS_MAT_HENCKY;
   if (strcmp(M->Type, "Drucker-Prager") == 0) return NLPS_MAT_DRUCKER_PRAGER;
   if (strcmp(M->Type, "Von-Mises") == 0) return NLPS_MAT_VON_MISES;
+  if (strcmp(M->Type, "Matsuoka-Nakai") == 0) return NLPS_MAT_MATSUOKA_NAKAI;
+  if (strcmp(M->Type, "Lade-Duncan") == 0) return NLPS_MAT_LADE_DUNCAN;
   return -1;
 }
 
@@ -161,6 +163,9 @@ int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Pa
     mats[m].delta_voce = M->delta_Hardening_Voce;
     mats[m].Ceps = M->Ceps;
     mats[m].Gf = M->Gf;
+    mats[m].cohesion = M->Cohesion;
+    mats[m].alpha_borja = M->alpha_Hardening_Borja;
+    for (int k = 0; k < 3; k++) mats[m].a_borja[k] = M->a_Hardening_Borja[k];
   }
   nlps_particles p = nlps_glue_particles(MPM_Mesh);
   /* closest nodes in lattice numbering */

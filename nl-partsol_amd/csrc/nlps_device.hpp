@@ -39,7 +39,11 @@ struct MatD {
   double kappa_0, exp_param, eps_0, p_ref;
   double H, theta, K_0, K_inf, delta;  // Von-Mises.c:246-253 (sigma_y = kappa_0)
   double Ceps, Gf;                     // eigenerosion (EigenErosion.c:63-64)
+  // Matsuoka-Nakai (surface 0) / Lade-Duncan (surface 1): type = NLPS_KLAW_FRICTIONAL for both
+  int surface;
+  double c_cotphi, alpha_b, a_b[3];
 };
+#define NLPS_KLAW_FRICTIONAL 4
 
 struct ParamsD {
   double gamma_lme, neg_log_tol_zero, tol_wrapper;
@@ -323,6 +327,7 @@ struct StressIO {
   double cep[N * N];  // elastoplastic tangent moduli in principal space (Drucker-Prager.c:1088-1198)
   double back[3];     // principal back stress (Von-Mises), in/out
   int fail;
+  bool cep_keep;      // Matsuoka-Nakai / Lade-Duncan in 3-D after a plastic step: the stored C_ep is left alone
 };
 
 template <int N>
@@ -640,6 +645,360 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
   double ev[3] = {exp(2 * Etr[0]), exp(2 * Etr[1]), exp(2 * Etr[2])};
   ppal_to_xyz<N>(o.be, ev, v);
   o.be_zz = ev[2];
+  if (isnan(w[0]) || isnan(w[1]) || isnan(w[2])) o.fail = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Matsuoka-Nakai / Lade-Duncan: the monolithic three-invariant return mapping with line search of
+// Matsuoka-Nakai.c:300-700 and Lade-Duncan.c:290-692.  One routine for both: the files differ in the surfaces
+// (Matsuoka-Nakai.c:961-1053 | Lade-Duncan.c:959-1035) and in which of E_trial / E_k1 the plastic branch overwrites
+// (:432-434 | Lade-Duncan.c:430-432).  Kept as written upstream: the residual added to the diagonal of the 5 x 5 tangent
+// (:505-510), the line search along the NEW residual (:583-587), b_e = 1 after an elastic step (E_hencky_k1 stays zero,
+// :410-424 and :694), C_ep stored in 2-D only after a plastic step (:1285-1290).  Eigenvectors by column everywhere.
+// ------------------------------------------------------------------------------------------------
+struct FricInv {
+  double I1, I2, I3;
+  bool ld;
+  __device__ __forceinline__ void set(const double* T) {
+    I1 = T[0] + T[1] + T[2];
+    I2 = T[0] * T[1] + T[1] * T[2] + T[0] * T[2];
+    I3 = T[0] * T[1] * T[2];
+  }
+  __device__ __forceinline__ double K(double kap) const { return (ld ? 27.0 : 9.0) + kap; }
+  __device__ __forceinline__ double F(double kappa_phi) const {
+    return ld ? cbrt(K(kappa_phi) * I3) - I1 : cbrt(K(kappa_phi) * I3) - cbrt(I1 * I2);
+  }
+  __device__ __forceinline__ double grad_g(const double* T, int A) const {
+    const double c = cbrt(I1 * I2);
+    return (I1 * (I1 - T[A]) + I2) / (3.0 * (c * c));
+  }
+  __device__ __forceinline__ void dsurf(double* d, const double* T, double kap) const {
+    const double c = cbrt(K(kap) * I3);
+#pragma unroll
+    for (int A = 0; A < 3; A++) d[A] = c / (3.0 * T[A]) - (ld ? 1.0 : grad_g(T, A));
+  }
+  __device__ __forceinline__ double dF_dkappa(double kappa_phi) const {
+    const double c = cbrt(K(kappa_phi));
+    return (1.0 / 3.0) * (1.0 / (c * c)) * cbrt(I3);
+  }
+  __device__ __forceinline__ void ddG(double* dd, const double* T, double kappa_psi) const {
+    const double c = cbrt(K(kappa_psi) * I3), q = cbrt(I1 * I2);
+    double g[3] = {0, 0, 0};
+    if (!ld) {
+#pragma unroll
+      for (int A = 0; A < 3; A++) g[A] = grad_g(T, A);
+    }
+#pragma unroll
+    for (int A = 0; A < 3; A++)
+#pragma unroll
+      for (int B = 0; B < 3; B++) {
+        const double dAB = (A == B) ? 1.0 : 0.0;
+        double v = (1.0 / 3.0) * c * (1.0 / (3.0 * T[A] * T[B]) - 1.0 * dAB / (T[A] * T[A]));
+        if (!ld) v -= (1.0 / (q * q)) / 3.0 * (3.0 * I1 - T[A] - T[B] - I1 * dAB) - (2.0 / q) * g[A] * g[B];
+        dd[A * 3 + B] = v;
+      }
+  }
+  __device__ __forceinline__ void ddG_dkappa(double* d, const double* T, double kappa_psi) const {
+    const double c3 = cbrt(I3), ck = cbrt(9.0 + kappa_psi);
+#pragma unroll
+    for (int A = 0; A < 3; A++) {
+      d[A] = c3 / (3.0 * T[A]);
+      if (!ld) d[A] = d[A] / (3.0 * (ck * ck));
+    }
+  }
+};
+
+// A x = b in place (row-major 5 x 5), partial pivoting on the first maximum like dgetrf; all indices static
+__device__ __forceinline__ bool lu_solve5(double (&A)[25], double (&b)[5]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    int piv = k;
+    double big = fabs(A[k * 5 + k]);
+#pragma unroll
+    for (int r = k + 1; r < 5; r++) {
+      const double v = fabs(A[r * 5 + k]);
+      if (v > big) {
+        big = v;
+        piv = r;
+      }
+    }
+#pragma unroll
+    for (int r = k + 1; r < 5; r++) {
+      if (piv == r) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+          const double t = A[k * 5 + c];
+          A[k * 5 + c] = A[r * 5 + c];
+          A[r * 5 + c] = t;
+        }
+        const double t = b[k];
+        b[k] = b[r];
+        b[r] = t;
+      }
+    }
+    if (A[k * 5 + k] == 0.0) ok = false;
+#pragma unroll
+    for (int r = k + 1; r < 5; r++) {
+      const double f = A[r * 5 + k] / A[k * 5 + k];
+#pragma unroll
+      for (int c = k + 1; c < 5; c++) A[r * 5 + c] -= f * A[k * 5 + c];
+      b[r] -= f * b[k];
+    }
+  }
+#pragma unroll
+  for (int k = 4; k >= 0; k--) {
+    double t = b[k];
+#pragma unroll
+    for (int c = k + 1; c < 5; c++) t -= A[k * 5 + c] * b[c];
+    b[k] = t / A[k * 5 + k];
+  }
+  return ok;
+}
+
+// in place inverse of a 3 x 3 with partial pivoting (dgetrf_ + dgetri_, Matsuoka-Nakai.c:1241-1283)
+__device__ __forceinline__ bool inverse3_pivot(double (&A)[9]) {
+  double M[3][6];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      M[i][j] = A[i * 3 + j];
+      M[i][3 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int piv = k;
+    {  // first maximum of column k among rows k..2 (static indices only)
+      double big = fabs(M[k][k]);
+#pragma unroll
+      for (int r = k + 1; r < 3; r++) {
+        const double v = fabs(M[r][k]);
+        if (v > big) {
+          big = v;
+          piv = r;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = k + 1; r < 3; r++)
+      if (piv == r) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const double t = M[k][c];
+          M[k][c] = M[r][c];
+          M[r][c] = t;
+        }
+      }
+    if (M[k][k] == 0.0) ok = false;
+    const double d = M[k][k];
+#pragma unroll
+    for (int c = 0; c < 6; c++) M[k][c] /= d;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (r == k) continue;
+      const double f = M[r][k];
+#pragma unroll
+      for (int c = 0; c < 6; c++) M[r][c] -= f * M[k][c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) A[i * 3 + j] = M[i][3 + j];
+  return ok;
+}
+
+template <int N>
+__device__ __forceinline__ void law_frictional(const MatD& m, const ParamsD& prm, const double* d_phi, const double* b_e_n,
+                                            double b_e_n_zz, double kappa_in, double eps_in, StressIO<N>& o) {
+  double btr[N * N], v[N * N], w[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; k++)
+#pragma unroll
+        for (int l = 0; l < N; l++) s += d_phi[i * N + k] * b_e_n[k * N + l] * d_phi[j * N + l];
+      btr[i * N + j] = s;
+    }
+  sym_eigen<N>(w, v, btr);
+  if (N == 2) w[2] = b_e_n_zz;
+  double E_tr[3] = {0.5 * log(w[0]), 0.5 * log(w[1]), 0.5 * log(w[2])};
+  double E_k1[3] = {0, 0, 0}, E_k2[3] = {0, 0, 0};
+  FricInv s;
+  s.ld = m.surface != 0;
+  const double E = m.E, nu = m.nu, c_cotphi = m.c_cotphi, alpha = m.alpha_b;
+  const double a0 = m.a_b[0], a1 = m.a_b[1], a2 = m.a_b[2];
+  const double cd = 1.0 / E, co = -nu / E;                   // compliance CC (:799-810)
+  const double sd = m.lame + 2 * m.G, so = m.lame;           // stiffness AA (:812-822)
+#define NLPS_FRIC_E(Eo, Tk)                                                                        \
+  {                                                                                                \
+    const double t0_ = (Tk)[0] + c_cotphi, t1_ = (Tk)[1] + c_cotphi, t2_ = (Tk)[2] + c_cotphi;     \
+    (Eo)[0] = cd * t0_ + co * t1_ + co * t2_;                                                      \
+    (Eo)[1] = co * t0_ + cd * t1_ + co * t2_;                                                      \
+    (Eo)[2] = co * t0_ + co * t1_ + cd * t2_;                                                      \
+  }
+#define NLPS_FRIC_KHAT(Lam) (a0 * (Lam)*exp(a1 * s.I1) * exp(-a2 * (Lam)))
+#define NLPS_FRIC_RES(R, Ek, kph, khat, Fk, dl)                          \
+  ((R)[0] = (Ek)[0] - E_tr[0] + (dl)*dG[0], (R)[1] = (Ek)[1] - E_tr[1] + (dl)*dG[1], \
+   (R)[2] = (Ek)[2] - E_tr[2] + (dl)*dG[2], (R)[3] = (kph) - (khat), (R)[4] = (Fk),  \
+   sqrt((R)[0] * (R)[0] + (R)[1] * (R)[1] + (R)[2] * (R)[2] + (R)[3] * (R)[3] + (R)[4] * (R)[4]))
+#define NLPS_FRIC_APEX(Tk) (fabs(((Tk)[0] + (Tk)[1] + (Tk)[2]) / 3.0) < 0.1)
+  const double Lambda_n = eps_in, kappa_n0 = kappa_in, kappa_n1 = alpha * kappa_in;
+  const double TOL = prm.tol_radial;
+  const int MaxIter_k1 = prm.max_iter_radial, MaxIter_k2 = 10 * prm.max_iter_radial;
+  double T_tr[3], T_k1[3], T_k2[3] = {0, 0, 0};
+  o.kappa = kappa_in;
+  o.eps = eps_in;
+  o.cep_keep = false;
+  T_tr[0] = sd * E_tr[0] + so * E_tr[1] + so * E_tr[2] - c_cotphi;
+  T_tr[1] = so * E_tr[0] + sd * E_tr[1] + so * E_tr[2] - c_cotphi;
+  T_tr[2] = so * E_tr[0] + so * E_tr[1] + sd * E_tr[2] - c_cotphi;
+  s.set(T_tr);
+  const double F_0 = s.F(kappa_n0);
+#pragma unroll
+  for (int r = 0; r < 3; r++) T_k1[r] = T_tr[r];
+  if (F_0 <= NLPS_TOL_NR) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int j = 0; j < N; j++) o.cep[i * N + j] = (i == j) ? sd : so;
+  } else {
+    double dG[3], ddG[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, R1[5], R2[5] = {0, 0, 0, 0, 0};
+    double kappa_k1 = kappa_n0, kappa_k2 = 0.0, F_k1 = F_0, F_k2 = 0.0, dl1 = 0.0, dl2 = 0.0;
+    double Lambda_k1 = Lambda_n, Lambda_k2 = 0.0, N1, N2 = 0.0, delta;
+    NLPS_FRIC_E(E_k1, T_k1);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (s.ld) E_k1[r] = E_tr[r];
+      else E_tr[r] = E_k1[r];
+    }
+    double kappa_hat = NLPS_FRIC_KHAT(Lambda_n);
+    s.dsurf(dG, T_tr, kappa_n1);
+    const double N0 = NLPS_FRIC_RES(R1, E_k1, kappa_n0, kappa_hat, F_0, 0.0);
+    N1 = N0;
+    int Iter_k1 = 0;
+#pragma unroll 1
+    while ((fabs(N1 / N0) >= TOL) && (fabs(F_k1 / F_0) >= TOL)) {
+      delta = 1.0;
+      const double dkappa_ds = a0 * a1 * Lambda_k1 * exp(a1 * s.I1) * exp(-a2 * Lambda_k1);
+      const double dkappa_dl = (1 - a2 * Lambda_k1) * a0 * exp(a1 * s.I1) * exp(-a2 * Lambda_k1);
+      double dF[3], ddG_dk[3], TM[25];
+      s.dsurf(dF, T_k1, kappa_k1);
+      const double dF_dk = s.dF_dkappa(kappa_k1);
+      s.ddG(ddG, T_k1, alpha * kappa_k1);
+      s.ddG_dkappa(ddG_dk, T_k1, alpha * kappa_k1);
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) TM[r * 5 + c] = ((r == c) ? cd : co) + dl1 * ddG[r * 3 + c];
+        TM[r * 5 + 3] = alpha * dl1 * ddG_dk[r];
+        TM[r * 5 + 4] = dG[r];
+        TM[15 + r] = -dkappa_ds;
+        TM[20 + r] = dF[r];
+      }
+      TM[18] = 1.0;
+      TM[19] = -dkappa_dl;
+      TM[23] = dF_dk;
+      TM[24] = 0.0;
+#pragma unroll
+      for (int r = 0; r < 5; r++) TM[r * 5 + r] += R1[r];
+      if (!lu_solve5(TM, R1)) {
+        o.fail = 1;
+        break;
+      }
+      dl2 = dl1 - delta * R1[4];
+      if (Lambda_n + dl2 < 0.0) break;
+      Lambda_k2 = Lambda_n + dl2;
+#pragma unroll
+      for (int r = 0; r < 3; r++) T_k2[r] = T_k1[r] - delta * R1[r];
+      kappa_k2 = kappa_k1 - delta * R1[3];
+      if (NLPS_FRIC_APEX(T_k2)) break;
+      int Iter_k2 = 0;
+#define NLPS_FRIC_EVAL_K2()                                              \
+  {                                                                      \
+    s.set(T_k2);                                                         \
+    NLPS_FRIC_E(E_k2, T_k2);                                             \
+    kappa_hat = NLPS_FRIC_KHAT(Lambda_k2);                               \
+    s.dsurf(dG, T_k2, alpha * kappa_k2);                                 \
+    F_k2 = s.F(kappa_k2);                                                \
+    N2 = NLPS_FRIC_RES(R2, E_k2, kappa_k2, kappa_hat, F_k2, dl2);        \
+  }
+      NLPS_FRIC_EVAL_K2();
+#pragma unroll 1
+      while ((fabs(N2 - N1) > TOL) && (fabs(F_k2 / F_0) >= TOL)) {
+        delta = (delta * delta) * 0.5 * N1 / (N2 - delta * N1 + N1);
+        if ((delta > 1.0) || (delta < 0.0)) break;
+        dl2 = dl1 - delta * R2[4];
+        if (Lambda_n + dl2 < 0.0) break;
+        Lambda_k2 = Lambda_n + dl2;
+#pragma unroll
+        for (int r = 0; r < 3; r++) T_k2[r] = T_k1[r] - delta * R2[r];
+        kappa_k2 = kappa_k1 - delta * R2[3];
+        if (NLPS_FRIC_APEX(T_k2)) {
+          Lambda_k2 = Lambda_n;
+          kappa_k2 = kappa_n0;
+          T_k2[0] = T_k2[1] = T_k2[2] = 0.0;
+          break;
+        }
+        NLPS_FRIC_EVAL_K2();
+        Iter_k2++;
+        if (Iter_k2 == MaxIter_k2) break;
+      }
+#undef NLPS_FRIC_EVAL_K2
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        T_k1[r] = T_k2[r];
+        E_k1[r] = E_k2[r];
+      }
+      kappa_k1 = kappa_k2;
+      Lambda_k1 = Lambda_k2;
+      F_k1 = F_k2;
+      dl1 = dl2;
+#pragma unroll
+      for (int r = 0; r < 5; r++) R1[r] = R2[r];
+      N1 = N2;
+      Iter_k1++;
+      if (NLPS_FRIC_APEX(T_k1)) {
+        Lambda_k1 = Lambda_n;
+        kappa_k1 = kappa_n0;
+        T_k1[0] = T_k1[1] = T_k1[2] = 0.0;
+        break;
+      }
+      if (Iter_k1 == MaxIter_k1) break;
+    }
+    o.eps = Lambda_k1;
+    o.kappa = kappa_k1;
+    {
+      double aux[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) aux[q] = ((q % 4 == 0) ? cd : co) + dl1 * ddG[q];
+      if (!inverse3_pivot(aux)) o.fail = 1;
+      if (N == 2) {
+        o.cep[0] = aux[0];
+        o.cep[1] = aux[1];
+        o.cep[2 % (N * N)] = aux[3];
+        o.cep[3 % (N * N)] = aux[4];
+      } else {
+        o.cep_keep = true;
+      }
+    }
+  }
+#undef NLPS_FRIC_E
+#undef NLPS_FRIC_KHAT
+#undef NLPS_FRIC_RES
+#undef NLPS_FRIC_APEX
+  const double Tp[3] = {T_k1[0] + c_cotphi, T_k1[1] + c_cotphi, T_k1[2] + c_cotphi};
+  ppal_to_xyz<N>(o.tau, Tp, v);
+  o.tau_zz = Tp[2];
+  const double lam[3] = {exp(2 * E_k1[0]), exp(2 * E_k1[1]), exp(2 * E_k1[2])};
+  ppal_to_xyz<N>(o.be, lam, v);
+  o.be_zz = lam[2];
+  o.W = 0.5 * (Tp[0] * E_tr[0] + Tp[1] * E_tr[1] + Tp[2] * E_tr[2]);
   if (isnan(w[0]) || isnan(w[1]) || isnan(w[2])) o.fail = 1;
 }
 

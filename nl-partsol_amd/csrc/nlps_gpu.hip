@@ -375,7 +375,11 @@ __device__ __forceinline__ void store_block(const PView& P, int f0, int p, const
 // LAW = -1: dispatch on the particle's material at run time (mixed clouds); LAW = 0/1/2: the whole
 // cloud uses that one law, so only its code (and register footprint) is compiled into the kernel.
 // CEP: also keep the Drucker-Prager tangent moduli (only the implicit driver's Jacobian reads them).
-template <int ND, int LAW = -1, bool CEP = false>
+// FRIC: the Matsuoka-Nakai / Lade-Duncan code is compiled in (its 5 x 5 Newton system would otherwise set the register
+// budget of every other law).  A kernel without it is never launched on a cloud that holds the law: the level-B
+// stress kernel exists in both forms, the fused step runs one launch per law for such a cloud (nlps_gpu_create forces
+// k3_per_law, nlps_gpu_set_law_launch_mode refuses the dispatch kernel).
+template <int ND, int LAW = -1, bool CEP = false, bool FRIC = (LAW == NLPS_KLAW_FRICTIONAL)>
 __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* __restrict__ mats, const ParamsD& prm,
                                              const double* Fn1, const double* DF, double J, double* tau) {
   MatD m = mats[P.mat[p]];
@@ -383,6 +387,7 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
   o.fail = 0;
   o.kappa = 0.0;
   o.eps = 0.0;
+  o.cep_keep = false;
   const int law = (LAW >= 0) ? LAW : m.type;
   if (law == NLPS_MAT_NEO_HOOKEAN) {
     law_neo_hookean<ND>(m, Fn1, J, o);
@@ -398,13 +403,15 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
       law_von_mises<ND>(m, prm, DF, be, bzz, PF(P, F_EN, p), o);
 #pragma unroll
       for (int a = 0; a < 3; a++) PF(P, F_BACK + a, p) = o.back[a];  // in place, like upstream (Constitutive.c:116)
+    } else if (FRIC && law == NLPS_KLAW_FRICTIONAL) {
+      law_frictional<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
     } else {
       law_drucker_prager<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
     }
     store_block<ND>(P, fBEN1(P), p, o.be, o.be_zz, true);
     PF(P, F_KN1, p) = o.kappa;
     PF(P, F_EN1, p) = o.eps;
-    if (CEP) {
+    if (CEP && !(FRIC && o.cep_keep)) {
 #pragma unroll
       for (int q = 0; q < ND * ND; q++) PF(P, F_CEP + q, p) = o.cep[q];
     }
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(BLK) void k_damage(PView P, GridD g, const MatD* __
 }
 
 // __constitutive_update (U-Newmark-beta.c:1208-1242)
-template <int ND>
+template <int ND, bool FRIC>
 __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict__ mats, ParamsD prm,
                                                 int* __restrict__ gstatus) {
   int p = blockIdx.x * BLK + threadIdx.x;
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict_
   double Fn1[ND * ND], DF[ND * ND], tau[ND * ND], z;
   load_block<ND>(P, fFN1(P), p, Fn1, z);
   load_block<ND>(P, F_DF, p, DF, z);
-  int st = stress_update<ND, -1, true>(P, p, mats, prm, Fn1, DF, PF(P, F_JN1, p), tau);
+  int st = stress_update<ND, -1, true, FRIC>(P, p, mats, prm, Fn1, DF, PF(P, F_JN1, p), tau);
   if (st) {
     atomicOr(&P.status[p], st);
     atomicOr(gstatus, st);
@@ -1021,8 +1028,16 @@ static MatD make_mat(const nlps_material& m, int nd) {
   d.delta = m.delta_voce;
   d.Ceps = m.Ceps;
   d.Gf = m.Gf;
+  if (m.type == NLPS_MAT_MATSUOKA_NAKAI || m.type == NLPS_MAT_LADE_DUNCAN) {  // one kernel law, two surfaces
+    d.type = NLPS_KLAW_FRICTIONAL;
+    d.surface = m.type == NLPS_MAT_LADE_DUNCAN;
+    d.c_cotphi = rf > 0.0 ? m.cohesion / tan(rf) : 0.0;  // Matsuoka-Nakai.c:334-336
+    d.alpha_b = m.alpha_borja;
+    for (int i = 0; i < 3; i++) d.a_b[i] = m.a_borja[i];
+  }
   return d;
 }
+static inline int klaw_of(int type) { return type >= NLPS_KLAW_FRICTIONAL ? NLPS_KLAW_FRICTIONAL : type; }
 
 // h_avg exactly as compute_nodal_distance_local does it (Read_GramsBox.c:460-507): chain order sum
 static void host_h_avg(const nlps_grid& G, const nlps_host::StencilTables& tab, std::vector<double>& out) {
@@ -1304,15 +1319,15 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   }
   // materials
   h->nmats = nmats;
-  h->uniform_law = nmats > 0 ? mats[0].type : -1;
+  h->uniform_law = nmats > 0 ? klaw_of(mats[0].type) : -1;
   h->law_present = 0;
   for (int i = 0; i < nmats; i++) {
-    if (mats[i].type != mats[0].type) h->uniform_law = -1;
-    if (mats[i].type < 0 || mats[i].type > 3) {
-      h->err = "material type outside 0..3 (Neo-Hookean, Hencky, Drucker-Prager, Von-Mises)";
+    if (mats[i].type < 0 || mats[i].type > NLPS_MAT_LADE_DUNCAN) {
+      h->err = "material type outside 0..5 (Neo-Hookean, Hencky, Drucker-Prager, Von-Mises, Matsuoka-Nakai, Lade-Duncan)";
       return 1;
     }
-    h->law_present |= 1 << mats[i].type;
+    if (klaw_of(mats[i].type) != klaw_of(mats[0].type)) h->uniform_law = -1;
+    h->law_present |= 1 << klaw_of(mats[i].type);
   }
   {
     std::vector<MatD> md(nmats);
@@ -1367,7 +1382,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
       key[p] = (kt * mc + kc) * mn + kn;
       if (h->uniform_law < 0) {  // which laws meet in which tile (decides how K3 treats a cloud with several laws)
         unsigned char& m = tile_laws[(size_t)kt];
-        m |= (unsigned char)(1 << (mats[mi].type & 3));
+        m |= (unsigned char)(1 << klaw_of(mats[mi].type));
       }
     }
     if (h->uniform_law < 0) {
@@ -1381,6 +1396,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
       // interleaved particle by particle: every launch would touch every tile and every cache line (measured 0.68 ms
       // against 0.51 ms for the one kernel that dispatches on the law at run time), so that kernel stays for them.
       h->k3_per_law = used > 0 && 4 * mixed <= used;
+      if (h->law_present & (1 << NLPS_KLAW_FRICTIONAL)) h->k3_per_law = 1;  // not in the dispatch kernel (stress_update)
     }
     std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return key[a] < key[b]; });
     h->slab_lo = std::max(0, lo - 3);
@@ -1656,6 +1672,10 @@ extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_set_tile_or
 extern "C" int nlps_gpu_set_law_launch_mode(nlps_gpu* h, int mode) {
   if (mode != 1 && mode != 2) {
     h->err = "nlps_gpu_set_law_launch_mode: 1 = one launch per law, 2 = one kernel dispatching on the law";
+    return 1;
+  }
+  if (mode == 2 && (h->law_present & (1 << NLPS_KLAW_FRICTIONAL))) {
+    h->err = "nlps_gpu_set_law_launch_mode: the dispatch kernel does not hold Matsuoka-Nakai / Lade-Duncan";
     return 1;
   }
   h->k3_per_law = mode == 1;
@@ -2493,7 +2513,10 @@ extern "C" int nlps_gpu_compatibility(nlps_gpu* h, const double* dU, const doubl
 extern "C" int nlps_gpu_constitutive(nlps_gpu* h) {
   if (materialise_roll(h)) return 1;
   h->level_b_fields = true;
-  LAUNCH_ND((k_stress<2>), (k_stress<3>), nblk(h->P.np), h->P, h->mats_d, h->prm, h->gstatus_d);
+  if (h->law_present & (1 << NLPS_KLAW_FRICTIONAL))
+    LAUNCH_ND((k_stress<2, true>), (k_stress<3, true>), nblk(h->P.np), h->P, h->mats_d, h->prm, h->gstatus_d);
+  else
+    LAUNCH_ND((k_stress<2, false>), (k_stress<3, false>), nblk(h->P.np), h->P, h->mats_d, h->prm, h->gstatus_d);
   HIPCHK(hipGetLastError());
   return check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()");
 }
@@ -2745,19 +2768,21 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (det) {  // one wave per tile and per law present, particles in list order, one slab per (tile, law)
       td.slab_n = __builtin_popcount(h->law_present);
       td.slab_slot = -1;
-      for (int l = 0; l < 4; l++) {
+      for (int l = 0; l <= NLPS_KLAW_FRICTIONAL; l++) {
         if (!(h->law_present & (1 << l))) continue;
         td.slab_slot++;
         if (ND == 2) {
           if (l == 0) NLPS_K3D(2, 0);
           else if (l == 1) NLPS_K3D(2, 1);
           else if (l == 2) NLPS_K3D(2, 2);
-          else NLPS_K3D(2, 3);
+          else if (l == 3) NLPS_K3D(2, 3);
+          else NLPS_K3D(2, 4);
         } else {
           if (l == 0) NLPS_K3D(3, 0);
           else if (l == 1) NLPS_K3D(3, 1);
           else if (l == 2) NLPS_K3D(3, 2);
-          else NLPS_K3D(3, 3);
+          else if (l == 3) NLPS_K3D(3, 3);
+          else NLPS_K3D(3, 4);
         }
       }
       return;
@@ -2772,16 +2797,18 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else if (law == 1) NLPS_K3(2, 1);
       else if (law == 2) NLPS_K3(2, 2);
       else if (law == 3) NLPS_K3(2, 3);
+      else if (law == 4) NLPS_K3(2, 4);
       else if (!h->k3_per_law) NLPS_K3(2, -1);
       else {  // several laws in the cloud: one launch of the single-law kernel per law present
         const int last = 31 - __builtin_clz((unsigned)h->law_present);
-        for (int l = 0; l < 4; l++) {
+        for (int l = 0; l <= NLPS_KLAW_FRICTIONAL; l++) {
           if (!(h->law_present & (1 << l))) continue;
           if (signal && l == last) arm_signal(h, td, 1);
           if (l == 0) NLPS_K3F(2, 0);
           else if (l == 1) NLPS_K3F(2, 1);
           else if (l == 2) NLPS_K3F(2, 2);
-          else NLPS_K3F(2, 3);
+          else if (l == 3) NLPS_K3F(2, 3);
+          else NLPS_K3F(2, 4);
         }
       }
     } else {
@@ -2789,16 +2816,18 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else if (law == 1) NLPS_K3(3, 1);
       else if (law == 2) NLPS_K3(3, 2);
       else if (law == 3) NLPS_K3(3, 3);
+      else if (law == 4) NLPS_K3(3, 4);
       else if (!h->k3_per_law) NLPS_K3(3, -1);
       else {
         const int last = 31 - __builtin_clz((unsigned)h->law_present);
-        for (int l = 0; l < 4; l++) {
+        for (int l = 0; l <= NLPS_KLAW_FRICTIONAL; l++) {
           if (!(h->law_present & (1 << l))) continue;
           if (signal && l == last) arm_signal(h, td, 1);
           if (l == 0) NLPS_K3F(3, 0);
           else if (l == 1) NLPS_K3F(3, 1);
           else if (l == 2) NLPS_K3F(3, 2);
-          else NLPS_K3F(3, 3);
+          else if (l == 3) NLPS_K3F(3, 3);
+          else NLPS_K3F(3, 4);
         }
       }
     }

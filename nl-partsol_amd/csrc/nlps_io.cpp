@@ -656,10 +656,13 @@ extern "C" int nlps_host_read_deck(const char* path, nlps_deck* d) {
   return 0;
 }
 
-// Define-Material blocks (InOutFun/Material/Read_GramsMaterials2.c:51-175) of the four laws of this path:
-//   Define-Material(idx=0,Model=Neo-Hookean-Wriggers | Hencky | Drucker-Prager | Von-Mises) { property = value ... }
+// Define-Material blocks (InOutFun/Material/Read_GramsMaterials2.c:51-175) of the six laws of this path:
+//   Define-Material(idx=0,Model=Neo-Hookean-Wriggers | Hencky | Drucker-Prager | Von-Mises | Matsuoka-Nakai |
+//                   Lade-Duncan) { property = value ... }
 // with the property names, defaults and completeness checks of Material/Hyperelastic/Neo-Hookean.c, Hencky.c and
-// Material/Plasticity/Drucker-Prager.c, Von-Mises.c.  The eigenerosion / eigensoftening constants (Ceps, Gf, ft,
+// Material/Plasticity/Drucker-Prager.c, Von-Mises.c, Matsuoka-Nakai.c, Lade-Duncan.c (the last two also set the
+// globals TOL_Radial_Returning / Max_Iterations_Radial_Returning to 1e-10 / 20 and 1e-14 / 10: the caller's
+// nlps_params).  The eigenerosion / eigensoftening constants (Ceps, Gf, ft,
 // heps, wcrit) are accepted and dropped, as the reference does when those drivers are off.
 extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlps_material* mats, double* rho,
                                         int* idx, int* nmats) {
@@ -686,10 +689,13 @@ extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlp
     else if (model == "Hencky") m.type = NLPS_MAT_HENCKY;
     else if (model == "Drucker-Prager") m.type = NLPS_MAT_DRUCKER_PRAGER;
     else if (model == "Von-Mises") m.type = NLPS_MAT_VON_MISES;
+    else if (model == "Matsuoka-Nakai") m.type = NLPS_MAT_MATSUOKA_NAKAI;
+    else if (model == "Lade-Duncan") m.type = NLPS_MAT_LADE_DUNCAN;
     else return fail("Define-Material: model " + model + " is not one of the laws of this path");
     const std::string who = "Define-Material(" + model + ")";
     bool open = false, closed = false, has_rho = false, has_E = false, has_nu = false, has_phi = false, has_psi = false,
-         has_eps0 = false, has_yield = false, fbar = false;
+         has_eps0 = false, has_yield = false, fbar = false, has_alpha = false, has_a1 = false, has_a2 = false,
+         has_a3 = false, has_kappa0 = false;
     double H = 0.0, r = 0.0;
     while (!closed) {
       if (!in.next()) return fail(who + ": the block is not closed");
@@ -698,6 +704,7 @@ extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlp
       const char* k = kv[0];
       const double v = np_ > 1 ? atof(kv[1]) : 0.0;
       const bool dp = m.type == NLPS_MAT_DRUCKER_PRAGER, vm = m.type == NLPS_MAT_VON_MISES;
+      const bool ld = m.type == NLPS_MAT_LADE_DUNCAN, fr = ld || m.type == NLPS_MAT_MATSUOKA_NAKAI;
       if (!strcmp(k, "{") && np_ == 1) open = true;
       else if (!strcmp(k, "}") && np_ == 1) closed = true;
       else if (np_ != 2) return fail(who + ": Use this format -> Propertie = value");
@@ -722,7 +729,17 @@ extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlp
       else if (vm && !strcmp(k, "K-0")) m.K0_voce = v;
       else if (vm && !strcmp(k, "K-inf")) m.Kinf_voce = v;
       else if (vm && !strcmp(k, "delta")) m.delta_voce = v;
-      else return fail(who + ": Undefined " + k);
+      else if (fr && !strcmp(k, "alpha")) m.alpha_borja = v, has_alpha = true;
+      else if (fr && !strcmp(k, "a1")) m.a_borja[0] = v, has_a1 = true;
+      else if (fr && !strcmp(k, "a2")) m.a_borja[1] = v, has_a2 = true;
+      else if (fr && !strcmp(k, "a3")) m.a_borja[2] = v, has_a3 = true;
+      else if (fr && !strcmp(k, "Reference-pressure")) m.p_ref = v;
+      else if (fr && !strcmp(k, "Friction-angle")) m.phi_deg = v, has_phi = true;
+      else if (fr && !strcmp(k, "EPS-0")) m.eps_0 = v, has_eps0 = true;
+      else if (fr && !strcmp(k, "kappa-0")) m.kappa_0 = v, has_kappa0 = true;
+      else if (fr && !strcmp(k, "Cohesion")) m.cohesion = v;
+      else if (ld && !strcmp(k, "Atmospheric-pressure")) {
+      } else return fail(who + ": Undefined " + k);
     }
     (void)open;  // the reference notes the opening brace and never asks for it either
     if (!(has_rho && has_E && has_nu)) return fail(who + ": rho, E and nu are required");
@@ -734,6 +751,36 @@ extern "C" int nlps_host_read_materials(const char* path, int max_materials, nlp
       if (!has_eps0) m.eps_0 = (m.kappa_0 / (mo * H)) * std::pow(1, (1.0 / mo - 1.0));  // Drucker-Prager.c:200-209
     }
     if (m.type == NLPS_MAT_VON_MISES && !has_yield) return fail(who + ": Yield-stress is required");
+    if (m.type == NLPS_MAT_MATSUOKA_NAKAI || m.type == NLPS_MAT_LADE_DUNCAN) {
+      const double PI = 3.14159265358979323846;
+      if (!(has_alpha && has_a1 && has_a2 && has_a3)) return fail(who + ": alpha, a1, a2 and a3 are required");
+      if (m.type == NLPS_MAT_MATSUOKA_NAKAI) {
+        // Matsuoka-Nakai.c:207-211: without a friction angle, the one that matches kappa_0 (degrees)
+        if (!has_phi) m.phi_deg = (180.0 / PI) * std::asin(std::sqrt(m.kappa_0 / (m.kappa_0 + 8.0)));
+      } else if (has_phi) {
+        // Lade-Duncan.c:210-237: kappa_0 from the friction angle, EPS-0 from kappa_0 = a1 EPS exp(a2 I1) exp(-a3 EPS)
+        // at I1 = 3 (p_ref - c cot phi) by Newton (tolerance = the reader's TOL_Radial_Returning, 1e-14; 10 iterations)
+        const double rad = (PI / 180.0) * m.phi_deg, c_cotphi = m.cohesion / std::tan(rad);
+        const double a1 = m.a_borja[0], a2 = m.a_borja[1], a3 = m.a_borja[2], I1 = 3 * (m.p_ref - c_cotphi);
+        const double kappa_0 = 8.0 * std::sin(rad) * std::sin(rad) / (1.0 - std::sin(rad) * std::sin(rad));
+        double EPS_0 = 0.0, f = kappa_0 - a1 * EPS_0 * std::exp(a2 * I1) * std::exp(-a3 * EPS_0);
+        int iter = 0;
+        while (std::fabs(f) > 1E-14) {
+          iter++;
+          const double df = (a3 * EPS_0 - 1) * a1 * std::exp(a2 * I1) * std::exp(-a3 * EPS_0);
+          EPS_0 += -f / df;
+          f = kappa_0 - a1 * EPS_0 * std::exp(a2 * I1) * std::exp(-a3 * EPS_0);
+          if (iter > 10) return fail(who + ": Iter > 10");
+        }
+        m.kappa_0 = kappa_0;
+        m.eps_0 = EPS_0;
+      } else if (has_kappa0) {
+        // :238-241 (its first test is an assignment, so kappa-0 alone decides; the angle is left in radians there)
+        m.phi_deg = std::asin(std::sqrt(m.kappa_0 / (m.kappa_0 + 8)));
+      } else {
+        return fail(who + ": Some parameters are missed for Lade-Duncan initialization");
+      }
+    }
     mats[*nmats] = m;
     rho[*nmats] = r;
     if (idx) idx[*nmats] = id;

@@ -169,7 +169,9 @@ def read_materials(path, max_materials=16):
     _check(f(str(path).encode(), max_materials, mats, rho, idx, C.byref(n)), "nlps_host_read_materials")
     out = []
     for i in range(n.value):
-        out.append((idx[i], rho[i], {k: getattr(mats[i], k) for k, _ in _nlps.Material._fields_}))
+        m = {k: getattr(mats[i], k) for k, _ in _nlps.Material._fields_}
+        m["a_borja"] = tuple(m["a_borja"])
+        out.append((idx[i], rho[i], m))
     return out
 
 

@@ -93,3 +93,48 @@ def von_mises_material():
     the numbers are of the order of the reference's tests/Constitutive/Von-Mises.c driver (unit-free)."""
     return {"type": 3, "E": 1.0e4, "nu": 0.3, "kappa_0": 30.0, "hardening_modulus": 400.0, "theta_voce": 0.6,
             "K0_voce": 30.0, "Kinf_voce": 45.0, "delta_voce": 12.0}
+
+
+def matsuoka_nakai_material(lade_duncan=False):
+    """Three-invariant frictional plasticity (Matsuoka-Nakai.c:300-700 / Lade-Duncan.c:290-692); the numbers are the
+    active set of the reference's tests/Constitutive/Matsuoka_Nakai.c driver (:38-52: E, nu, a1..a3, alpha, the
+    initial kappa and plastic strain), with the friction angle its reader derives from kappa_0 when none is given
+    (InOutFun/Material/Plasticity/Matsuoka-Nakai.c:207-211).  Compressive pre-stress comes with the particles
+    (`frictional_prestress`): both surfaces need negative principal stresses."""
+    kappa_0 = 4.543
+    return {"type": 5 if lade_duncan else 4, "E": 1.0e4, "nu": 0.2, "kappa_0": kappa_0, "eps_0": 1.065199,
+            "phi_deg": float(np.degrees(np.arcsin(np.sqrt(kappa_0 / (kappa_0 + 8.0))))), "cohesion": 0.0,
+            "alpha_borja": 0.162, "a_borja": (10.0, 0.0, 0.8)}
+
+
+def frictional_states(ndim, mat, n, seed=0, pressure=(10.0, 30.0)):
+    """Rows of b_e for n particles under compressive Kirchhoff stresses -p (1, q, r) in random principal axes (the
+    driver above confines at -20, :50), with the ratios bounded so that every state lies INSIDE the yield surface of
+    the material (Matsuoka-Nakai: I1 I2 / I3 < 9 + kappa_0; Lade-Duncan: I1^3 / I3 < 27 + kappa_0) but many of them
+    close to it: a small strain increment then sends part of the cloud through the plastic branch."""
+    rng = np.random.default_rng(seed)
+    E, nu, k0 = mat["E"], mat["nu"], mat["kappa_0"]
+    ld = mat["type"] == 5
+    CC = np.full((3, 3), -nu / E)
+    np.fill_diagonal(CC, 1.0 / E)
+    T = 5 if ndim == 2 else 9
+    out = np.zeros((n, T))
+    for p in range(n):
+        while True:
+            t = -rng.uniform(*pressure) * np.array([1.0, rng.uniform(1.0, 1.3), rng.uniform(1.0, 4.0)])
+            I1, I2, I3 = t.sum(), t[0] * t[1] + t[1] * t[2] + t[0] * t[2], t.prod()
+            ratio = I1 ** 3 / I3 if ld else I1 * I2 / I3
+            lim = (27.0 if ld else 9.0) + k0
+            if ratio < 0.995 * lim and (p % 3 == 0 or ratio > 0.97 * lim):  # two of three close to the surface
+                break
+        e = CC @ (t + 0.0)  # no cohesion shift in the materials above
+        if ndim == 3:
+            Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            out[p] = (Q @ np.diag(np.exp(2 * e)) @ Q.T).ravel()
+        else:
+            e = e[rng.permutation(3)]
+            th = rng.uniform(0, np.pi)
+            Q = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            out[p, :4] = (Q @ np.diag(np.exp(2 * e[:2])) @ Q.T).ravel()
+            out[p, 4] = np.exp(2 * e[2])
+    return out

@@ -1233,6 +1233,329 @@ static int stress_von_mises(int ndim, const orc_material *mat, const orc_params 
   return 0;
 }
 
+/* ======================================================================================
+ * Matsuoka-Nakai and Lade-Duncan: the monolithic three-invariant return mapping with line search of
+ * Plasticity/Matsuoka-Nakai.c:300-700 and Plasticity/Lade-Duncan.c:290-692 (Borja et al. 2003).  The two files share
+ * every statement but the yield / potential surfaces (Matsuoka-Nakai.c:961-1053, Lade-Duncan.c:959-1035) and what the
+ * plastic branch does with the trial strain (:432-434 against Lade-Duncan.c:430-432), so one routine restates both.
+ * Unknowns of the local Newton iteration: principal Kirchhoff stresses (shifted by c cot(phi)), kappa_phi and the
+ * plastic multiplier; the 5 x 5 system goes through LAPACKE_dgetrf / dgetrs upstream (:1120-1163), partial pivoting
+ * here.  Kept as written: the residual added to the diagonal of the tangent (:505-510), the line search that steps
+ * along the NEW residual (:583-587), the elastic branch that leaves E_hencky_k1 at zero so the corrector writes
+ * b_e = 1 (:410-424, :694), C_ep written in 2-D only after a plastic step (:1285-1290).  Eigenvectors by column
+ * everywhere, as for the other laws (upstream indexes them by row in __update_internal_variables_plastic, :1190).
+ * ====================================================================================== */
+static int lu_solve5(double A[25], double b[5]) { /* A x = b in place, row-major, partial pivoting (first maximum) */
+  for (int k = 0; k < 5; k++) {
+    int piv = k;
+    double big = fabs(A[k * 5 + k]);
+    for (int r = k + 1; r < 5; r++)
+      if (fabs(A[r * 5 + k]) > big) {
+        big = fabs(A[r * 5 + k]);
+        piv = r;
+      }
+    if (A[piv * 5 + k] == 0.0) return 1; /* dgetrf INFO > 0 (:1130-1147) */
+    if (piv != k) {
+      for (int c = 0; c < 5; c++) {
+        double t = A[k * 5 + c];
+        A[k * 5 + c] = A[piv * 5 + c];
+        A[piv * 5 + c] = t;
+      }
+      double t = b[k];
+      b[k] = b[piv];
+      b[piv] = t;
+    }
+    for (int r = k + 1; r < 5; r++) {
+      double f = A[r * 5 + k] / A[k * 5 + k];
+      for (int c = k + 1; c < 5; c++) A[r * 5 + c] -= f * A[k * 5 + c];
+      b[r] -= f * b[k];
+    }
+  }
+  for (int k = 4; k >= 0; k--) {
+    double t = b[k];
+    for (int c = k + 1; c < 5; c++) t -= A[k * 5 + c] * b[c];
+    b[k] = t / A[k * 5 + k];
+  }
+  return 0;
+}
+
+static int inverse3_pivot(double A[9]) { /* in place, partial pivoting (dgetrf_ + dgetri_, :1241-1283) */
+  double M[3][6];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      M[i][j] = A[i * 3 + j];
+      M[i][3 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int k = 0; k < 3; k++) {
+    int piv = k;
+    for (int r = k + 1; r < 3; r++)
+      if (fabs(M[r][k]) > fabs(M[piv][k])) piv = r;
+    if (M[piv][k] == 0.0) return 1;
+    if (piv != k)
+      for (int c = 0; c < 6; c++) {
+        double t = M[k][c];
+        M[k][c] = M[piv][c];
+        M[piv][c] = t;
+      }
+    double d = M[k][k];
+    for (int c = 0; c < 6; c++) M[k][c] /= d;
+    for (int r = 0; r < 3; r++) {
+      if (r == k) continue;
+      double f = M[r][k];
+      for (int c = 0; c < 6; c++) M[r][c] -= f * M[k][c];
+    }
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[i * 3 + j] = M[i][3 + j];
+  return 0;
+}
+
+typedef struct {
+  int lade_duncan;
+  double I1, I2, I3;
+} fric_inv;
+
+static void fric_invariants(fric_inv *v, const double *T) { /* :399-401 */
+  v->I1 = T[0] + T[1] + T[2];
+  v->I2 = T[0] * T[1] + T[1] * T[2] + T[0] * T[2];
+  v->I3 = T[0] * T[1] * T[2];
+}
+/* __F: Matsuoka-Nakai.c:961-965, Lade-Duncan.c:959-964 */
+static double fric_F(const fric_inv *v, double kappa_phi) {
+  if (v->lade_duncan) return cbrt((27.0 + kappa_phi) * v->I3) - v->I1;
+  return cbrt((9.0 + kappa_phi) * v->I3) - cbrt(v->I1 * v->I2);
+}
+/* the part the two gradients share in Matsuoka-Nakai (:974-976): d cbrt(I1 I2) / d tau_A */
+static double fric_grad_g(const fric_inv *v, const double *T, int A) {
+  return (v->I1 * (v->I1 - T[A]) + v->I2) / (3.0 * pow(cbrt(v->I1 * v->I2), 2.0));
+}
+/* __d_F_d_stress / __d_G_d_stress: Matsuoka-Nakai.c:969-1007, Lade-Duncan.c:968-1001 (same form, kappa_phi | kappa_psi) */
+static void fric_dsurf(double *d, const fric_inv *v, const double *T, double kap) {
+  for (int A = 0; A < 3; A++) {
+    if (v->lade_duncan) d[A] = cbrt((27.0 + kap) * v->I3) / (3.0 * T[A]) - 1.0;
+    else d[A] = cbrt((9.0 + kap) * v->I3) / (3.0 * T[A]) - fric_grad_g(v, T, A);
+  }
+}
+/* __d_F_d_kappa_phi: :986-991 | Lade-Duncan.c:979-985 */
+static double fric_dF_dkappa(const fric_inv *v, double kappa_phi) {
+  double K1 = (v->lade_duncan ? 27.0 : 9.0) + kappa_phi;
+  return (1.0 / 3.0) * pow(cbrt(K1), -2.0) * cbrt(v->I3);
+}
+/* __dd_G_dd_stress: :1011-1040 | Lade-Duncan.c:1005-1017 */
+static void fric_ddG(double *dd, const fric_inv *v, const double *T, double kappa_psi) {
+  double K2 = (v->lade_duncan ? 27.0 : 9.0) + kappa_psi;
+  for (int A = 0; A < 3; A++)
+    for (int B = 0; B < 3; B++) {
+      double first = (1.0 / 3.0) * cbrt(K2 * v->I3) * (1.0 / (3.0 * T[A] * T[B]) - 1.0 * (A == B) / pow(T[A], 2.0));
+      if (v->lade_duncan) dd[A * 3 + B] = first;
+      else {
+        double ddg = pow(cbrt(v->I1 * v->I2), -2.0) / 3.0 * (3.0 * v->I1 - T[A] - T[B] - v->I1 * (A == B)) -
+                     (2.0 / cbrt(v->I1 * v->I2)) * fric_grad_g(v, T, A) * fric_grad_g(v, T, B);
+        dd[A * 3 + B] = first - ddg;
+      }
+    }
+}
+/* __dd_G_d_stress_d_kappa_psi: :1042-1053 | Lade-Duncan.c:1020-1031 (which drops the 3 cbrt(K2)^2 divisor) */
+static void fric_ddG_dkappa(double *d, const fric_inv *v, const double *T, double kappa_psi) {
+  for (int A = 0; A < 3; A++) {
+    d[A] = cbrt(v->I3) / (3.0 * T[A]);
+    if (!v->lade_duncan) d[A] = d[A] / (3.0 * pow(cbrt(9.0 + kappa_psi), 2));
+  }
+}
+/* __residual :1057-1082 */
+static double fric_residual(double *R, const double *E_tr, const double *E_k, const double *dG, double kappa_phi,
+                            double kappa_hat, double F_k, double dl) {
+  R[0] = E_k[0] - E_tr[0] + dl * dG[0];
+  R[1] = E_k[1] - E_tr[1] + dl * dG[1];
+  R[2] = E_k[2] - E_tr[2] + dl * dG[2];
+  R[3] = kappa_phi - kappa_hat;
+  R[4] = F_k;
+  double n2 = 0.0;
+  for (int A = 0; A < 5; A++) n2 += R[A] * R[A];
+  return pow(n2, 0.5);
+}
+
+static int stress_frictional(int ndim, const orc_material *mat, const orc_params *prm, const double *d_phi,
+                             const double *b_e_n, double kappa_in, double eps_in, double *T, double *W, double *b_e,
+                             double *kappa_out, double *eps_out, double *C_ep) {
+  double eigval[3] = {0, 0, 0}, eigvec[9] = {0}, btr[9] = {0};
+  orc_trial_b_e(btr, d_phi, b_e_n, ndim); /* __compute_trial_b_e :705-747 */
+  if (orc_sym_eigen(eigval, eigvec, btr, ndim)) return 1;
+  if (ndim == 2) eigval[2] = b_e_n[4];
+  double E_tr[3] = {0.5 * log(eigval[0]), 0.5 * log(eigval[1]), 0.5 * log(eigval[2])};
+  double E_k1[3] = {0, 0, 0}, E_k2[3] = {0, 0, 0};
+  fric_inv v;
+  v.lade_duncan = mat->type == ORC_MAT_LADE_DUNCAN;
+
+  const double E = mat->E, nu = mat->nu;
+  const double Lame = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu)), G = E / (2.0 * (1.0 + nu));
+  const double rad = (PI_MATRIXLIB / 180.0) * mat->phi_deg;
+  const double c_cotphi = rad > 0.0 ? mat->cohesion / tan(rad) : 0.0;
+  const double alpha = mat->alpha_borja;
+  const double *a = mat->a_borja;
+  /* __elastic_tangent :799-824: compliance CC and stiffness AA in principal space */
+  const double CC[9] = {1.0 / E, -nu / E, -nu / E, -nu / E, 1.0 / E, -nu / E, -nu / E, -nu / E, 1.0 / E};
+  const double AA[9] = {Lame + 2 * G, Lame, Lame, Lame, Lame + 2 * G, Lame, Lame, Lame, Lame + 2 * G};
+#define FRIC_E_HENCKY(Eo, Tk) /* __E_hencky :841-849 */                                            \
+  for (int r_ = 0; r_ < 3; r_++)                                                                   \
+    (Eo)[r_] = CC[3 * r_] * ((Tk)[0] + c_cotphi) + CC[3 * r_ + 1] * ((Tk)[1] + c_cotphi) + CC[3 * r_ + 2] * ((Tk)[2] + c_cotphi)
+#define FRIC_KAPPA_HAT(Lam) (a[0] * (Lam)*exp(a[1] * v.I1) * exp(-a[2] * (Lam))) /* __kappa :933-937 */
+
+  const double Lambda_n = eps_in;
+  const double kappa_n[2] = {kappa_in, alpha * kappa_in};
+  const double TOL = prm->tol_radial_returning, TOL_apex = 0.1;
+  const int MaxIter_k1 = prm->max_iter_radial_returning, MaxIter_k2 = 10 * prm->max_iter_radial_returning;
+  double T_tr[3], T_k1[3], T_k2[3], kappa_k1[2], kappa_k2[2];
+  double dG[3] = {0, 0, 0}, ddG[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ddG_dk[3], dkappa_ds, dkappa_dl, dF[3], dF_dk;
+  double R1[5] = {0, 0, 0, 0, 0}, R2[5] = {0, 0, 0, 0, 0}, TM[25];
+  double F_0, F_k1, F_k2 = 0.0, N0, N1, N2, Lambda_k1, Lambda_k2, dl1 = 0.0, dl2, delta;
+
+  *kappa_out = kappa_in; /* the n+1 state starts from n, Constitutive.c:196-203 */
+  *eps_out = eps_in;
+  for (int r = 0; r < 3; r++) /* __trial_elastic :828-837 */
+    T_tr[r] = AA[3 * r] * E_tr[0] + AA[3 * r + 1] * E_tr[1] + AA[3 * r + 2] * E_tr[2] - c_cotphi;
+  fric_invariants(&v, T_tr);
+  F_0 = fric_F(&v, kappa_n[0]);
+  T_k1[0] = T_tr[0];
+  T_k1[1] = T_tr[1];
+  T_k1[2] = T_tr[2];
+
+  if (F_0 <= TOL_NR) { /* elastic :410-424 */
+    double Tp[3] = {T_k1[0] + c_cotphi, T_k1[1] + c_cotphi, T_k1[2] + c_cotphi};
+    ppal_to_xyz(T, Tp, eigvec, ndim); /* __update_internal_variables_elastic :853-908 */
+    if (C_ep) /* __elastic_tangent_moduli :912-929 */
+      for (int i = 0; i < ndim; i++)
+        for (int j = 0; j < ndim; j++) C_ep[i * ndim + j] = AA[i * 3 + j];
+  } else { /* plastic: monolithic Newton with line search :426-690 */
+    FRIC_E_HENCKY(E_k1, T_k1);
+    for (int r = 0; r < 3; r++) {
+      if (v.lade_duncan) E_k1[r] = E_tr[r]; /* Lade-Duncan.c:430-432 */
+      else E_tr[r] = E_k1[r];               /* Matsuoka-Nakai.c:432-434 */
+    }
+    double kappa_hat = FRIC_KAPPA_HAT(Lambda_n);
+    fric_dsurf(dG, &v, T_tr, kappa_n[1]);
+    N0 = fric_residual(R1, E_tr, E_k1, dG, kappa_n[0], kappa_hat, F_0, 0.0);
+    kappa_k1[0] = kappa_n[0];
+    kappa_k1[1] = kappa_n[1];
+    F_k1 = F_0;
+    dl1 = 0.0;
+    Lambda_k1 = Lambda_n;
+    N1 = N0;
+    int Iter_k1 = 0, Iter_k2;
+#define FRIC_APEX(Tk) (fabs(((Tk)[0] + (Tk)[1] + (Tk)[2]) / 3.0) < TOL_apex)
+#define FRIC_EVAL_K2() /* :550-573 */                                                   \
+  do {                                                                                  \
+    fric_invariants(&v, T_k2);                                                          \
+    FRIC_E_HENCKY(E_k2, T_k2);                                                          \
+    kappa_hat = FRIC_KAPPA_HAT(Lambda_k2);                                              \
+    fric_dsurf(dG, &v, T_k2, kappa_k2[1]);                                              \
+    F_k2 = fric_F(&v, kappa_k2[0]);                                                     \
+    N2 = fric_residual(R2, E_tr, E_k2, dG, kappa_k2[0], kappa_hat, F_k2, dl2);          \
+  } while (0)
+    while ((fabs(N1 / N0) >= TOL) && (fabs(F_k1 / F_0) >= TOL)) {
+      delta = 1.0;
+      /* hardening derivatives :941-957 (I1 of the last evaluated stress) */
+      dkappa_ds = a[0] * a[1] * Lambda_k1 * exp(a[1] * v.I1) * exp(-a[2] * Lambda_k1);
+      dkappa_dl = (1 - a[2] * Lambda_k1) * a[0] * exp(a[1] * v.I1) * exp(-a[2] * Lambda_k1);
+      fric_dsurf(dF, &v, T_k1, kappa_k1[0]);
+      dF_dk = fric_dF_dkappa(&v, kappa_k1[0]);
+      fric_ddG(ddG, &v, T_k1, kappa_k1[1]);
+      fric_ddG_dkappa(ddG_dk, &v, T_k1, kappa_k1[1]);
+      for (int r = 0; r < 3; r++) { /* tangent :472-503 */
+        for (int c = 0; c < 3; c++) TM[r * 5 + c] = CC[r * 3 + c] + dl1 * ddG[r * 3 + c];
+        TM[r * 5 + 3] = alpha * dl1 * ddG_dk[r];
+        TM[r * 5 + 4] = dG[r];
+        TM[3 * 5 + r] = -dkappa_ds;
+        TM[4 * 5 + r] = dF[r];
+      }
+      TM[3 * 5 + 3] = 1.0;
+      TM[3 * 5 + 4] = -dkappa_dl;
+      TM[4 * 5 + 3] = dF_dk;
+      TM[4 * 5 + 4] = 0.0;
+      for (int r = 0; r < 5; r++) TM[r * 5 + r] += R1[r]; /* "preconditioner" :505-510 */
+      if (lu_solve5(TM, R1)) return 1;
+      dl2 = dl1 - delta * R1[4];
+      if (Lambda_n + dl2 < 0.0) break;
+      Lambda_k2 = Lambda_n + dl2;
+      T_k2[0] = T_k1[0] - delta * R1[0];
+      T_k2[1] = T_k1[1] - delta * R1[1];
+      T_k2[2] = T_k1[2] - delta * R1[2];
+      kappa_k2[0] = kappa_k1[0] - delta * R1[3];
+      kappa_k2[1] = alpha * kappa_k2[0];
+      Iter_k2 = 0;
+      if (FRIC_APEX(T_k2)) break; /* :536-544: the k2 values it resets are not used again */
+      FRIC_EVAL_K2();
+      while ((fabs(N2 - N1) > TOL) && (fabs(F_k2 / F_0) >= TOL)) { /* line search :575-629 */
+        delta = pow(delta, 2.0) * 0.5 * N1 / (N2 - delta * N1 + N1);
+        if ((delta > 1.0) || (delta < 0.0)) break;
+        dl2 = dl1 - delta * R2[4];
+        if (Lambda_n + dl2 < 0.0) break;
+        Lambda_k2 = Lambda_n + dl2;
+        T_k2[0] = T_k1[0] - delta * R2[0];
+        T_k2[1] = T_k1[1] - delta * R2[1];
+        T_k2[2] = T_k1[2] - delta * R2[2];
+        kappa_k2[0] = kappa_k1[0] - delta * R2[3];
+        kappa_k2[1] = alpha * kappa_k2[0];
+        if (FRIC_APEX(T_k2)) {
+          Lambda_k2 = Lambda_n;
+          kappa_k2[0] = kappa_n[0];
+          kappa_k2[1] = alpha * kappa_k2[0];
+          T_k2[0] = T_k2[1] = T_k2[2] = 0.0;
+          break;
+        }
+        FRIC_EVAL_K2();
+        Iter_k2++;
+        if (Iter_k2 == MaxIter_k2) break;
+      }
+      for (int r = 0; r < 3; r++) { /* :632-649 */
+        T_k1[r] = T_k2[r];
+        E_k1[r] = E_k2[r];
+      }
+      kappa_k1[0] = kappa_k2[0];
+      kappa_k1[1] = kappa_k2[1];
+      Lambda_k1 = Lambda_k2;
+      F_k1 = F_k2;
+      dl1 = dl2;
+      for (int r = 0; r < 5; r++) R1[r] = R2[r];
+      N1 = N2;
+      Iter_k1++;
+      if (FRIC_APEX(T_k1)) { /* :651-659 */
+        Lambda_k1 = Lambda_n;
+        kappa_k1[0] = kappa_n[0];
+        kappa_k1[1] = alpha * kappa_k1[0];
+        T_k1[0] = T_k1[1] = T_k1[2] = 0.0;
+        break;
+      }
+      if (Iter_k1 == MaxIter_k1) break; /* :661-679 only prints the condition number */
+    }
+#undef FRIC_APEX
+#undef FRIC_EVAL_K2
+    *eps_out = Lambda_k1; /* __update_internal_variables_plastic :1167-1215 */
+    *kappa_out = kappa_k1[0];
+    double Tp[3] = {T_k1[0] + c_cotphi, T_k1[1] + c_cotphi, T_k1[2] + c_cotphi};
+    ppal_to_xyz(T, Tp, eigvec, ndim);
+    if (C_ep) { /* __elastoplastic_tangent_moduli :1219-1291: inverse of CC + dlambda ddG; stored in 2-D only */
+      double aux[9];
+      for (int i = 0; i < 9; i++) aux[i] = CC[i] + dl1 * ddG[i];
+      if (inverse3_pivot(aux)) return 1;
+      if (ndim == 2) {
+        C_ep[0] = aux[0];
+        C_ep[1] = aux[1];
+        C_ep[2] = aux[3];
+        C_ep[3] = aux[4];
+      }
+    }
+  }
+#undef FRIC_E_HENCKY
+#undef FRIC_KAPPA_HAT
+  { /* __corrector_b_e :751-795 with E_hencky_k1 (zero after an elastic step) */
+    double lam[3] = {exp(2 * E_k1[0]), exp(2 * E_k1[1]), exp(2 * E_k1[2])};
+    ppal_to_xyz(b_e, lam, eigvec, ndim);
+  }
+  *W = 0.5 * ((T_k1[0] + c_cotphi) * E_tr[0] + (T_k1[1] + c_cotphi) * E_tr[1] + (T_k1[2] + c_cotphi) * E_tr[2]); /* :696-699 */
+  return 0;
+}
+
 int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, const double *F_n1,
                    const double *DF, double J, const double *b_e_n, double kappa_n, double eps_n,
                    double *stress, double *W, double *b_e_n1, double *kappa_n1, double *eps_n1, double *C_ep,
@@ -1251,6 +1574,9 @@ int orc_stress_one(int ndim, const orc_material *mat, const orc_params *prm, con
     return stress_von_mises(ndim, mat, prm, DF, b_e_n, eps_n, back_stress ? back_stress : zero_back, stress, W,
                             b_e_n1, eps_n1, C_ep);
   }
+  case ORC_MAT_MATSUOKA_NAKAI: /* Constitutive.c:180-213 */
+  case ORC_MAT_LADE_DUNCAN:    /* Constitutive.c:215-248 */
+    return stress_frictional(ndim, mat, prm, DF, b_e_n, kappa_n, eps_n, stress, W, b_e_n1, kappa_n1, eps_n1, C_ep);
   default:
     return 1; /* Constitutive.c:251-256 exit()s */
   }

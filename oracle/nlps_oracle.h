@@ -26,7 +26,8 @@ extern "C" {
 
 #define ORC_MAXNB 128 /* >= 5^3 two-ring candidates */
 
-enum { ORC_MAT_NEO_HOOKEAN = 0, ORC_MAT_HENCKY = 1, ORC_MAT_DRUCKER_PRAGER = 2, ORC_MAT_VON_MISES = 3 };
+enum { ORC_MAT_NEO_HOOKEAN = 0, ORC_MAT_HENCKY = 1, ORC_MAT_DRUCKER_PRAGER = 2, ORC_MAT_VON_MISES = 3,
+       ORC_MAT_MATSUOKA_NAKAI = 4, ORC_MAT_LADE_DUNCAN = 5 };
 
 /* Background mesh: Types.h:631-760 (only the members the path reads). */
 typedef struct {
@@ -74,6 +75,11 @@ typedef struct {
   double hardening_modulus;     /* Hardening_modulus */
   double theta_voce, K0_voce, Kinf_voce, delta_voce; /* *_Hardening_Voce */
   double Ceps, Gf;              /* eigenerosion: normalising constant and critical energy release rate */
+  /* Matsuoka-Nakai / Lade-Duncan (Plasticity/Matsuoka-Nakai.c:330-341): with phi_deg, kappa_0 (initial Kappa) and
+   * eps_0 (initial EPS of Matsuoka-Nakai, Generate-One-Phase-Analysis.c:624-626) */
+  double cohesion;              /* Cohesion */
+  double alpha_borja;           /* alpha_Hardening_Borja */
+  double a_borja[3];            /* a_Hardening_Borja */
 } orc_material;
 
 /* Globals snapshot: Globals.h:21,33-58; defaults InOutFun/Read_GramsShapeFun.c:100-104 */

@@ -42,7 +42,8 @@ class Material(C.Structure):
                 ("psi_deg", C.c_double), ("kappa_0", C.c_double), ("exponent_ortiz", C.c_double),
                 ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
                 ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
-                ("delta_voce", C.c_double), ("Ceps", C.c_double), ("Gf", C.c_double)]
+                ("delta_voce", C.c_double), ("Ceps", C.c_double), ("Gf", C.c_double),
+                ("cohesion", C.c_double), ("alpha_borja", C.c_double), ("a_borja", C.c_double * 3)]
 
 
 class Params(C.Structure):
@@ -213,7 +214,9 @@ def make_materials(mats):
                           float(m.get("p_ref", 0.0)), float(m.get("hardening_modulus", 0.0)),
                           float(m.get("theta_voce", 1.0)), float(m.get("K0_voce", 0.0)),
                           float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)),
-                          float(m.get("Ceps", 0.0)), float(m.get("Gf", 0.0)))
+                          float(m.get("Ceps", 0.0)), float(m.get("Gf", 0.0)), float(m.get("cohesion", 0.0)),
+                               float(m.get("alpha_borja", 0.0)),
+                               (C.c_double * 3)(*[float(v) for v in m.get("a_borja", (0.0, 0.0, 0.0))]))
     return arr
 
 

@@ -483,7 +483,7 @@ def test_define_material_blocks(tmp_path):
     gid.read_deck(p)  # the material blocks do not disturb the other reader
     for bad, msg in ((MATERIALS.replace("  Yield-stress=30.0\n", ""), "Yield-stress is required"),
                      (MATERIALS.replace("  m=1.0\n", ""), "must have one sign"),
-                     (MATERIALS.replace("Model=Hencky", "Model=Matsuoka-Nakai"), "not one of the laws"),
+                     (MATERIALS.replace("Model=Hencky", "Model=Saint-Venant-Kirchhoff"), "not one of the laws"),
                      (MATERIALS.replace("\tCeps=1.5\n", "\tFbar=true\n"), "Fbar needs"),
                      (MATERIALS.replace("  nu=0.25\n}", "  nu=0.25\n"), "not closed"),
                      (MATERIALS.replace("  nu=0.25\n", ""), "rho, E and nu are required"),
@@ -491,6 +491,82 @@ def test_define_material_blocks(tmp_path):
         p.write_text(bad)
         with pytest.raises(E, match=msg):
             gid.read_materials(p)
+
+
+FRICTIONAL = """Define-Material(idx=0,Model=Matsuoka-Nakai)
+{
+  rho=1800
+  E=1.0e4
+  nu=0.2
+  alpha=0.162
+  a1=10.0
+  a2=0.0
+  a3=0.8
+  EPS-0=1.065199
+  kappa-0=4.543
+}
+Define-Material(idx=1,Model=Lade-Duncan)
+{
+  rho=1800
+  E=1.0e4
+  nu=0.2
+  alpha=0.5
+  a1=20000.0
+  a2=0.005
+  a3=35.0
+  Friction-angle=30.0
+  Cohesion=2.0
+  Reference-pressure=-20.0
+  Atmospheric-pressure=-100.0
+}
+Define-Material(idx=2,Model=Lade-Duncan)
+{
+  rho=1800
+  E=1.0e4
+  nu=0.2
+  alpha=0.5
+  a1=10.0
+  a2=0.0
+  a3=0.8
+  kappa-0=4.543
+}
+"""
+
+
+def test_define_material_blocks_of_the_frictional_laws(tmp_path):
+    """Define-Material for Matsuoka-Nakai and Lade-Duncan (InOutFun/Material/Plasticity/Matsuoka-Nakai.c:57-222,
+    Lade-Duncan.c:60-270): the Borja hardening constants, the friction angle Matsuoka-Nakai derives from kappa-0 when
+    none is given (:207-211, degrees), Lade-Duncan's kappa_0 from the friction angle with EPS-0 from the Newton
+    iteration on kappa_0 = a1 EPS exp(a2 I1) exp(-a3 EPS) at I1 = 3 (p_ref - c cot phi) (:210-237), its other branch
+    (kappa-0 alone: the angle stays in radians, :238-241), and the completeness checks.  The first block is the
+    material of the parity tests (synth.matsuoka_nakai_material)."""
+    E = nlps().NlpsError
+    p = tmp_path / "run.nlp"
+    p.write_text(FRICTIONAL)
+    mats = gid.read_materials(p)
+    assert [(i, r, m["type"]) for i, r, m in mats] == [(0, 1800.0, 4), (1, 1800.0, 5), (2, 1800.0, 5)]
+    mn, ref = mats[0][2], synth.matsuoka_nakai_material()
+    for k in ("E", "nu", "kappa_0", "eps_0", "alpha_borja", "a_borja", "cohesion"):
+        assert mn[k] == ref[k], k
+    assert abs(mn["phi_deg"] - ref["phi_deg"]) <= 1e-13 * ref["phi_deg"]
+    ld = mats[1][2]
+    rad = np.radians(30.0)
+    k0 = 8.0 * np.sin(rad) ** 2 / (1.0 - np.sin(rad) ** 2)
+    I1 = 3 * (-20.0 - 2.0 / np.tan(rad))
+    assert abs(ld["kappa_0"] - k0) <= 1e-14 * k0 and ld["cohesion"] == 2.0 and ld["phi_deg"] == 30.0
+    e0 = ld["eps_0"]
+    assert e0 > 0 and abs(k0 - 20000.0 * e0 * np.exp(0.005 * I1) * np.exp(-35.0 * e0)) <= 1e-13
+    ld2 = mats[2][2]
+    assert ld2["kappa_0"] == 4.543 and abs(ld2["phi_deg"] - np.arcsin(np.sqrt(4.543 / 12.543))) <= 1e-15
+    for bad, msg in ((FRICTIONAL.replace("  a2=0.0\n", "", 1), "alpha, a1, a2 and a3 are required"),
+                     (FRICTIONAL.replace("  Atmospheric-pressure=-100.0\n", "  Dilatancy-angle=3\n"), "Undefined Dilatancy-angle")):
+        p.write_text(bad)
+        with pytest.raises(E, match=msg):
+            gid.read_materials(p)
+    third = FRICTIONAL[:FRICTIONAL.rindex("  kappa-0=4.543")] + "}\n"
+    p.write_text(third)
+    with pytest.raises(E, match="Some parameters are missed"):
+        gid.read_materials(p)
 
 
 def test_dirichlet_boundaries_and_curves(tmp_path):

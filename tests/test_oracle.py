@@ -555,3 +555,73 @@ def test_von_mises_restatement(ndim):
     tm = tau[:ndim * ndim].reshape(ndim, ndim)
     pr = np.append(np.linalg.eigvalsh(tm), tau[4]) if ndim == 2 else np.linalg.eigvalsh(tm)
     assert abs(np.linalg.norm(pr - pr.mean()) - np.sqrt(2 / 3) * base["kappa_0"]) <= 1e-9 * base["kappa_0"]
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("law", ["matsuoka-nakai", "lade-duncan"])
+def test_frictional_restatement(ndim, law):
+    """Matsuoka-Nakai.c:300-700 / Lade-Duncan.c:290-692 come with a driver without expected values
+    (tests/Constitutive/Matsuoka_Nakai.c), so the restatement is pinned by what a converged step of the algorithm
+    promises: an elastic step is the Hencky closed form and (as written upstream, :410-424 and :694) leaves b_e = 1;
+    after a plastic step the principal stresses sit on the yield surface of the new kappa, kappa equals its
+    hardening law a1 L exp(a2 I1) exp(-a3 L), and b_e carries exactly the elastic strain C^-1 (tau + c).  States start
+    inside the surface and take small strain increments: from far outside, the residual upstream adds to the diagonal
+    of its tangent (:505-510) keeps the iteration from converging (measured; without that term every case converges),
+    and nothing can be said about such a step but that both implementations walk the same path."""
+    o = orc()
+    rng = np.random.default_rng(7)
+    ld = law == "lade-duncan"
+    mat = synth.matsuoka_nakai_material(ld)
+    mats = o.make_materials([mat])
+    prm = o.default_params()
+    prm.tol_radial_returning, prm.max_iter_radial_returning = 1e-10, 20
+    T = 5 if ndim == 2 else 9
+    E, nu, a = mat["E"], mat["nu"], mat["a_borja"]
+    lame, G = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+    AA = np.full((3, 3), lame) + 2 * G * np.eye(3)
+
+    def surface(t, kap):
+        I1, I2, I3 = t.sum(), t[0] * t[1] + t[1] * t[2] + t[0] * t[2], t.prod()
+        return np.cbrt((27 + kap) * I3) - I1 if ld else np.cbrt((9 + kap) * I3) - np.cbrt(I1 * I2)
+
+    n = 300
+    states = synth.frictional_states(ndim, mat, n, seed=3)
+    nel = npl = nconv = 0
+    for p in range(n):
+        A = 1.5e-4 * rng.normal(size=(ndim, ndim))
+        DF = np.zeros(T)
+        DF[:ndim * ndim] = (np.eye(ndim) + A).ravel()
+        if ndim == 2:
+            DF[4] = 1.0
+        be = states[p]
+        st, tau, W, b1, k1, e1 = o.stress_one(ndim, mats[0], prm, DF, DF, 1.0, be, mat["kappa_0"], mat["eps_0"])
+        assert st == 0 and np.all(np.isfinite(tau)) and np.all(np.isfinite(b1))
+        btr = (np.eye(ndim) + A) @ be[:ndim * ndim].reshape(ndim, ndim) @ (np.eye(ndim) + A).T
+        w, V = np.linalg.eigh(btr)
+        etr = 0.5 * np.log(np.append(w, be[4]) if ndim == 2 else w)
+        ttr = AA @ etr
+        F0 = surface(ttr, mat["kappa_0"])
+        tm = tau[:ndim * ndim].reshape(ndim, ndim)
+        tp = np.append(np.linalg.eigvalsh(tm), tau[4]) if ndim == 2 else np.linalg.eigvalsh(tm)
+        if F0 <= 1e-5:  # TOL_NR
+            nel += 1
+            ref = (V * ttr[:ndim]) @ V.T
+            assert np.abs(tm - ref).max() <= 1e-11 * np.abs(ref).max()
+            assert k1 == mat["kappa_0"] and e1 == mat["eps_0"]
+            ident = np.zeros(T)
+            ident[[0, 3, 4] if ndim == 2 else [0, 4, 8]] = 1.0
+            assert np.abs(b1 - ident).max() <= 1e-14
+            assert abs(W - 0.5 * (ttr * etr).sum()) <= 1e-11 * abs(W)
+        else:
+            npl += 1
+            if abs(surface(tp, k1) / F0) > 1e-8:
+                continue  # not converged (see above)
+            nconv += 1
+            assert abs(k1 - a[0] * e1 * np.exp(a[1] * tp.sum()) * np.exp(-a[2] * e1)) <= 1e-8 * max(1.0, abs(k1))
+            bm = b1[:ndim * ndim].reshape(ndim, ndim)
+            ee = 0.5 * np.log(np.append(np.linalg.eigvalsh(bm), b1[4]) if ndim == 2 else np.linalg.eigvalsh(bm))
+            CC = np.linalg.inv(AA)
+            assert np.abs(np.sort(ee) - np.sort(CC @ tp)).max() <= 1e-12
+            assert e1 >= mat["eps_0"]
+    assert nel > n // 10 and npl > n // 10, (nel, npl)
+    assert nconv > 0.8 * npl, (nconv, npl)
