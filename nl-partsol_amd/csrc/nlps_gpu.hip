@@ -192,10 +192,7 @@ __global__ void k_step_clear(int n0, int nnodes, NView N, int* __restrict__ tile
 // 1-ring activation (LME.c:949-960): the particles only mark their I0 (one byte store each instead of 3^d
 // scattered ones); node n is active iff some I0 lies in its 1-ring.
 template <int ND>
-__global__ void k_dilate(int n0, int nnodes, GridD g, NView N) {
-  int A = blockIdx.x * blockDim.x + threadIdx.x;
-  if (A >= nnodes) return;
-  A += n0;
+__device__ __forceinline__ void dilate_node(int A, const GridD& g, const NView& N) {
   const int i0 = A % g.n[0], j0 = (A / g.n[0]) % g.n[1], k0 = A / (g.n[0] * g.n[1]);
   unsigned any = 0u;
 #pragma unroll
@@ -584,8 +581,23 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
 // ------------------------------------------------------------------------------------------------
 // nodal kernels (grid numbering)
 // ------------------------------------------------------------------------------------------------
+// Dirichlet sets of one step for the nodal kernel: set i fixes the directions `bits[i]` of its nodes at v[i]; a node
+// finds its sets in the bit mask bcmask[A] (built once per set of lists, ensure_bcs), later sets override earlier ones
+// like the sequence of k_bc launches they replace (one launch per set and step: 5 us each).
+#define NLPS_MAX_BC_INLINE 8
+struct BcStep {
+  int n;
+  int dim[NLPS_MAX_BC_INLINE], bits[NLPS_MAX_BC_INLINE];
+  double v[NLPS_MAX_BC_INLINE][3];
+};
+__global__ void k_bc_mark(const int* __restrict__ nodes, int n, unsigned bit, unsigned* __restrict__ mask) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) atomicOr(&mask[nodes[q]], bit);
+}
+
 template <int ND>
-__global__ void k_nodal_dU(int n0, int nnodes, int n0b, int nnodesb, NView N) {  // U-Verlet.c:357-362
+__global__ void k_nodal_dU(int n0, int nnodes, int n0b, int nnodesb, NView N, const unsigned* __restrict__ bcmask,
+                           BcStep bc) {  // U-Verlet.c:357-362 + impose_Dirichlet_Boundary_Conditions :455-527
   int A = blockIdx.x * blockDim.x + threadIdx.x;  // two node ranges: [n0, n0+nnodes) and [n0b, n0b+nnodesb)
   if (A >= nnodes + nnodesb) return;
   A = A < nnodes ? n0 + A : n0b + (A - nnodes);
@@ -593,9 +605,32 @@ __global__ void k_nodal_dU(int n0, int nnodes, int n0b, int nnodesb, NView N) { 
   // an active node no particle lists (narrow LME kernels: the 1-ring activation reaches further than the cut-off
   // radius) has M = 0: its value is 0 like VecPointwiseDivide's in the maintained driver, never 0/0 (the gather
   // kernels read every window slot, a NaN there would poison the zero-weighted non-members)
-  bool act = N.active[A] && M != 0.0;
+  const bool active = N.active[A];
+  bool act = active && M != 0.0;
+  double val[ND];
+  bool fix[ND];
 #pragma unroll
-  for (int a = 0; a < ND; a++) N.dU[(size_t)A * ND + a] = act ? N.nm[(size_t)A * (1 + ND) + 1 + a] / M : 0.0;
+  for (int a = 0; a < ND; a++) {
+    val[a] = act ? N.nm[(size_t)A * (1 + ND) + 1 + a] / M : 0.0;
+    fix[a] = false;
+  }
+  const unsigned bm = (bcmask && active) ? bcmask[A] : 0u;
+  if (bm) {
+    for (int i = 0; i < bc.n; i++) {
+      if (!((bm >> i) & 1u)) continue;
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        if (k < bc.dim[i] && ((bc.bits[i] >> k) & 1)) {
+          val[k] = bc.v[i][k];
+          fix[k] = true;
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    N.dU[(size_t)A * ND + a] = val[a];
+    if (fix[a]) N.fixed[(size_t)A * ND + a] = 1;
+  }
 }
 
 template <int ND>
@@ -737,6 +772,19 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 }
 
 #include "nlps_tile_kernels.hpp"
+
+// The two kernels between the search and the tile lists in one launch (they do not depend on each other and both are
+// too small to fill the chip: 8 us + 10 us -> 10 us): workgroup 0 = exclusive scan of the tile counts + work lists
+// (tile_scan_block), the others = 1-ring activation of 1024 nodes each.
+template <int ND>
+__global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD g, NView N, TileScanArgs ts) {
+  if (blockIdx.x == 0) {
+    tile_scan_block(ts);
+    return;
+  }
+  const int A = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+  if (A < nnodes) dilate_node<ND>(n0 + A, g, N);
+}
 #include "nlps_tangent_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -864,6 +912,7 @@ struct BcDev {
   int* dnodes;
 };
 
+
 struct nlps_gpu {
   int nd, T;
   GridD g;
@@ -915,6 +964,7 @@ struct nlps_gpu {
   size_t maskedA_cap;
 
   std::vector<BcDev> bcs;
+  unsigned* bcmask_d = nullptr;  // per node: bit i = member of Dirichlet set i (<= NLPS_MAX_BC_INLINE sets; k_nodal_dU)
 
   // periodic physical re-sort
   int* perm_d;            // sorted slot -> caller's particle index (device copy of perm)
@@ -1699,7 +1749,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -2263,13 +2313,16 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   TileCnt tc = tile_cnt(h, true);
   if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
   else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
-  LAUNCH_ND((k_dilate<2>), (k_dilate<3>), nblk(h->nwn), h->n0, h->nwn, h->g, h->N);
+  {
+    const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
+    TileScanArgs ts{h->tile_count_d + h->tile0, h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB,
+                    h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d};
+    const int nb = 1 + (h->nwn + 1023) / 1024;
+    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts);
+    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts);
+  }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.active, 1, 1, 1, overlap ? 1 : 0)) return 1;
-  const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, h->stream, h->tile_count_d + h->tile0,
-                     h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB, h->band_lo,
-                     h->band_hi, h->work1_d, h->work2_d, h->nwork_d);
   hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                      h->order_d);
   if ((h->deterministic || h->tile_ordering) && !h->order2_d) {
@@ -2356,6 +2409,14 @@ static int ensure_bcs(nlps_gpu* h, const nlps_bcc* bcc, int nbcc) {
     }
     h->bcs.push_back(b);
   }
+  if (!h->bcmask_d) HIPCHK(hipMalloc((void**)&h->bcmask_d, (size_t)h->g.nnodes * sizeof(unsigned)));
+  HIPCHK(hipMemset(h->bcmask_d, 0, (size_t)h->g.nnodes * sizeof(unsigned)));
+  if (nbcc <= NLPS_MAX_BC_INLINE)
+    for (int i = 0; i < nbcc; i++)
+      if (h->bcs[i].n > 0)
+        hipLaunchKernelGGL(k_bc_mark, dim3(nblk(h->bcs[i].n)), dim3(BLK), 0, 0, h->bcs[i].dnodes, h->bcs[i].n, 1u << i,
+                           h->bcmask_d);
+  HIPCHK(hipGetLastError());
   // the copies above are ordered on the default stream only: a caller-provided non-blocking stream (torch
   // streams are) would not wait for their DMA
   HIPCHK(hipDeviceSynchronize());
@@ -2730,8 +2791,21 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   auto nodal_dU = [&](int part) {
     const NodeRanges r = node_ranges(h, part);
     if (r.an + r.bn == 0) return;
-    if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N);
-    else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N);
+    BcStep bs;
+    bs.n = 0;
+    const bool inline_bc = nbcc <= NLPS_MAX_BC_INLINE;
+    if (inline_bc) {
+      bs.n = nbcc;
+      for (int i = 0; i < nbcc; i++) {
+        bs.dim[i] = bcc[i].dim;
+        bs.bits[i] = h->bcs[i].n > 0 ? dirbits_of(bcc[i], step, h->nsteps) : 0;
+        for (int k = 0; k < 3; k++) bs.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
+      }
+    }
+    const unsigned* bm = (inline_bc && nbcc > 0) ? h->bcmask_d : nullptr;
+    if (ND == 2) hipLaunchKernelGGL(k_nodal_dU<2>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, bm, bs);
+    else hipLaunchKernelGGL(k_nodal_dU<3>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, bm, bs);
+    if (inline_bc) return;
     // Dirichlet values (nodes of the same range only)
     const NodeRanges in = node_ranges(h, 1);
     for (int i = 0; i < nbcc; i++) {

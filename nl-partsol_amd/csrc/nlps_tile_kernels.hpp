@@ -228,9 +228,20 @@ __device__ __forceinline__ int block_scan_1024(int v, int* sh, int* total) {
 // A tile is "boundary" when its node window reaches a ghost band: slow-axis layers <= band_lo or >= band_hi
 // (tpl = tiles per slow-axis tile layer, TB = tile edge).  ranges[cls][S-1] = {begin, end} in work<S> for
 // cls 0 = all, 1 = boundary, 2 = interior.
-__global__ void k_tile_scan(const int* __restrict__ count, int* __restrict__ start, int n, int tile0, int tpl, int TB,
-                            int band_lo, int band_hi, int2* __restrict__ work1, int2* __restrict__ work2,
-                            int* __restrict__ ranges) {
+struct TileScanArgs {
+  const int* count;
+  int* start;
+  int n, tile0, tpl, TB, band_lo, band_hi;
+  int2 *work1, *work2;
+  int* ranges;
+};
+__device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
+  const int* __restrict__ count = a.count;
+  int* __restrict__ start = a.start;
+  const int n = a.n, tile0 = a.tile0, tpl = a.tpl, TB = a.TB, band_lo = a.band_lo, band_hi = a.band_hi;
+  int2* __restrict__ work1 = a.work1;
+  int2* __restrict__ work2 = a.work2;
+  int* __restrict__ ranges = a.ranges;
   __shared__ int sh[1024];
   int chunk = (n + 1023) / 1024;
   int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0, b1 = 0, b2 = 0, i1 = 0, i2 = 0;
