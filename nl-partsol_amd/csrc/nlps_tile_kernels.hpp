@@ -54,6 +54,9 @@ static constexpr int K3_BLK = NLPS_K3_BLK, K5_BLK = NLPS_K5_BLK;
 #ifndef NLPS_K5_SPLIT
 #define NLPS_K5_SPLIT 1
 #endif
+#ifndef NLPS_K5_PREFETCH
+#define NLPS_K5_PREFETCH 1  // corrector operands requested before the gather loop: K5 0.097 -> 0.092 ms (1 M particles)
+#endif
 static constexpr int K2_SPLIT = NLPS_K2_SPLIT, K3_SPLIT = NLPS_K3_SPLIT, K5_SPLIT = NLPS_K5_SPLIT;
 
 struct TileD {
@@ -77,6 +80,14 @@ struct TileD {
   // Consecutive workgroups go to different XCDs, so a compacted list spreads the populated tiles evenly over
   // the 8 XCDs whatever the shape of the cloud (tile-index order left XCDs 23 % apart for the cube).
   const int2* work[2];
+  // Tail-split work list (single launch over all tiles, no boundary-first order): hyb = the non-empty tiles, those with
+  // more than BLK particles ("big") first; hyb_n = {number of big, number of small}.  A kernel with `hyb_slots`
+  // workgroup slots on the chip (CUs x resident workgroups) runs whole big tiles for as many FULL rounds of slots as
+  // there are, then the remaining big tiles as two half-lists each, then the small tiles: the last, partially filled
+  // round is made of short work items (tile_work_item).  hyb_slots = 0: the plain lists above.
+  const int* hyb;
+  const int* hyb_n;
+  int hyb_slots;
   // Workgroup range of the launch inside work[S-1]: {begin, end} at range[2*(S-1)].  The lists hold the tiles whose
   // window touches a ghost band (nodes shared with a neighbouring rank) first, so a launch can take all tiles,
   // only the "boundary" ones or only the "interior" ones (overlap of the halo exchange with interior work).
@@ -114,6 +125,49 @@ __device__ __forceinline__ void tile_signal(const TileD& td, int wb, int nb) {
 __device__ __forceinline__ void tile_signal_empty(const TileD& td, int nb) {
   if (td.sig_flag && nb == 0 && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(td.sig_flag, td.sig_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Work item of this workgroup: tile, part and the number of parts its tile list is dealt into (see TileD::hyb).
+// At 1 M particles (2197 occupied tiles, 1728 of them full, 768 slots for K2 / K3): 2 rounds of whole tiles, then
+// 192 x 2 half tiles + 469 partly filled ones instead of a third round as long as the first two.
+struct TileWork {
+  int tile, part, nparts, wb;
+};
+template <int SPLIT>
+__device__ __forceinline__ bool tile_work_item(const TileD& td, TileWork& w) {
+  if (td.hyb_slots > 0) {
+    const int nbig = td.hyb_n[0], nsm = td.hyb_n[1], slots = td.hyb_slots;
+    int F = (nbig / slots) * slots, r = nbig - F;
+    if (r == 0 || 2 * r + nsm > slots + slots / 4) {  // nothing left over, or the halves would need a round of their own
+      F = nbig;
+      r = 0;
+    }
+    const int b = (int)blockIdx.x;
+    w.wb = b;
+    if (b < F) {
+      w.tile = td.hyb[b];
+      w.part = 0;
+      w.nparts = 1;
+    } else if (b < F + 2 * r) {
+      w.tile = td.hyb[F + ((b - F) >> 1)];
+      w.part = (b - F) & 1;
+      w.nparts = 2;
+    } else if (b < F + 2 * r + nsm) {
+      w.tile = td.hyb[nbig + (b - F - 2 * r)];
+      w.part = 0;
+      w.nparts = 1;
+    } else {
+      return false;
+    }
+    return true;
+  }
+  w.wb = td.range[2 * (SPLIT - 1)] + (int)blockIdx.x;
+  if (w.wb >= td.range[2 * (SPLIT - 1) + 1]) return false;
+  const int2 wk = td.work[SPLIT - 1][w.wb];
+  w.tile = wk.x;
+  w.part = wk.y;
+  w.nparts = SPLIT;
+  return true;
 }
 
 // Developer profiling: wall-clock cycles per kernel phase, summed per wave (slot spread over 1024 rows to keep
@@ -234,6 +288,7 @@ struct TileScanArgs {
   int n, tile0, tpl, TB, band_lo, band_hi;
   int2 *work1, *work2;
   int* ranges;
+  int* hyb;  // tail-split list (TileD::hyb); its two counts go to ranges[12], ranges[13]
 };
 __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   const int* __restrict__ count = a.count;
@@ -263,11 +318,16 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   int run = block_scan_1024(c, sh, &tot);
   int rb1 = block_scan_1024(b1, sh, &nb1);
   int rb2 = block_scan_1024(b2, sh, &nb2);
-  int ri1 = block_scan_1024(i1, sh, &ni1) + nb1;
-  int ri2 = block_scan_1024(i2, sh, &ni2) + nb2;
+  int ri1 = block_scan_1024(i1, sh, &ni1);
+  int ri2 = block_scan_1024(i2, sh, &ni2);
+  // big (more than BLK particles: the second part of the split list exists) / small tiles before this thread's chunk
+  int hb = (rb2 - rb1) + (ri2 - ri1), hs = rb1 + ri1 - hb;
+  const int nbig = (nb2 - nb1) + (ni2 - ni1);
+  ri1 += nb1;
+  ri2 += nb2;
   if (threadIdx.x == 0) {
-    const int r[12] = {0, nb1 + ni1, 0, nb2 + ni2, 0, nb1, 0, nb2, nb1, nb1 + ni1, nb2, nb2 + ni2};
-    for (int k = 0; k < 12; k++) ranges[k] = r[k];
+    const int r[14] = {0, nb1 + ni1, 0, nb2 + ni2, 0, nb1, 0, nb2, nb1, nb1 + ni1, nb2, nb2 + ni2, nbig, nb1 + ni1 - nbig};
+    for (int k = 0; k < 14; k++) ranges[k] = r[k];
   }
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
@@ -280,7 +340,12 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
       int& r2 = bnd ? rb2 : ri2;
       work1[r1++] = make_int2(tile0 + q, 0);
       work2[r2++] = make_int2(tile0 + q, 0);
-      if (cq > BLK) work2[r2++] = make_int2(tile0 + q, 1);
+      if (cq > BLK) {
+        work2[r2++] = make_int2(tile0 + q, 1);
+        a.hyb[hb++] = tile0 + q;
+      } else {
+        a.hyb[nbig + hs++] = tile0 + q;
+      }
     }
   }
 }
@@ -423,12 +488,11 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
   constexpr int KN = Lme<ND>::KN;
   __shared__ double acc[NF * NWA];
   __shared__ unsigned actrow[NROWS];
-  const int wb = td.range[2 * (SPLIT - 1)] + (int)blockIdx.x;
   const int nbnd = td.sig_flag ? td.range[4 + 2 * (SPLIT - 1) + 1] : 0;  // boundary workgroups come first (cls 0 view)
   tile_signal_empty(td, nbnd);
-  if (wb >= td.range[2 * (SPLIT - 1) + 1]) return;
-  const int2 wk = td.work[SPLIT - 1][wb];
-  const int tile = wk.x, part = wk.y;
+  TileWork tw;
+  if (!tile_work_item<SPLIT>(td, tw)) return;
+  const int wb = tw.wb, tile = tw.tile, part = tw.part, nparts = tw.nparts;
   const int cnt = td.count[tile];
   PH_INIT
   int w0[3];
@@ -446,7 +510,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
   __syncthreads();
   const int start = td.start[tile];
   PH(0)
-  for (int s = part * NT + threadIdx.x; s < cnt; s += NT * SPLIT) {
+  for (int s = part * NT + threadIdx.x; s < cnt; s += NT * nparts) {
     const int p = td.order[start + s];
     Lme<ND> c;
     double x[ND], lam[ND];
@@ -677,12 +741,11 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
   __shared__ double duz[(ND == 3) ? NW : 1];
   constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
   __shared__ double fac[ND * NWA];
-  const int wb = td.range[2 * (K3_SPLIT - 1)] + (int)blockIdx.x;
   const int nbnd = (MODE == 1 && td.sig_flag) ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;
   if (MODE == 1) tile_signal_empty(td, nbnd);
-  if (wb >= td.range[2 * (K3_SPLIT - 1) + 1]) return;
-  const int2 wk = td.work[K3_SPLIT - 1][wb];
-  const int tile = wk.x, part = wk.y;
+  TileWork tw;
+  if (!tile_work_item<K3_SPLIT>(td, tw)) return;
+  const int wb = tw.wb, tile = tw.tile, part = tw.part, nparts = tw.nparts;
   int cnt = td.count[tile];
   PH_INIT
   constexpr int SELCAP = FILT ? 4096 : 1;
@@ -752,7 +815,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
   const double2* dv2 = reinterpret_cast<const double2*>(dvxy);
   const int start = td.start[tile];
   PH(8)
-  for (int s = part * NT + threadIdx.x; s < cnt; s += NT * K3_SPLIT) {
+  for (int s = part * NT + threadIdx.x; s < cnt; s += NT * nparts) {
     const int p = (FILT && listed) ? sel[FILT ? s : 0] : td.order[start + s];
     if (FILT && !listed && mats[P.mat[p]].type != LAW) continue;  // oversized tile: filter per lane
     Lme<ND> c;
@@ -1216,10 +1279,9 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ __attribute__((aligned(16))) double axy[2 * NW];
   __shared__ double az[(ND == 3) ? NW : 1];
-  const int wb = td.range[2 * (K5_SPLIT - 1)] + (int)blockIdx.x;
-  if (wb >= td.range[2 * (K5_SPLIT - 1) + 1]) return;
-  const int2 wk = td.work[K5_SPLIT - 1][wb];
-  const int tile = wk.x, part = wk.y;
+  TileWork tw;
+  if (!tile_work_item<K5_SPLIT>(td, tw)) return;
+  const int tile = tw.tile, part = tw.part, nparts = tw.nparts;
   const int cnt = td.count[tile];
   int w0[3];
   tile_origin<ND>(td, tile, w0);
@@ -1233,7 +1295,7 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
   __syncthreads();
   const double2* a2 = reinterpret_cast<const double2*>(axy);
   const int start = td.start[tile];
-  for (int s = part * K5_BLK + threadIdx.x; s < cnt; s += K5_BLK * K5_SPLIT) {
+  for (int s = part * K5_BLK + threadIdx.x; s < cnt; s += K5_BLK * nparts) {
     const int p = td.order_m[start + s];
     Lme<ND> c;
     double lam[ND], beta;
@@ -1243,6 +1305,17 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
     double Z = 0.0, sv[ND];
 #pragma unroll
     for (int a = 0; a < ND; a++) sv[a] = 0.0;
+#if NLPS_K5_PREFETCH
+    // the operands of the corrector are requested before the gather loop, so that their latency runs under it
+    double dd_[ND], vel_[ND], dis_[ND];
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      dd_[a] = PF(P, F_DDIS + a, p);
+      vel_[a] = PF(P, F_VEL + a, p);
+      dis_[a] = PF(P, F_DIS + a, p);
+    }
+    const double jn1_ = PF(P, F_JN1, p);
+#endif
 #pragma unroll NLPS_KUNROLL_K5
     for (int k = 0; k < KN; k++) {
       const unsigned pb = plane_bits<ND>(c, k);
@@ -1274,13 +1347,25 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
     const double Zinv = 1.0 / Z;
 #pragma unroll
     for (int a = 0; a < ND; a++) {
+#if NLPS_K5_PREFETCH
+      const double dd = dd_[a], av = sv[a] * Zinv;
+      PF(P, F_ACC + a, p) = av;
+      PF(P, F_VEL + a, p) = vel_[a] + gamma_nm * dt * av;
+      PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
+      PF(P, F_DIS + a, p) = dis_[a] + dd;
+#else
       const double dd = PF(P, F_DDIS + a, p), av = sv[a] * Zinv;
       PF(P, F_ACC + a, p) = av;
       PF(P, F_VEL + a, p) = PF(P, F_VEL + a, p) + gamma_nm * dt * av;
       PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
       PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
+#endif
     }
+#if NLPS_K5_PREFETCH
+    PF(P, F_JN, p) = jn1_;
+#else
     PF(P, F_JN, p) = PF(P, F_JN1, p);
+#endif
     // F_n <- F_n+1 and b_e,n <- b_e,n+1 (U-Verlet.c:1062-1075) cost no traffic: the host swaps the roles of
     // the two slots after this kernel (PView::flip); the stale slot is rewritten in full by the next K3.
     if (LAW != NLPS_MAT_NEO_HOOKEAN && LAW != NLPS_MAT_HENCKY) {
