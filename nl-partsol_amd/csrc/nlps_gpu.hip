@@ -2304,7 +2304,7 @@ static void arm_signal(nlps_gpu* h, TileD& td, int stage) {
 // lists hold the boundary tiles first; not the deterministic mode, one slab per tile)
 template <typename K>
 static int tail_slots(nlps_gpu* h, K kernel, int block, int cls) {
-  if (!h->tail_split || h->overlap != 0 || h->deterministic || cls != 0) return 0;
+  if (!h->tail_split || h->overlap != 0 || h->deterministic || cls != 0 || h->ntw >= 65536) return 0;  // 16-bit class counters
   const void* key = (const void*)kernel;
   auto it = h->kslots.find(key);
   if (it != h->kslots.end()) return it->second;

@@ -277,11 +277,40 @@ __device__ __forceinline__ int block_scan_1024(int v, int* sh, int* total) {
   return base + incl - v;
 }
 
+// the same for four 16-bit counters packed into one 64-bit word (sums below 65536 each)
+__device__ __forceinline__ unsigned long long block_scan_1024_u64(unsigned long long v, unsigned long long* sh,
+                                                                  unsigned long long* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) sh[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const unsigned long long t = sh[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
 // exclusive scan of the per-tile particle counts + the compacted work lists (one 1024-thread block).
 // count/start are already offset to the first tile of the node window; tile0 = that tile's index.
 // A tile is "boundary" when its node window reaches a ghost band: slow-axis layers <= band_lo or >= band_hi
 // (tpl = tiles per slow-axis tile layer, TB = tile edge).  ranges[cls][S-1] = {begin, end} in work<S> for
 // cls 0 = all, 1 = boundary, 2 = interior.
+// size class of a tile in the tail-split list: 0..2 = more than BLK particles (can be dealt to two workgroups), largest
+// first, so that what is left for the last round of workgroups are the lighter tiles; 3 = one pass of BLK lanes at most
+__device__ __forceinline__ int hyb_class(int cnt) {
+  return cnt > BLK + 3 * BLK / 4 ? 0 : (cnt > BLK + BLK / 4 ? 1 : (cnt > BLK ? 2 : 3));
+}
 struct TileScanArgs {
   const int* count;
   int* start;
@@ -300,9 +329,11 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   __shared__ int sh[1024];
   int chunk = (n + 1023) / 1024;
   int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0, b1 = 0, b2 = 0, i1 = 0, i2 = 0;
+  unsigned long long hc = 0;  // tail-split list: tiles per size class (TileD::hyb), 16 bits each
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
     c += cq;
+    if (cq > 0) hc += 1ull << (16 * hyb_class(cq));
     const int tz = (tile0 + q) / tpl;
     const bool bnd = (tz * TB - 2 <= band_lo) || (tz * TB + TB + 1 >= band_hi);
     const int e1 = cq > 0, e2 = (cq > 0) + (cq > BLK);
@@ -316,13 +347,31 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   }
   int nb1, nb2, ni1, ni2, tot;
   int run = block_scan_1024(c, sh, &tot);
-  int rb1 = block_scan_1024(b1, sh, &nb1);
-  int rb2 = block_scan_1024(b2, sh, &nb2);
-  int ri1 = block_scan_1024(i1, sh, &ni1);
-  int ri2 = block_scan_1024(i2, sh, &ni2);
-  // big (more than BLK particles: the second part of the split list exists) / small tiles before this thread's chunk
-  int hb = (rb2 - rb1) + (ri2 - ri1), hs = rb1 + ri1 - hb;
-  const int nbig = (nb2 - nb1) + (ni2 - ni1);
+  __shared__ unsigned long long sh64[16];
+  int rb1, rb2, ri1, ri2;
+  if (n < 32768) {  // the four list counters as 16-bit fields of one scan (each sum is below 2 n)
+    unsigned long long wt;
+    const unsigned long long wp = block_scan_1024_u64((unsigned long long)b1 | ((unsigned long long)b2 << 16) |
+                                                          ((unsigned long long)i1 << 32) | ((unsigned long long)i2 << 48),
+                                                      sh64, &wt);
+    rb1 = (int)(wp & 0xFFFFull), rb2 = (int)((wp >> 16) & 0xFFFFull), ri1 = (int)((wp >> 32) & 0xFFFFull), ri2 = (int)(wp >> 48);
+    nb1 = (int)(wt & 0xFFFFull), nb2 = (int)((wt >> 16) & 0xFFFFull), ni1 = (int)((wt >> 32) & 0xFFFFull), ni2 = (int)(wt >> 48);
+  } else {
+    rb1 = block_scan_1024(b1, sh, &nb1);
+    rb2 = block_scan_1024(b2, sh, &nb2);
+    ri1 = block_scan_1024(i1, sh, &ni1);
+    ri2 = block_scan_1024(i2, sh, &ni2);
+  }
+  unsigned long long htot;
+  const unsigned long long hpre = block_scan_1024_u64(hc, sh64, &htot);
+  // position of this thread's first tile of every class: classes in descending size, tile order inside a class
+  int hpos[4], hbase = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    hpos[k] = hbase + (int)((hpre >> (16 * k)) & 0xFFFFull);
+    hbase += (int)((htot >> (16 * k)) & 0xFFFFull);
+  }
+  const int nbig = hbase - (int)((htot >> 48) & 0xFFFFull);  // classes 0..2 hold more than BLK particles
   ri1 += nb1;
   ri2 += nb2;
   if (threadIdx.x == 0) {
@@ -340,12 +389,10 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
       int& r2 = bnd ? rb2 : ri2;
       work1[r1++] = make_int2(tile0 + q, 0);
       work2[r2++] = make_int2(tile0 + q, 0);
-      if (cq > BLK) {
-        work2[r2++] = make_int2(tile0 + q, 1);
-        a.hyb[hb++] = tile0 + q;
-      } else {
-        a.hyb[nbig + hs++] = tile0 + q;
-      }
+      if (cq > BLK) work2[r2++] = make_int2(tile0 + q, 1);
+      const int k = hyb_class(cq);
+      const int at = (k == 0) ? hpos[0]++ : (k == 1) ? hpos[1]++ : (k == 2) ? hpos[2]++ : hpos[3]++;
+      a.hyb[at] = tile0 + q;
     }
   }
 }
