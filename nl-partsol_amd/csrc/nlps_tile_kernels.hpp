@@ -390,9 +390,11 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
       work1[r1++] = make_int2(tile0 + q, 0);
       work2[r2++] = make_int2(tile0 + q, 0);
       if (cq > BLK) work2[r2++] = make_int2(tile0 + q, 1);
-      const int k = hyb_class(cq);
-      const int at = (k == 0) ? hpos[0]++ : (k == 1) ? hpos[1]++ : (k == 2) ? hpos[2]++ : hpos[3]++;
-      a.hyb[at] = tile0 + q;
+      if (n < 65536) {  // 16-bit class counters: larger windows run the plain lists (tail_slots)
+        const int k = hyb_class(cq);
+        const int at = (k == 0) ? hpos[0]++ : (k == 1) ? hpos[1]++ : (k == 2) ? hpos[2]++ : hpos[3]++;
+        a.hyb[at] = tile0 + q;
+      }
     }
   }
 }
