@@ -81,7 +81,7 @@ __host__ __device__ __forceinline__ int fBEN1(const PView& P) { return P.flip ? 
 
 struct NView {
   unsigned char* active;  // [nnodes]
-  unsigned char* seed;    // [nnodes] 1 where some particle has this node as I0 (k_dilate turns it into `active`)
+  unsigned char* seed;    // [nnodes] 1 where some particle has this node as I0 (dilate_node turns it into `active`)
   const double* h_avg;    // [nnodes]
   double* nm;             // [nnodes][1+ND]
   double* dU;             // [nnodes][ND]
@@ -986,7 +986,7 @@ struct nlps_gpu {
   int tail_split = 1;            // developer switch NLPS_TAIL_SPLIT
   int ncu = 256;                 // compute units of the device
   std::map<const void*, int> kslots;  // resident workgroups on the chip, per kernel (slots_of)
-  int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists (k_tile_scan)
+  int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists + the two counts of the tail-split list (tile_scan_block)
   int *dmg_first_d = nullptr, *dmg_last_d = nullptr;  // eigenerosion: run of every node in the I0-sorted particle list
   double* slab_d = nullptr; // P2G window slabs [ntiles][K2_SPLIT][1+ND][NW] (TileD::slab), deterministic mode only
   bool deterministic = false;

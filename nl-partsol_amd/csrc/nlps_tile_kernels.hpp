@@ -75,7 +75,7 @@ struct TileD {
   const int* count;
   const int* order;   // tile lists: canonical (layer, closest node) order when per-tile ordering is on (K2, K3)
   const int* order_m; // tile lists as binned: runs of memory-consecutive particles (K5 and the level-B gathers)
-  // compacted work lists (k_tile_scan): work[S-1][b] = (tile, part) for the b-th workgroup of a kernel that
+  // compacted work lists (tile_scan_block): work[S-1][b] = (tile, part) for the b-th workgroup of a kernel that
   // splits a tile's particles over S workgroups, only for non-empty (tile, part) pairs; nwork[S-1] entries.
   // Consecutive workgroups go to different XCDs, so a compacted list spreads the populated tiles evenly over
   // the 8 XCDs whatever the shape of the cloud (tile-index order left XCDs 23 % apart for the cube).
@@ -102,7 +102,7 @@ struct TileD {
   unsigned sig_seq;
 };
 
-// see TileD::sig_flag.  nb = number of boundary workgroups of this launch (device-side, from k_tile_scan's ranges);
+// see TileD::sig_flag.  nb = number of boundary workgroups of this launch (device-side, from the tile scan.s ranges);
 // called by all threads of a workgroup after its global flush
 __device__ __forceinline__ void tile_signal(const TileD& td, int wb, int nb) {
   if (!td.sig_flag || wb >= nb) return;
