@@ -984,6 +984,7 @@ struct nlps_gpu {
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int* hyb_d = nullptr;          // tail-split list (TileD::hyb)
   int tail_split = 1;            // developer switch NLPS_TAIL_SPLIT
+  int resort_from_lists = 1;     // developer switch NLPS_RESORT_FROM_LISTS (resort)
   int ncu = 256;                 // compute units of the device
   std::map<const void*, int> kslots;  // resident workgroups on the chip, per kernel (slots_of)
   int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists + the two counts of the tail-split list (tile_scan_block)
@@ -1340,6 +1341,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->P.erosion = prm->driver_eigenerosion != 0;
   if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
   if (const char* e = getenv("NLPS_TAIL_SPLIT")) h->tail_split = atoi(e);        // developer switch, see TileD::hyb
+  if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
   {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1558,16 +1560,24 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
 static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live_only = false) {
   const int np = h->P.np;
   if (np == 0) return 0;
-  TileCnt tc;
-  for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
-  tc.count = nullptr;
-  if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
-  else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
-  HIPCHK(hipGetLastError());
-  size_t bytes = h->cub_tmp_bytes;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
-                                            h->stream));
-  const int* idx = h->sval2_d;  // new slot -> old slot
+  // The tile lists of the last step in canonical order (k_tile_order: layer r = the r-th particle of every closest node,
+  // nodes in lattice order) ARE the memory order the kernels want -- each wave then reads 64 consecutive slots that hit
+  // 64 distinct window rows -- so the periodic re-sort of the fused step takes them as its permutation: no keys, no
+  // radix sort.  Otherwise (first sort, migration, level-B callers): sort by (tile, corner type, node).
+  const bool from_lists = !leaving && live_only && h->binned && h->order2_d && (h->tile_ordering || h->deterministic) &&
+                          h->resort_from_lists;
+  if (!from_lists) {
+    TileCnt tc;
+    for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
+    tc.count = nullptr;
+    if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
+    else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
+    HIPCHK(hipGetLastError());
+    size_t bytes = h->cub_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
+                                              h->stream));
+  }
+  const int* idx = from_lists ? h->order2_d : h->sval2_d;  // new slot -> old slot
   const size_t npad = h->P.npad;
   const int nf = h->level_b_fields ? (int)NFD : (int)F_CEP;  // C_ep and the rate tensors only exist for level B
   // the field block moves into its twin in one launch and the two swap roles (no copy back; the twin costs a second

@@ -24,6 +24,7 @@ ap.add_argument("--phases", action="store_true")
 ap.add_argument("--no-order", action="store_true")
 ap.add_argument("--det", action="store_true", help="deterministic mode")
 ap.add_argument("--stir", type=int, default=0, help="untimed shear steps first (DESIGN.md stirred cloud)")
+ap.add_argument("--resort", action="store_true", help="one periodic re-sort of the fused step before the timed steps")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("NLPS_GPU_LIB", "product")))
 a = ap.parse_args()
 nlps = importlib.import_module("nl-partsol_amd.nlps")
@@ -74,6 +75,11 @@ if a.stir:
         S.explicit_step(bcs, 0, dt)
 for t in range(5):
     S.explicit_step(bcs, t, dt, 0.5, grav)
+if a.resort:
+    S.set_resort_interval(1)
+    for t in range(2):
+        S.explicit_step(bcs, 4, dt, 0.5, grav)
+    S.set_resort_interval(0)
 if a.phases:
     S.L.nlps_gpu_debug_phases.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     out = np.zeros(32, dtype=np.uint64)
