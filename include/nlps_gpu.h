@@ -216,6 +216,13 @@ int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force
  * every `every_n_steps` steps (default 50, 0 = never). */
 int nlps_gpu_resort(nlps_gpu *h);
 int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
+/* Adaptive re-sort of the fused explicit step (off by default): the search stage counts the particles that are no
+ * longer in the tile their memory slot was sorted into; every step adds that share of the cloud to a debt, and when
+ * the debt since the last re-sort exceeds `budget` (and at least min_steps steps have passed) the step re-sorts ahead
+ * of the interval above.  budget = 0 switches it off; an interval of 0 switches every re-sort off.  A budget of 0.6
+ * is about the cost of one re-sort in units of the slowdown displaced particles cause.  No reference
+ * counterpart (the CPU path has no memory order to keep). */
+int nlps_gpu_set_adaptive_resort(nlps_gpu *gpu, double budget, int min_steps);
 
 /* ------------------------------------------------------------------ multi-GPU: ghost-layer exchange over RCCL, owned by
  * the library.  One process per GPU; the particles are range-partitioned into slabs along the slowest grid

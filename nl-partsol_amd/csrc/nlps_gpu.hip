@@ -105,6 +105,12 @@ struct TileCnt {
   int tile0, ntw;   // tiles of the node window (nlps_gpu_set_node_window); default: all
   int win_lo, win_hi, plane;  // node layers (slowest axis) of the window, nodes per layer
   int* gstatus;
+  // adaptive re-sort (nlps_gpu_set_adaptive_resort), nullptr = off: home[slot] = tile of the particle in that memory
+  // slot at the first search after the last re-sort (rehome != 0: this search records it); foreign = 64 counters,
+  // 128 B apart, of the particles found in another tile than their slot's home
+  int* home;
+  int rehome;
+  int* foreign;
 };
 template <int ND>
 struct TileCfg;
@@ -151,6 +157,15 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
   if (p < P.np) {
     P.tile[p] = t;  // -1: not binned (failed element search or outside the node window)
     P.rank[p] = rank;
+  }
+  if (tc.home) {
+    bool away = false;
+    if (p < P.np) {
+      if (tc.rehome) tc.home[p] = t;
+      else away = t != tc.home[p];
+    }
+    const u64 m = __ballot(away);
+    if (lane == 0 && m) atomicAdd(&tc.foreign[32 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63)], (int)__popcll(m));
   }
 }
 
@@ -777,8 +792,16 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 // too small to fill the chip: 8 us + 10 us -> 10 us): workgroup 0 = exclusive scan of the tile counts + work lists
 // (tile_scan_block), the others = 1-ring activation of 1024 nodes each.
 template <int ND>
-__global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD g, NView N, TileScanArgs ts) {
+__global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD g, NView N, TileScanArgs ts,
+                                                      int* __restrict__ foreign, int* __restrict__ foreign_host) {
   if (blockIdx.x == 0) {
+    if (foreign && threadIdx.x < 64) {  // this step's count of displaced particles (bin_particle) -> pinned host word
+      int v = foreign[32 * threadIdx.x];
+      foreign[32 * threadIdx.x] = 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (threadIdx.x == 0) *foreign_host = v;
+    }
     tile_scan_block(ts);
     return;
   }
@@ -985,6 +1008,15 @@ struct nlps_gpu {
   int* hyb_d = nullptr;          // tail-split list (TileD::hyb)
   int tail_split = 1;            // developer switch NLPS_TAIL_SPLIT
   int resort_from_lists = 1;     // developer switch NLPS_RESORT_FROM_LISTS (resort)
+  // adaptive re-sort (nlps_gpu_set_adaptive_resort): see TileCnt::home.  The count of displaced particles of a step
+  // reaches the pinned host word at the end of its search stage; explicit_step adds count / NumGP to `debt` every
+  // step and re-sorts ahead of the interval when the debt since the last re-sort exceeds `adaptive_resort`
+  int* home_d = nullptr;
+  int* foreign_d = nullptr;
+  int* foreign_h = nullptr;
+  bool rehome = true;
+  double adaptive_resort = 0.8, debt = 0.0;  // default budget: about one re-sort's cost
+  int adaptive_min_steps = 4;
   int ncu = 256;                 // compute units of the device
   std::map<const void*, int> kslots;  // resident workgroups on the chip, per kernel (slots_of)
   int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists + the two counts of the tail-split list (tile_scan_block)
@@ -1482,6 +1514,11 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
   if (dev_alloc(h, &h->hyb_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->nwork_d, 16)) return 1;
+  if (const char* e = getenv("NLPS_ADAPTIVE_RESORT")) h->adaptive_resort = atof(e);  // developer switch (0 = off)
+  if (dev_alloc(h, &h->home_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->foreign_d, 64 * 32)) return 1;
+  HIPCHK(hipHostMalloc((void**)&h->foreign_h, sizeof(int), hipHostMallocDefault));
+  *h->foreign_h = 0;
 #if NLPS_PHASE_TIMING
   if (dev_alloc(h, &h->phase_d, 16 * 1024)) return 1;
 #endif
@@ -1570,6 +1607,7 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
     TileCnt tc;
     for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
     tc.count = nullptr;
+    tc.home = nullptr;
     if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
     else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
     HIPCHK(hipGetLastError());
@@ -1618,6 +1656,8 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
   h->perm_dirty = true;
   h->binned = false;
   h->steps_since_sort = 0;
+  h->rehome = true;  // the slots have new owners: the next search records their tiles
+  h->debt = 0.0;
   return 0;
 }
 
@@ -1755,11 +1795,30 @@ extern "C" int nlps_gpu_set_law_launch_mode(nlps_gpu* h, int mode) {
 }
 extern "C" int nlps_gpu_set_deterministic(nlps_gpu* h, int on) {
   h->deterministic = on != 0;
+  h->rehome = true;
+  h->debt = 0.0;
   return 0;
 }
 extern "C" int nlps_gpu_set_resort_interval(nlps_gpu* h, int every_n_steps) {
   h->resort_every = every_n_steps;
   h->steps_since_sort = 0;  // the interval counts from this call
+  return 0;
+}
+extern "C" int nlps_gpu_set_adaptive_resort(nlps_gpu* h, double budget, int min_steps) {
+  if (budget < 0.0 || min_steps < 1) {
+    h->err = "nlps_gpu_set_adaptive_resort: budget >= 0 (0 = off), min_steps >= 1";
+    return 1;
+  }
+  h->adaptive_resort = budget;
+  h->adaptive_min_steps = min_steps;
+  h->rehome = true;
+  h->debt = 0.0;
+  return 0;
+}
+extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_displaced(nlps_gpu* h, int* count, double* debt) {
+  HIPCHK(hipStreamSynchronize(h->stream));  // developer read-out: the count of the last completed search stage
+  *count = h->foreign_h ? *(volatile int*)h->foreign_h : 0;
+  *debt = h->debt;
   return 0;
 }
 
@@ -1771,11 +1830,12 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->hyb_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
     if (b.dnodes) (void)hipFree(b.dnodes);
+  if (h->foreign_h) (void)hipHostFree(h->foreign_h);
   for (int i = 0; i < 8; i++) (void)hipEventDestroy(h->ev[i]);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -2256,6 +2316,15 @@ static TileCnt tile_cnt(nlps_gpu* h, bool on) {
   tc.win_hi = h->win_hi;
   tc.plane = h->g.nnodes / h->g.n[h->nd - 1];
   tc.gstatus = h->gstatus_d;
+  tc.home = nullptr;
+  tc.rehome = 0;
+  tc.foreign = nullptr;
+  if (on && h->adaptive_resort > 0.0 && !h->deterministic) {
+    tc.home = h->home_d;
+    tc.foreign = h->foreign_d;
+    tc.rehome = h->rehome ? 1 : 0;
+    h->rehome = false;
+  }
   return tc;
 }
 static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 boundary, 2 interior
@@ -2366,8 +2435,9 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
     TileScanArgs ts{h->tile_count_d + h->tile0, h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB,
                     h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d, h->hyb_d};
     const int nb = 1 + (h->nwn + 1023) / 1024;
-    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts);
-    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts);
+    int* fo = (h->adaptive_resort > 0.0 && !h->deterministic) ? h->foreign_d : nullptr;
+    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h);
+    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h);
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.active, 1, 1, 1, overlap ? 1 : 0)) return 1;
@@ -2800,7 +2870,16 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   if (nbcc > 0 && check_step(h, step, "nlps_gpu_explicit_step")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
-  if (h->resort_every > 0 && h->steps_since_sort >= h->resort_every) {
+  // periodic re-sort; earlier when enough particles have left the tiles their memory slots were sorted into: the count
+  // of a recent step sits in the pinned word (no synchronisation: it may be a step old), its share of the cloud is this
+  // step's cost estimate, and the re-sort comes when the estimates since the last one add up to the budget
+  bool drifted = false;
+  if (h->adaptive_resort > 0.0 && !h->deterministic && h->resort_every > 0 && h->P.np > 0) {  // (a re-sort moment read
+    // from an asynchronous word is not reproducible: the deterministic mode keeps the fixed interval)
+    h->debt += (double)*(volatile int*)h->foreign_h / (double)h->P.np;
+    drifted = h->debt > h->adaptive_resort && h->steps_since_sort >= h->adaptive_min_steps;
+  }
+  if (h->resort_every > 0 && (h->steps_since_sort >= h->resort_every || drifted)) {
     if (resort(h, nullptr, true)) return 1;
   }
   h->steps_since_sort++;

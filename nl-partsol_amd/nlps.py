@@ -67,7 +67,7 @@ SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_g
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_nodal_traction_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
-           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_set_law_launch_mode", "nlps_gpu_set_deterministic",
+           "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_set_adaptive_resort", "nlps_gpu_set_law_launch_mode", "nlps_gpu_set_deterministic",
            "nlps_gpu_rccl_unique_id", "nlps_gpu_rccl_attach", "nlps_gpu_rccl_attach_comm", "nlps_gpu_rccl_detach",
            "nlps_gpu_rccl_reduce", "nlps_gpu_rccl_selftest_exchange", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_form_initial_guess", "nlps_gpu_nodal_kinetic_increments", "nlps_gpu_nodal_inertial_forces",
@@ -427,6 +427,16 @@ class Solver:
 
     def set_resort_interval(self, n):
         self._chk(self.L.nlps_gpu_set_resort_interval(self.h, int(n)))
+
+    def set_adaptive_resort(self, budget, min_steps=4):
+        self.L.nlps_gpu_set_adaptive_resort.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        self._chk(self.L.nlps_gpu_set_adaptive_resort(self.h, float(budget), int(min_steps)))
+
+    def debug_displaced(self):
+        v, d = C.c_int(0), C.c_double(0)
+        self.L.nlps_gpu_debug_displaced.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        self._chk(self.L.nlps_gpu_debug_displaced(self.h, C.byref(v), C.byref(d)))
+        return v.value, d.value
 
     def set_law_launch_mode(self, mode):
         self._chk(self.L.nlps_gpu_set_law_launch_mode(self.h, int(mode)))

@@ -25,6 +25,7 @@ ap.add_argument("--no-order", action="store_true")
 ap.add_argument("--det", action="store_true", help="deterministic mode")
 ap.add_argument("--stir", type=int, default=0, help="untimed shear steps first (DESIGN.md stirred cloud)")
 ap.add_argument("--resort", action="store_true", help="one periodic re-sort of the fused step before the timed steps")
+ap.add_argument("--adaptive", type=float, default=0.0, help="adaptive re-sort budget (also during the stir and the timed steps)")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("NLPS_GPU_LIB", "product")))
 a = ap.parse_args()
 nlps = importlib.import_module("nl-partsol_amd.nlps")
@@ -71,8 +72,14 @@ if a.stir:
     bcs = nlps.BccSet([])
     dt = 2e-3
     S.set_resort_interval(0)
+    if a.adaptive:
+        S.set_resort_interval(1000000)
+        S.set_adaptive_resort(a.adaptive)
     for t in range(a.stir):
         S.explicit_step(bcs, 0, dt)
+        if a.adaptive and t % 8 == 7:
+            c_, d_ = S.debug_displaced()
+            print("   stir step %d: displaced %.3f debt %.3f" % (t, c_ / case["cloud"]["x"].shape[0], d_), flush=True)
 for t in range(5):
     S.explicit_step(bcs, t, dt, 0.5, grav)
 if a.resort:
