@@ -1005,8 +1005,6 @@ struct nlps_gpu {
   int* tile_count_d;
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
-  int* hyb_d = nullptr;          // tail-split list (TileD::hyb)
-  int tail_split = 1;            // developer switch NLPS_TAIL_SPLIT
   int resort_from_lists = 1;     // developer switch NLPS_RESORT_FROM_LISTS (resort)
   // adaptive re-sort (nlps_gpu_set_adaptive_resort): see TileCnt::home.  The count of displaced particles of a step
   // reaches the pinned host word at the end of its search stage; explicit_step adds count / NumGP to `debt` every
@@ -1017,9 +1015,7 @@ struct nlps_gpu {
   bool rehome = true;
   double adaptive_resort = 0.8, debt = 0.0;  // default budget: about one re-sort's cost
   int adaptive_min_steps = 4;
-  int ncu = 256;                 // compute units of the device
-  std::map<const void*, int> kslots;  // resident workgroups on the chip, per kernel (slots_of)
-  int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists + the two counts of the tail-split list (tile_scan_block)
+  int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists (tile_scan_block)
   int *dmg_first_d = nullptr, *dmg_last_d = nullptr;  // eigenerosion: run of every node in the I0-sorted particle list
   double* slab_d = nullptr; // P2G window slabs [ntiles][K2_SPLIT][1+ND][NW] (TileD::slab), deterministic mode only
   bool deterministic = false;
@@ -1372,14 +1368,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->prm.max_iter_radial = prm->max_iter_radial_returning;
   h->P.erosion = prm->driver_eigenerosion != 0;
   if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
-  if (const char* e = getenv("NLPS_TAIL_SPLIT")) h->tail_split = atoi(e);        // developer switch, see TileD::hyb
   if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      h->ncu = prop.multiProcessorCount;
-  }
 
   h->tab = nlps_host::build_tables(g.nd);
   HIPCHK(hipMalloc((void**)&h->rank1_d, 27 * 27));
@@ -1512,7 +1501,6 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->tile_start_d, (size_t)h->ntiles + 1)) return 1;
   if (dev_alloc(h, &h->work1_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
-  if (dev_alloc(h, &h->hyb_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->nwork_d, 16)) return 1;
   if (const char* e = getenv("NLPS_ADAPTIVE_RESORT")) h->adaptive_resort = atof(e);  // developer switch (0 = off)
   if (dev_alloc(h, &h->home_d, h->P.npad)) return 1;
@@ -1829,7 +1817,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->hyb_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2341,9 +2329,6 @@ static TileD tile_view(nlps_gpu* h, int cls = 0) {  // cls: 0 all tiles, 1 bound
   td.sig_seq = 0;
   td.work[0] = h->work1_d;
   td.work[1] = h->work2_d;
-  td.hyb = h->hyb_d;
-  td.hyb_n = h->nwork_d + 12;
-  td.hyb_slots = 0;
   td.range = h->nwork_d + 4 * cls;
   td.phase = h->phase_d;
   td.start = h->tile_start_d;
@@ -2378,22 +2363,6 @@ static void arm_signal(nlps_gpu* h, TileD& td, int stage) {
   td.sig_seq = ++R->sig_seq;
 }
 
-// Workgroup slots of a tile kernel on this chip (CUs x resident workgroups), for the tail-split work list (TileD::hyb).
-// 0 = the plain lists: the split needs one launch over all tiles in no particular order (no overlapped exchange, whose
-// lists hold the boundary tiles first; not the deterministic mode, one slab per tile)
-template <typename K>
-static int tail_slots(nlps_gpu* h, K kernel, int block, int cls) {
-  if (!h->tail_split || h->overlap != 0 || h->deterministic || cls != 0 || h->ntw >= 65536) return 0;  // 16-bit class counters
-  const void* key = (const void*)kernel;
-  auto it = h->kslots.find(key);
-  if (it != h->kslots.end()) return it->second;
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb <= 0) {
-    (void)hipGetLastError();
-    nb = 0;
-  }
-  return h->kslots[key] = nb * h->ncu;
-}
 static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm, bool signal = false) {
   TileD td = tile_view(h, cls);
   if (signal) arm_signal(h, td, 0);
@@ -2406,8 +2375,7 @@ static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm
   const dim3 blk(BLK);
 #define NLPS_K2L(NDv, P2Gv)                                                                              \
   do {                                                                                                   \
-    td.hyb_slots = tail_slots(h, k2_tile<NDv, P2Gv>, BLK, (signal ? 1 : cls));                           \
-    hipLaunchKernelGGL((k2_tile<NDv, P2Gv>), dim3(h->ntw * K2_SPLIT + td.hyb_slots), blk, 0, h->stream, h->P, h->g, h->N, td, \
+    hipLaunchKernelGGL((k2_tile<NDv, P2Gv>), dim3(h->ntw * K2_SPLIT), blk, 0, h->stream, h->P, h->g, h->N, td,         \
                        h->prm, dt, gamma_nm, h->gstatus_d);                                              \
   } while (0)
   if (h->nd == 2) {
@@ -2433,7 +2401,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   {
     const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
     TileScanArgs ts{h->tile_count_d + h->tile0, h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB,
-                    h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d, h->hyb_d};
+                    h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d};
     const int nb = 1 + (h->nwn + 1023) / 1024;
     int* fo = (h->adaptive_resort > 0.0 && !h->deterministic) ? h->foreign_d : nullptr;
     if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h);
@@ -2962,10 +2930,8 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     }
 #define NLPS_K3(NDv, LAWv)                                                                                      \
   do {                                                                                                          \
-    td.hyb_slots = tail_slots(h, k3_tile<NDv, LAWv, 1>, K3_BLK, (signal ? 1 : cls));                            \
-    hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT + td.hyb_slots), dim3(K3_BLK), 0, h->stream, h->P, h->g, \
+    hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g,          \
                        h->N, td, h->mats_d, h->prm, h->gstatus_d, (const double*)nullptr);                      \
-    td.hyb_slots = 0;                                                                                           \
   } while (0)
 #define NLPS_K3D(NDv, LAWv)                                                                                     \
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1, true, 64>), dim3(h->ntw), dim3(64), 0, h->stream, h->P, h->g, h->N, td, \
@@ -3043,8 +3009,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     TileD td = tile_view(h, cls);
 #define NLPS_K5(NDv, LAWv)                                                                               \
   do {                                                                                                   \
-    td.hyb_slots = tail_slots(h, k5_tile<NDv, LAWv>, K5_BLK, cls);                                       \
-    hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT + td.hyb_slots), dim3(K5_BLK), 0, h->stream, h->P, h->g, \
+    hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g,      \
                        h->N, td, dt, gamma_nm);                                                          \
   } while (0)
     const int law = h->uniform_law;

@@ -80,14 +80,6 @@ struct TileD {
   // Consecutive workgroups go to different XCDs, so a compacted list spreads the populated tiles evenly over
   // the 8 XCDs whatever the shape of the cloud (tile-index order left XCDs 23 % apart for the cube).
   const int2* work[2];
-  // Tail-split work list (single launch over all tiles, no boundary-first order): hyb = the non-empty tiles, those with
-  // more than BLK particles ("big") first; hyb_n = {number of big, number of small}.  A kernel with `hyb_slots`
-  // workgroup slots on the chip (CUs x resident workgroups) runs whole big tiles for as many FULL rounds of slots as
-  // there are, then the remaining big tiles as two half-lists each, then the small tiles: the last, partially filled
-  // round is made of short work items (tile_work_item).  hyb_slots = 0: the plain lists above.
-  const int* hyb;
-  const int* hyb_n;
-  int hyb_slots;
   // Workgroup range of the launch inside work[S-1]: {begin, end} at range[2*(S-1)].  The lists hold the tiles whose
   // window touches a ghost band (nodes shared with a neighbouring rank) first, so a launch can take all tiles,
   // only the "boundary" ones or only the "interior" ones (overlap of the halo exchange with interior work).
@@ -127,40 +119,12 @@ __device__ __forceinline__ void tile_signal_empty(const TileD& td, int nb) {
     __hip_atomic_store(td.sig_flag, td.sig_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Work item of this workgroup: tile, part and the number of parts its tile list is dealt into (see TileD::hyb).
-// At 1 M particles (2197 occupied tiles, 1728 of them full, 768 slots for K2 / K3): 2 rounds of whole tiles, then
-// 192 x 2 half tiles + 469 partly filled ones instead of a third round as long as the first two.
+// Work item of this workgroup: tile, part and the number of parts its tile list is dealt into
 struct TileWork {
   int tile, part, nparts, wb;
 };
 template <int SPLIT>
 __device__ __forceinline__ bool tile_work_item(const TileD& td, TileWork& w) {
-  if (td.hyb_slots > 0) {
-    const int nbig = td.hyb_n[0], nsm = td.hyb_n[1], slots = td.hyb_slots;
-    int F = (nbig / slots) * slots, r = nbig - F;
-    if (r == 0 || 2 * r + nsm > slots + slots / 4) {  // nothing left over, or the halves would need a round of their own
-      F = nbig;
-      r = 0;
-    }
-    const int b = (int)blockIdx.x;
-    w.wb = b;
-    if (b < F) {
-      w.tile = td.hyb[b];
-      w.part = 0;
-      w.nparts = 1;
-    } else if (b < F + 2 * r) {
-      w.tile = td.hyb[F + ((b - F) >> 1)];
-      w.part = (b - F) & 1;
-      w.nparts = 2;
-    } else if (b < F + 2 * r + nsm) {
-      w.tile = td.hyb[nbig + (b - F - 2 * r)];
-      w.part = 0;
-      w.nparts = 1;
-    } else {
-      return false;
-    }
-    return true;
-  }
   w.wb = td.range[2 * (SPLIT - 1)] + (int)blockIdx.x;
   if (w.wb >= td.range[2 * (SPLIT - 1) + 1]) return false;
   const int2 wk = td.work[SPLIT - 1][w.wb];
@@ -306,18 +270,12 @@ __device__ __forceinline__ unsigned long long block_scan_1024_u64(unsigned long 
 // A tile is "boundary" when its node window reaches a ghost band: slow-axis layers <= band_lo or >= band_hi
 // (tpl = tiles per slow-axis tile layer, TB = tile edge).  ranges[cls][S-1] = {begin, end} in work<S> for
 // cls 0 = all, 1 = boundary, 2 = interior.
-// size class of a tile in the tail-split list: 0..2 = more than BLK particles (can be dealt to two workgroups), largest
-// first, so that what is left for the last round of workgroups are the lighter tiles; 3 = one pass of BLK lanes at most
-__device__ __forceinline__ int hyb_class(int cnt) {
-  return cnt > BLK + 3 * BLK / 4 ? 0 : (cnt > BLK + BLK / 4 ? 1 : (cnt > BLK ? 2 : 3));
-}
 struct TileScanArgs {
   const int* count;
   int* start;
   int n, tile0, tpl, TB, band_lo, band_hi;
   int2 *work1, *work2;
   int* ranges;
-  int* hyb;  // tail-split list (TileD::hyb); its two counts go to ranges[12], ranges[13]
 };
 __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   const int* __restrict__ count = a.count;
@@ -329,11 +287,9 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   __shared__ int sh[1024];
   int chunk = (n + 1023) / 1024;
   int lo = threadIdx.x * chunk, hi = min(n, lo + chunk), c = 0, b1 = 0, b2 = 0, i1 = 0, i2 = 0;
-  unsigned long long hc = 0;  // tail-split list: tiles per size class (TileD::hyb), 16 bits each
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
     c += cq;
-    if (cq > 0) hc += 1ull << (16 * hyb_class(cq));
     const int tz = (tile0 + q) / tpl;
     const bool bnd = (tz * TB - 2 <= band_lo) || (tz * TB + TB + 1 >= band_hi);
     const int e1 = cq > 0, e2 = (cq > 0) + (cq > BLK);
@@ -362,21 +318,11 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
     ri1 = block_scan_1024(i1, sh, &ni1);
     ri2 = block_scan_1024(i2, sh, &ni2);
   }
-  unsigned long long htot;
-  const unsigned long long hpre = block_scan_1024_u64(hc, sh64, &htot);
-  // position of this thread's first tile of every class: classes in descending size, tile order inside a class
-  int hpos[4], hbase = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    hpos[k] = hbase + (int)((hpre >> (16 * k)) & 0xFFFFull);
-    hbase += (int)((htot >> (16 * k)) & 0xFFFFull);
-  }
-  const int nbig = hbase - (int)((htot >> 48) & 0xFFFFull);  // classes 0..2 hold more than BLK particles
   ri1 += nb1;
   ri2 += nb2;
   if (threadIdx.x == 0) {
-    const int r[14] = {0, nb1 + ni1, 0, nb2 + ni2, 0, nb1, 0, nb2, nb1, nb1 + ni1, nb2, nb2 + ni2, nbig, nb1 + ni1 - nbig};
-    for (int k = 0; k < 14; k++) ranges[k] = r[k];
+    const int r[12] = {0, nb1 + ni1, 0, nb2 + ni2, 0, nb1, 0, nb2, nb1, nb1 + ni1, nb2, nb2 + ni2};
+    for (int k = 0; k < 12; k++) ranges[k] = r[k];
   }
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
@@ -390,11 +336,6 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
       work1[r1++] = make_int2(tile0 + q, 0);
       work2[r2++] = make_int2(tile0 + q, 0);
       if (cq > BLK) work2[r2++] = make_int2(tile0 + q, 1);
-      if (n < 65536) {  // 16-bit class counters: larger windows run the plain lists (tail_slots)
-        const int k = hyb_class(cq);
-        const int at = (k == 0) ? hpos[0]++ : (k == 1) ? hpos[1]++ : (k == 2) ? hpos[2]++ : hpos[3]++;
-        a.hyb[at] = tile0 + q;
-      }
     }
   }
 }

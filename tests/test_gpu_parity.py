@@ -1324,46 +1324,6 @@ def test_nodal_traction_forces(ndim):
     assert_close(R_g2, R_o2, 1e-10, "tractions after a re-sort")
 
 
-@pytest.mark.parametrize("material", [NH, DP])
-def test_tail_split_work_list_is_only_a_schedule(material, monkeypatch):
-    """The tail-split work list (TileD::hyb: tiles in size classes, largest first, the leftover big tiles of the last
-    round of workgroups dealt to two workgroups each) changes which workgroup takes which particles, never a result:
-    the same cloud stepped with the list and with the plain lists (developer switch NLPS_TAIL_SPLIT=0) agrees to the
-    rounding of the atomic accumulation order, and with the oracle.  27 k particles in 3-D: 64 full tiles of 512
-    particles and partly filled ones around them, far fewer than the chip has workgroup slots, so every big tile is
-    split."""
-    o = orc()
-    n = nlps()
-    vel = [0.5, -0.3, -2.0]
-    nsteps = 4
-    grav = [0.0, 0.0, -9.81]
-    E = material["E"]
-    dt = 0.1 / np.sqrt(E / 1000.0)
-
-    def run(split):
-        monkeypatch.setenv("NLPS_TAIL_SPLIT", "1" if split else "0")
-        case = make_case(3, [21, 21, 21], [3, 3, 3], [15, 15, 15], material=material, velocity=vel)
-        bcs_list = [dirichlet_plane(case, 2, 2, nsteps)]
-        S = gpu_setup(case, nsteps=nsteps)
-        gb = n.BccSet(bcs_list)
-        for t in range(nsteps):
-            S.explicit_step(gb, t, dt, 0.5, grav)
-        assert S.status_flags() == 0
-        return case, bcs_list, S.download_state()
-
-    case, bcs_list, a = run(True)
-    _, _, b = run(False)
-    assert np.array_equal(a["I0"], b["I0"])
-    for k in ("x", "vel", "acc", "F_n", "Stress", "rho", "lambda"):  # (W is a difference of near-equal terms here)
-        assert_close(a[k], b[k], 1e-11, f"tail-split on / off: {k}")
-    M, P, prm, mats = oracle_setup(case)
-    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet(bcs_list), nsteps, gravity=grav)
-    for t in range(nsteps):
-        assert stepper.step(t, dt) == 0
-    for k, ok in (("x", "x"), ("vel", "vel"), ("F_n", "F_n"), ("Stress", "stress")):
-        assert_close(a[k], P[ok], 1e-9, f"tail-split vs oracle: {k}")
-
-
 def test_adaptive_resort_only_moves_memory():
     """nlps_gpu_set_adaptive_resort: the search stage counts the particles that left the tile their memory slot was
     sorted into, the step re-sorts when their accumulated share exceeds the budget.  A sheared block (particles cross
