@@ -111,6 +111,10 @@ struct TileCnt {
   int* home;
   int rehome;
   int* foreign;
+  // canonical tile lists without a per-tile sort (k_fill_order): node_cnt[node] counts the particles of every closest
+  // node, nrank[p] = the rank of p inside its node (arrival order of the atomic); nullptr = off
+  int* node_cnt;
+  int* nrank;
 };
 template <int ND>
 struct TileCfg;
@@ -157,6 +161,9 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
   if (p < P.np) {
     P.tile[p] = t;  // -1: not binned (failed element search or outside the node window)
     P.rank[p] = rank;
+    // (the lanes of a wave mostly hold distinct closest nodes -- the memory order is the canonical one -- so these
+    // atomics spread over the node array)
+    if (tc.node_cnt) tc.nrank[p] = valid ? atomicAdd(&tc.node_cnt[I0], 1) : 0;
   }
   if (tc.home) {
     bool away = false;
@@ -187,12 +194,14 @@ __device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
 // One launch instead of five hipMemsetAsync (each of which costs one or two 5-us fill kernels): resets the
 // search seeds and tile counters and, for the fused explicit step, the nodal accumulators of the node window.
 template <int ND>
-__global__ void k_step_clear(int n0, int nnodes, NView N, int* __restrict__ tile_count, int ntiles, int nodal) {
+__global__ void k_step_clear(int n0, int nnodes, NView N, int* __restrict__ tile_count, int ntiles, int nodal,
+                             int* __restrict__ node_cnt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < ntiles) tile_count[t] = 0;
   if (t >= nnodes) return;
   const size_t A = (size_t)n0 + t;
   N.seed[A] = 0;  // Shape-Functions.c:38-46
+  if (node_cnt) node_cnt[A] = 0;
   if (nodal) {
 #pragma unroll
     for (int a = 0; a < 1 + ND; a++) N.nm[A * (1 + ND) + a] = 0.0;
@@ -791,9 +800,29 @@ __global__ void k_mark_fixed_masked(const int* __restrict__ nodes, int n, int di
 // The two kernels between the search and the tile lists in one launch (they do not depend on each other and both are
 // too small to fill the chip: 8 us + 10 us -> 10 us): workgroup 0 = exclusive scan of the tile counts + work lists
 // (tile_scan_block), the others = 1-ring activation of 1024 nodes each.
+// Layer tables of the canonical tile lists: layer r of a tile = the r-th particle of every node that has one, nodes in
+// lattice order.  The nodes of a tile form NNW words of 64 (3-D: 4^3 nodes = 1 word, 2-D: 16^2 = 4 words);
+// mask[tile][r][w] = the nodes of word w that reach layer r, base[tile][r][w] = list offset of the first of them.  A
+// particle of node l with rank r inside its node (bin_particle) sits at
+// start[tile] + base[r][l / 64] + popcount(mask[r][l / 64] & below(l % 64)).  base[tile][0][0] < 0: some node is
+// deeper than LMAX, the tile keeps the order of the binning.  Replaces the per-tile counting sort (k_tile_order,
+// 13.6 us) outside deterministic mode.
+struct TileTab {
+  static constexpr int LMAX = 32;
+  int nt[3];
+  const int* node_cnt;
+  unsigned long long* mask;
+  int* base;
+};
+template <int ND>
+struct TileTabCfg {
+  static constexpr int NN = (ND == 3) ? TileCfg<3>::TB * TileCfg<3>::TB * TileCfg<3>::TB : TileCfg<2>::TB * TileCfg<2>::TB;
+  static constexpr int NNW = NN / 64;
+};
+
 template <int ND>
 __global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD g, NView N, TileScanArgs ts,
-                                                      int* __restrict__ foreign, int* __restrict__ foreign_host) {
+                                                      int* __restrict__ foreign, int* __restrict__ foreign_host, TileTab tab) {
   if (blockIdx.x == 0) {
     if (foreign && threadIdx.x < 64) {  // this step's count of displaced particles (bin_particle) -> pinned host word
       int v = foreign[32 * threadIdx.x];
@@ -805,8 +834,76 @@ __global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD 
     tile_scan_block(ts);
     return;
   }
-  const int A = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
-  if (A < nnodes) dilate_node<ND>(n0 + A, g, N);
+  const int nbd = (nnodes + 1023) >> 10;  // workgroups of the activation
+  if ((int)blockIdx.x <= nbd) {
+    const int A = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+    if (A < nnodes) dilate_node<ND>(n0 + A, g, N);
+    return;
+  }
+  // layer tables of the canonical tile lists (TileTab), one wave per tile
+  constexpr int TB = TileCfg<ND>::TB, NNW = TileTabCfg<ND>::NNW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = ((int)blockIdx.x - 1 - nbd) * 16 + wave;
+  if (q >= ts.n) return;
+  const int tile = ts.tile0 + q;
+  const int tx = tile % tab.nt[0], ty = (tile / tab.nt[0]) % tab.nt[1], tz = tile / (tab.nt[0] * tab.nt[1]);
+  int c[NNW], maxc = 0;
+#pragma unroll
+  for (int w = 0; w < NNW; w++) {
+    const int l = w * 64 + lane;
+    const int bx = l % TB, by = (l / TB) % TB, bz = l / (TB * TB);
+    const int i = tx * TB + bx, j = ty * TB + by, k = (ND == 3) ? tz * TB + bz : 0;
+    const bool in = i < g.n[0] && j < g.n[1] && (ND == 2 || k < g.n[2]);
+    c[w] = in ? tab.node_cnt[i + g.n[0] * (j + g.n[1] * k)] : 0;
+    maxc = max(maxc, c[w]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off));
+  unsigned long long* tm = tab.mask + (size_t)tile * TileTab::LMAX * NNW;
+  int* tb = tab.base + (size_t)tile * TileTab::LMAX * NNW;
+  if (maxc > TileTab::LMAX) {  // deeper than the table: this tile keeps the order of the binning
+    if (lane == 0) tb[0] = -1;
+    return;
+  }
+  int run = 0;
+  for (int r = 0; r < maxc; r++) {
+#pragma unroll
+    for (int w = 0; w < NNW; w++) {
+      const unsigned long long m = __ballot(c[w] > r);
+      if (lane == 0) {
+        tm[r * NNW + w] = m;
+        tb[r * NNW + w] = run;
+      }
+      run += (int)__popcll(m);
+    }
+  }
+  if (maxc == 0 && lane == 0) tb[0] = 0;
+}
+// Both tile lists in one pass over the particles: order = as binned (position = rank of the wave-aggregated tile atomic:
+// runs of memory-consecutive particles), order2 = canonical (TileTab).
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_fill_orders(int np, const int* __restrict__ tile, const int* __restrict__ rank,
+                                                     const int* __restrict__ nrank, const int* __restrict__ I0a,
+                                                     const int* __restrict__ start, GridD g, TileTab tab,
+                                                     int* __restrict__ order, int* __restrict__ order2) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const int t = tile[p];
+  if (t < 0) return;
+  constexpr int TB = TileCfg<ND>::TB;
+  const int s0 = start[t], pos = s0 + rank[p];
+  order[pos] = p;
+  constexpr int NNW = TileTabCfg<ND>::NNW;
+  const int* tb = tab.base + (size_t)t * TileTab::LMAX * NNW;
+  if (tb[0] < 0) {
+    order2[pos] = p;
+    return;
+  }
+  const int I0 = I0a[p], r = nrank[p];
+  const int bx = (I0 % g.n[0]) % TB, by = ((I0 / g.n[0]) % g.n[1]) % TB, bz = (ND == 3) ? (I0 / (g.n[0] * g.n[1])) % TB : 0;
+  const int l = bx + TB * (by + TB * bz), w = l >> 6;
+  const unsigned long long m = tab.mask[((size_t)t * TileTab::LMAX + r) * NNW + w];
+  order2[s0 + tb[r * NNW + w] + (int)__popcll(m & ((1ull << (l & 63)) - 1ull))] = p;
 }
 #include "nlps_tangent_kernels.hpp"
 
@@ -1006,6 +1103,10 @@ struct nlps_gpu {
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int resort_from_lists = 1;     // developer switch NLPS_RESORT_FROM_LISTS (resort)
+  // canonical lists from per-node counters (TileTab): node_cnt[nnodes], nrank[npad], layer tables [ntiles][LMAX]
+  int *node_cnt_d = nullptr, *nrank_d = nullptr, *tabo_d = nullptr;
+  unsigned long long* tabm_d = nullptr;
+  int node_lists_on = 1;         // developer switch NLPS_NODE_LISTS (0: the per-tile counting sort k_tile_order)
   // adaptive re-sort (nlps_gpu_set_adaptive_resort): see TileCnt::home.  The count of displaced particles of a step
   // reaches the pinned host word at the end of its search stage; explicit_step adds count / NumGP to `debt` every
   // step and re-sorts ahead of the interval when the debt since the last re-sort exceeds `adaptive_resort`
@@ -1503,6 +1604,14 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
   if (dev_alloc(h, &h->nwork_d, 16)) return 1;
   if (const char* e = getenv("NLPS_ADAPTIVE_RESORT")) h->adaptive_resort = atof(e);  // developer switch (0 = off)
+  if (const char* e = getenv("NLPS_NODE_LISTS")) h->node_lists_on = atoi(e);
+  if (dev_alloc(h, &h->node_cnt_d, (size_t)h->g.nnodes)) return 1;
+  if (dev_alloc(h, &h->nrank_d, h->P.npad)) return 1;
+  {
+    const size_t nnw = h->g.nd == 3 ? TileTabCfg<3>::NNW : TileTabCfg<2>::NNW;
+    if (dev_alloc(h, &h->tabo_d, (size_t)h->ntiles * TileTab::LMAX * nnw)) return 1;
+    if (dev_alloc(h, &h->tabm_d, (size_t)h->ntiles * TileTab::LMAX * nnw)) return 1;
+  }
   if (dev_alloc(h, &h->home_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->foreign_d, 64 * 32)) return 1;
   HIPCHK(hipHostMalloc((void**)&h->foreign_h, sizeof(int), hipHostMallocDefault));
@@ -1596,6 +1705,7 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
     for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
     tc.count = nullptr;
     tc.home = nullptr;
+    tc.node_cnt = nullptr;
     if (h->nd == 2) hipLaunchKernelGGL(k_sort_keys<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
     else hipLaunchKernelGGL(k_sort_keys<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->g, tc, h->skey_d, h->sval_d, leaving, h->mats_d);
     HIPCHK(hipGetLastError());
@@ -1818,7 +1928,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -2294,6 +2404,9 @@ static int compute_node_mask(nlps_gpu* h) {
   return 0;
 }
 
+// canonical tile lists from per-node counters (TileTab) instead of the per-tile counting sort: every mode but the
+// deterministic one (which needs ranks that do not depend on the arrival order of an atomic)
+static bool node_lists(const nlps_gpu* h) { return h->tile_ordering && !h->deterministic && h->node_lists_on; }
 static TileCnt tile_cnt(nlps_gpu* h, bool on) {
   TileCnt tc;
   for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
@@ -2307,6 +2420,8 @@ static TileCnt tile_cnt(nlps_gpu* h, bool on) {
   tc.home = nullptr;
   tc.rehome = 0;
   tc.foreign = nullptr;
+  tc.node_cnt = (on && node_lists(h)) ? h->node_cnt_d : nullptr;
+  tc.nrank = h->nrank_d;
   if (on && h->adaptive_resort > 0.0 && !h->deterministic) {
     tc.home = h->home_d;
     tc.foreign = h->foreign_d;
@@ -2394,7 +2509,7 @@ static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, int overlap = 0) {
   int np = h->P.np;
   LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
-            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0);
+            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0, node_lists(h) ? h->node_cnt_d : nullptr);
   TileCnt tc = tile_cnt(h, true);
   if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
   else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
@@ -2402,27 +2517,42 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
     const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
     TileScanArgs ts{h->tile_count_d + h->tile0, h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB,
                     h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d};
-    const int nb = 1 + (h->nwn + 1023) / 1024;
+    TileTab tab;
+    for (int a = 0; a < 3; a++) tab.nt[a] = h->nt[a];
+    tab.node_cnt = h->node_cnt_d;
+    tab.mask = h->tabm_d;
+    tab.base = h->tabo_d;
+    const int nb = 1 + (h->nwn + 1023) / 1024 + (node_lists(h) ? (h->ntw + 15) / 16 : 0);
     int* fo = (h->adaptive_resort > 0.0 && !h->deterministic) ? h->foreign_d : nullptr;
-    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h);
-    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h);
+    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h, tab);
+    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h, tab);
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.active, 1, 1, 1, overlap ? 1 : 0)) return 1;
-  hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
-                     h->order_d);
   if ((h->deterministic || h->tile_ordering) && !h->order2_d) {
     HIPCHK(hipMalloc((void**)&h->order2_d, h->P.npad * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->order2_d, 0, h->P.npad * sizeof(int), h->stream));
   }
-  if (h->deterministic) {
-    TileD td = tile_view(h, 0);
-    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
-    else hipLaunchKernelGGL((k_tile_order<3, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
-  } else if (h->tile_ordering) {
-    TileD td = tile_view(h, 0);
-    if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
-    else hipLaunchKernelGGL((k_tile_order<3, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+  if (node_lists(h)) {  // both lists in one pass, the canonical one through the layer tables of this step (TileTab)
+    TileTab tab;
+    for (int a = 0; a < 3; a++) tab.nt[a] = h->nt[a];
+    tab.node_cnt = h->node_cnt_d;
+    tab.mask = h->tabm_d;
+    tab.base = h->tabo_d;
+    if (h->nd == 2) hipLaunchKernelGGL(k_fill_orders<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
+    else hipLaunchKernelGGL(k_fill_orders<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
+  } else {
+    hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
+                       h->order_d);
+    if (h->deterministic) {
+      TileD td = tile_view(h, 0);
+      if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+      else hipLaunchKernelGGL((k_tile_order<3, true>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+    } else if (h->tile_ordering) {
+      TileD td = tile_view(h, 0);
+      if (h->nd == 2) hipLaunchKernelGGL((k_tile_order<2, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+      else hipLaunchKernelGGL((k_tile_order<3, false>), dim3(h->ntw), dim3(256), 0, h->stream, h->P, h->g, td, (const int*)h->order_d, h->order2_d);
+    }
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[1], h->stream));
