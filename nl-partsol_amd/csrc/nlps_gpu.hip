@@ -576,6 +576,25 @@ __global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P) {
   int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
   constexpr int T = (ND == 2) ? 5 : 9;
+  {
+    // DF of the last explicit step, which K3 did not store: the n slot holds F_n+1 of that step, the n+1 slot still
+    // the F_n it started from (the roll is a renaming), so DF = F_n+1 F_n^-1 on the d x d block (the 2-D zz slot of DF
+    // stays 1, compute-Strains.c:20-44 never touches it)
+    double Fnew[ND * ND], Fold[ND * ND], inv[ND * ND], z;
+    load_block<ND>(P, fFN(P), p, Fnew, z);
+    load_block<ND>(P, fFN1(P), p, Fold, z);
+    if (inverse<ND>(inv, Fold)) {
+#pragma unroll
+      for (int i = 0; i < ND; i++)
+#pragma unroll
+        for (int j = 0; j < ND; j++) {
+          double a2 = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < ND; k2++) a2 += Fnew[i * ND + k2] * inv[k2 * ND + j];
+          PF(P, F_DF + i * ND + j, p) = a2;
+        }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < T; s++) {
     PF(P, fFN1(P) + s, p) = PF(P, fFN(P) + s, p);

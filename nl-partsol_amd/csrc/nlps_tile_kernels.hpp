@@ -1110,7 +1110,10 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
       st |= ST_JACOBIAN;  // fatal in the explicit scheme (U-Verlet.c:608-613), clamped in the implicit one
       if (MODE != 1) Jn1 = 0.0;
     }
-    store_block<ND>(P, F_DF, pl, DF, 0.0, false);
+    // the fused explicit step (MODE 1) keeps DF in registers: nothing reads it before the next step rewrites it, and a
+    // level-B stage or a download gets it back as F_n+1 F_n^-1 from the two slots of F (k_copy_n_to_n1): 72 B per
+    // particle less to store (K3 0.260 -> 0.251 ms at 1 M particles)
+    if (MODE != 1) store_block<ND>(P, F_DF, pl, DF, 0.0, false);
     store_block<ND>(P, fFN1(P), pl, Fn1, 0.0, false);
     PF(P, F_JN1, pl) = Jn1;
     if (RATES) {
