@@ -400,7 +400,10 @@ __device__ __forceinline__ void store_block(const PView& P, int f0, int p, const
 // budget of every other law).  A kernel without it is never launched on a cloud that holds the law: the level-B
 // stress kernel exists in both forms, the fused step runs one launch per law for such a cloud (nlps_gpu_create forces
 // k3_per_law, nlps_gpu_set_law_launch_mode refuses the dispatch kernel).
-template <int ND, int LAW = -1, bool CEP = false, bool FRIC = (LAW == NLPS_KLAW_FRICTIONAL)>
+// LAZY (the fused explicit step): the hyperelastic laws do not store tau and W -- they are functions of F_n+1 (and J)
+// alone, nothing in the step reads them back, and k_copy_n_to_n1 recomputes them with the same code from the same
+// stored inputs when a level-B stage or a download asks (80 B per particle less to store in K3).
+template <int ND, int LAW = -1, bool CEP = false, bool FRIC = (LAW == NLPS_KLAW_FRICTIONAL), bool LAZY = false>
 __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* __restrict__ mats, const ParamsD& prm,
                                              const double* Fn1, const double* DF, double J, double* tau) {
   MatD m = mats[P.mat[p]];
@@ -439,8 +442,10 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
   }
 #pragma unroll
   for (int s = 0; s < ND * ND; s++) tau[s] = o.tau[s];
-  store_block<ND>(P, F_TAU, p, o.tau, o.tau_zz, true);
-  PF(P, F_W, p) = o.W;
+  if (!(LAZY && (law == NLPS_MAT_NEO_HOOKEAN || law == NLPS_MAT_HENCKY))) {
+    store_block<ND>(P, F_TAU, p, o.tau, o.tau_zz, true);
+    PF(P, F_W, p) = o.W;
+  }
   return o.fail ? ST_CONSTITUTIVE : 0;
 }
 
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict_
 // the reference's copy semantics (n+1 == n after the roll) are restored on demand, before any level-B stage
 // or download looks at them.
 template <int ND>
-__global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P) {
+__global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P, const MatD* __restrict__ mats) {
   int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
   constexpr int T = (ND == 2) ? 5 : 9;
@@ -593,6 +598,17 @@ __global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P) {
           for (int k2 = 0; k2 < ND; k2++) a2 += Fnew[i * ND + k2] * inv[k2 * ND + j];
           PF(P, F_DF + i * ND + j, p) = a2;
         }
+    }
+    // Kirchhoff stress and energy of the hyperelastic laws, which the fused step did not store (stress_update LAZY):
+    // the same functions of the same stored F_n+1 and J
+    const MatD m = mats[P.mat[p]];
+    if (m.type == NLPS_MAT_NEO_HOOKEAN || m.type == NLPS_MAT_HENCKY) {
+      StressIO<ND> o;
+      o.fail = 0;
+      if (m.type == NLPS_MAT_NEO_HOOKEAN) law_neo_hookean<ND>(m, Fnew, PF(P, F_JN, p), o);
+      else law_hencky<ND>(m, Fnew, o);
+      store_block<ND>(P, F_TAU, p, o.tau, o.tau_zz, true);
+      PF(P, F_W, p) = o.W;
     }
   }
 #pragma unroll
@@ -2593,7 +2609,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
 
 static int materialise_roll(nlps_gpu* h) {
   if (!h->rolled) return 0;
-  LAUNCH_ND((k_copy_n_to_n1<2>), (k_copy_n_to_n1<3>), nblk(h->P.np), h->P);
+  LAUNCH_ND((k_copy_n_to_n1<2>), (k_copy_n_to_n1<3>), nblk(h->P.np), h->P, h->mats_d);
   HIPCHK(hipGetLastError());
   h->rolled = false;
   return 0;

@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
 #pragma unroll
     for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, pl) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
     double tau[ND * ND], B[ND * ND];
-    st |= stress_update<ND, LAW>(P, pl, mats, prm, Fn1, DF, Jn1, tau);
+    st |= stress_update<ND, LAW, false, (LAW == NLPS_KLAW_FRICTIONAL), true>(P, pl, mats, prm, Fn1, DF, Jn1, tau);
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), -1.0);
     PH(11)
     if (fo_ok) {
