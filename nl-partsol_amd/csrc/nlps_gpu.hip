@@ -433,8 +433,8 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
       law_drucker_prager<ND>(m, prm, DF, be, bzz, PF(P, F_KN, p), PF(P, F_EN, p), o);
     }
     store_block<ND>(P, fBEN1(P), p, o.be, o.be_zz, true);
-    PF(P, F_KN1, p) = o.kappa;
-    PF(P, F_EN1, p) = o.eps;
+    PF(P, LAZY ? F_KN : F_KN1, p) = o.kappa;  // fused step: straight to the n slots (read above, by this thread)
+    PF(P, LAZY ? F_EN : F_EN1, p) = o.eps;
     if (CEP && !(FRIC && o.cep_keep)) {
 #pragma unroll
       for (int q = 0; q < ND * ND; q++) PF(P, F_CEP + q, p) = o.cep[q];
@@ -616,6 +616,9 @@ __global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P, const MatD* __res
     PF(P, fFN1(P) + s, p) = PF(P, fFN(P) + s, p);
     PF(P, fBEN1(P) + s, p) = PF(P, fBEN(P) + s, p);
   }
+  PF(P, F_JN1, p) = PF(P, F_JN, p);
+  PF(P, F_KN1, p) = PF(P, F_KN, p);
+  PF(P, F_EN1, p) = PF(P, F_EN, p);
 }
 
 template <int ND>

@@ -651,8 +651,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
 #pragma unroll
     for (int a = 0; a < ND; a++) {
       double v = PF(P, F_VEL + a, pl), ac = PF(P, F_ACC + a, pl);
-      dd[a] = dt * v + 0.5 * dsqr(dt) * ac;
-      PF(P, F_DDIS + a, pl) = dd[a];
+      dd[a] = dt * v + 0.5 * dsqr(dt) * ac;  // (lives in registers only: K3 writes the particle increment K5 reads)
       PF(P, F_VEL + a, pl) = v + (1 - gamma_nm) * dt * ac;
     }
     const double mz = PF(P, F_MASS, pl) * Zinv;
@@ -1115,7 +1114,9 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
     // particle less to store (K3 0.260 -> 0.251 ms at 1 M particles)
     if (MODE != 1) store_block<ND>(P, F_DF, pl, DF, 0.0, false);
     store_block<ND>(P, fFN1(P), pl, Fn1, 0.0, false);
-    PF(P, F_JN1, pl) = Jn1;
+    // fused step: J goes straight to its n slot (nothing reads J_n inside the step; J_n+1 = J_n is restored with the
+    // roll, k_copy_n_to_n1), so K5 has no copy to make
+    PF(P, MODE == 1 ? F_JN : F_JN1, pl) = Jn1;
     if (RATES) {
       double dDF[ND * ND], dFn[ND * ND], dFn1[ND * ND], zz;
 #pragma unroll
@@ -1307,7 +1308,6 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
       vel_[a] = PF(P, F_VEL + a, p);
       dis_[a] = PF(P, F_DIS + a, p);
     }
-    const double jn1_ = PF(P, F_JN1, p);
 #endif
 #pragma unroll NLPS_KUNROLL_K5
     for (int k = 0; k < KN; k++) {
@@ -1354,18 +1354,9 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
       PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
 #endif
     }
-#if NLPS_K5_PREFETCH
-    PF(P, F_JN, p) = jn1_;
-#else
-    PF(P, F_JN, p) = PF(P, F_JN1, p);
-#endif
-    // F_n <- F_n+1 and b_e,n <- b_e,n+1 (U-Verlet.c:1062-1075) cost no traffic: the host swaps the roles of
-    // the two slots after this kernel (PView::flip); the stale slot is rewritten in full by the next K3.
-    if (LAW != NLPS_MAT_NEO_HOOKEAN && LAW != NLPS_MAT_HENCKY) {
-      // kappa and eps-bar exist for the plastic law only (Constitutive.c:160-168)
-      PF(P, F_KN, p) = PF(P, F_KN1, p);
-      PF(P, F_EN, p) = PF(P, F_EN1, p);
-    }
+    // The roll of U-Verlet.c:1062-1075 costs no traffic here: F and b_e roll by renaming (the host swaps the roles of
+    // their two slots after this kernel, PView::flip; the stale slot is rewritten in full by the next K3), J, kappa and
+    // eps-bar were written to their n slots by K3 in the first place (stress_update LAZY).
   }
 }
 
