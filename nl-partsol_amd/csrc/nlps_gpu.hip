@@ -51,10 +51,13 @@ enum {
   F_KN = 75, F_KN1 = 76, F_EN = 77, F_EN1 = 78, F_LAM = 79, F_BETA = 82,
   F_LAMP = 83,  // lambda of the previous step (Newton start extrapolation)
   F_BACK = 86,  // principal back stress (Von-Mises), 3 components
-  F_CEP = 89,   // C_ep[ndim*ndim] (Drucker-Prager / Von-Mises tangent moduli, implicit driver only)
-  F_DTFN = 98, F_DTFN1 = 107, F_DTDF = 116,  // rate tensors (level-B compatibility with dU_dt)
-  F_DMG = 125, F_DMG1 = 126,                 // Damage_n, Damage_n1 (eigenerosion, level B only)
-  NFD = 127
+  // rho * J, the invariant of the explicit density update rho <- rho / det DF (U-Verlet.c:630-632: det DF = J_n+1 / J_n):
+  // the fused step leaves rho alone and k_copy_n_to_n1 returns rho = (rho J) / J_n when somebody asks (k_init_rhoj)
+  F_RHOJ = 89,
+  F_CEP = 90,   // C_ep[ndim*ndim] (Drucker-Prager / Von-Mises tangent moduli, implicit driver only)
+  F_DTFN = 99, F_DTFN1 = 108, F_DTDF = 117,  // rate tensors (level-B compatibility with dU_dt)
+  F_DMG = 126, F_DMG1 = 127,                 // Damage_n, Damage_n1 (eigenerosion, level B only)
+  NFD = 128
 };
 
 struct PView {
@@ -619,6 +622,13 @@ __global__ __launch_bounds__(BLK) void k_copy_n_to_n1(PView P, const MatD* __res
   PF(P, F_JN1, p) = PF(P, F_JN, p);
   PF(P, F_KN1, p) = PF(P, F_KN, p);
   PF(P, F_EN1, p) = PF(P, F_EN, p);
+  PF(P, F_RHO, p) = PF(P, F_RHOJ, p) / PF(P, F_JN, p);
+}
+
+// first explicit step after the upload or after level-B stages: the invariant of the density update (F_RHOJ)
+__global__ __launch_bounds__(BLK) void k_init_rhoj(PView P) {
+  int p = blockIdx.x * BLK + threadIdx.x;
+  if (p < P.np) PF(P, F_RHOJ, p) = PF(P, F_RHO, p) * PF(P, F_JN, p);
 }
 
 template <int ND>
@@ -1763,7 +1773,7 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
   if (live_only && !h->level_b_fields) {
     // contiguous runs of live components (enum at the top of this file; F and b_e by their current n slots)
     const int fn = fFN(h->P), ben = fBEN(h->P);
-    const int runs[][2] = {{F_X, 12}, {fn, 9}, {ben, 9}, {F_JN, 1}, {F_RHO, 3}, {F_KN, 1}, {F_EN, 1}, {F_LAM, 10}};
+    const int runs[][2] = {{F_X, 12}, {fn, 9}, {ben, 9}, {F_JN, 1}, {F_RHO, 3}, {F_KN, 1}, {F_EN, 1}, {F_LAM, 11}};
     for (auto& r : runs)
       hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (r[1] + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
                          h->Pd_alt + (size_t)r[0] * npad, (const double*)h->P.d + (size_t)r[0] * npad, idx, np, npad, r[1]);
@@ -3006,6 +3016,10 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   if (nbcc > 0 && check_step(h, step, "nlps_gpu_explicit_step")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
+  if (!h->rolled && h->P.np > 0) {  // entering the fused scheme: rho J of every particle (see F_RHOJ)
+    hipLaunchKernelGGL(k_init_rhoj, dim3(nblk(h->P.np)), dim3(BLK), 0, h->stream, h->P);
+    HIPCHK(hipGetLastError());
+  }
   // periodic re-sort; earlier when enough particles have left the tiles their memory slots were sorted into: the count
   // of a recent step sits in the pinned word (no synchronisation: it may be a step old), its share of the cloud is this
   // step's cost estimate, and the re-sort comes when the estimates since the last one add up to the budget

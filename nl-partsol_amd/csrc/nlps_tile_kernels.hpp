@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
       }
       continue;
     }
-    PF(P, F_RHO, pl) = PF(P, F_RHO, pl) / det<ND>(DF);  // U-Verlet.c:630-632
+    // (the density update rho <- rho / det DF of U-Verlet.c:630-632 costs no traffic: rho J is invariant, F_RHOJ)
 #pragma unroll
     for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, pl) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
     double tau[ND * ND], B[ND * ND];
