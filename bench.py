@@ -8,9 +8,12 @@ and momentum, G2P gradient + F-update + Kirchhoff stress, P2G of the internal fo
 update) over the synthetic cloud.  N = 1 runs BASELINE configs[1]: 3-D elastic cube impact,
 1 M particles (50^3 cells x 8), LME, Neo-Hookean, inside a 60^3-cell grid with a rigid floor.
 N > 1 is WEAK scaling by default: every rank owns one such 1 M-particle block, stacked along z (the slab axis),
-ghost-node layers exchanged with the two z-neighbours over RCCL (torch.distributed, backend nccl);
+ghost-node layers exchanged with the two z-neighbours over RCCL (the library's own ncclSend / ncclRecv path);
 `--scaling strong --particles-total 8000000` splits ONE cube (BASELINE configs[3], 100^3 cells x 8) into N z-slabs
-instead, so N = 1, 2, 4, 8 all run the same 8 M-particle job.
+instead, so N = 1, 2, 4, 8 all run the same 8 M-particle job.  The line carries BOTH records (`weak`, `strong`; the
+headline fields are the one --scaling names), for N > 1 a partitioned-vs-whole check over the real communicator
+(`partition_check`), the rank count RCCL reports, the overlap form that survived the warm-up and per-rank kernel and
+exchange-wait times.
 Inputs are resident in HBM before the timed region; the timed region holds ONE physical re-sort of the particle
 arrays (the library's housekeeping, default cadence one per 50 steps: charged here at one per K steps).
 Rank 0 prints ONE JSON line.
@@ -58,7 +61,12 @@ def parse():
     ap.add_argument("--particles-total", type=int, default=8000000, help="--scaling strong: size of the one job")
     ap.add_argument("--no-stirred", action="store_true", help="skip the stirred-cloud figure (N = 1 only)")
     ap.add_argument("--overlap", type=int, choices=[0, 1], default=1,
-                    help="N > 1: run the halo exchanges behind the interior tiles (1) or blocking in place (0)")
+                    help="N > 1: run the halo exchanges behind the interior tiles (1: the fastest overlapped form that "
+                         "survives the warm-up, one launch per stage, else split launches) or blocking in place (0)")
+    ap.add_argument("--no-second-scaling", action="store_true",
+                    help="only the record --scaling asks for (default: the weak AND the strong record in the one line)")
+    ap.add_argument("--no-partition-check", action="store_true", help="N > 1: skip the partitioned-vs-whole check")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 2-D 1 M-particle secondary figure (N = 1 only)")
     return ap.parse_args()
 
 
@@ -127,6 +135,8 @@ def cpu_baseline(cells, budget_s=30.0):
         rates[nthr] = (P.np / float(np.median(ts)), len(ts))
     best = max(rates, key=lambda k: rates[k][0])
     return {"value": rates[best][0], "unit": "particle-steps/s", "cores": best, "kind": "port",
+            "cores_note": "%d thread(s) gave the best rate; tried 1 and %d (this GPU's share) of the %d host cores "
+                          "this process may use" % (best, nall, ncpu),
             "threads_1": rates[1][0], "threads_all": rates[nall][0], "threads_all_count": nall, "host_cores": ncpu,
             "flags": "-Ofast -fopenmp (the reference's CMAKE_C_FLAGS_RELEASE + OpenMP)",
             "port_over_reference": None,
@@ -262,110 +272,247 @@ def stirred_figure(nlps, synth, a, stream):
                               "nlps_gpu_set_adaptive_resort budget 0.8): the re-sorts it decides on are inside the timed steps"}
 
 
-def main():
-    a = parse()
-    if a.workload == "tangent":
-        return bench_tangent(a)
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
-    # rehearsal knobs (tests only): several ranks on the one GPU of a test box, gloo standing in for RCCL
-    backend = os.environ.get("NLPS_BENCH_BACKEND", "nccl")
-    local = int(os.environ.get("NLPS_BENCH_DEVICE", local))
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    nlps = importlib.import_module("nl-partsol_amd.nlps")
-    synth = importlib.import_module("nl-partsol_amd.synth")
+# ---------------------------------------------------------------------------------------------------
+# the explicit step on N ranks
+# ---------------------------------------------------------------------------------------------------
+ST_HALO = 16  # particle outside the rank's node window, or an exchange that never arrived (include/nlps_gpu.h)
 
+
+class Ctx:
+    """process-wide pieces: rank / world, torch.distributed, the shared HIP stream"""
+
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+        self.a, self.torch, self.dist = a, torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != a.gpus and self.world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+        # rehearsal knobs (tests only): several ranks on the one GPU of a test box, gloo standing in for RCCL
+        self.backend = os.environ.get("NLPS_BENCH_BACKEND", "nccl")
+        local = int(os.environ.get("NLPS_BENCH_DEVICE", local))
+        torch.cuda.set_device(local)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.nlps = importlib.import_module("nl-partsol_amd.nlps")
+        self.synth = importlib.import_module("nl-partsol_amd.synth")
+        self.halo_mod = importlib.import_module("nl-partsol_amd.halo")
+        # One real (non-default) HIP stream shared by the library's kernels and the torch ops of the halo callback:
+        # on the legacy default stream every torch op would synchronise with the library's own stream across queues
+        # (measured: ~50 us per op).
+        self.work_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.work_stream)
+        self.stream = self.work_stream.cuda_stream
+        self.dev = "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def reduce(self, value, op):
+        """scalar over all ranks (op: "max" / "min" / "sum")"""
+        if self.world == 1:
+            return value
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN,
+                                    "sum": self.dist.ReduceOp.SUM}[op])
+        return float(t.item())
+
+    def gather_rows(self, row):
+        """one row of floats per rank -> list of rows on every rank"""
+        if self.world == 1:
+            return [list(map(float, row))]
+        t = self.torch.tensor(list(map(float, row)), dtype=self.torch.float64, device=self.dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
+
+
+def make_solver(ctx, case, cells_z, margin, nsteps, want_mode):
+    """The rank's solver with its ghost-layer exchange attached.  want_mode: 2 one launch per stage (library RCCL
+    only), 1 split launches, 0 blocking exchanges.  -> (S, halo helper, info dict)"""
+    a, torch, dist, rank, world = ctx.a, ctx.torch, ctx.dist, ctx.rank, ctx.world
+    S = ctx.nlps.Solver(3, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"],
+                        nsteps=nsteps, stream=ctx.stream)
+    info = {"halo_impl": "none", "halo_overlap_mode": None, "rccl_nranks": None}
+    if world == 1:
+        return S, None, info
+    gn = case["grid_n"]
+    lo, hi = ctx.halo_mod.SlabHalo.layer_ranges(world, cells_z, margin, gn[2])
+    halo = ctx.halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)  # migration helper
+    nnodes = gn[0] * gn[1] * gn[2]
+    band_lo, band_hi = halo.ghost_bands(rank)
+    impl = a.halo_impl if ctx.backend == "nccl" else "torch"  # the gloo rehearsal has no RCCL
+    if impl == "c":
+        # the library creates its own communicator: rank 0's ncclUniqueId reaches the others through the process group
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(ctx.nlps.Solver.rccl_unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        ok = 1
+        try:
+            S.rccl_attach(bytes(uid.cpu().tolist()), rank, world, lo, hi, mode=1 if a.halo == "allreduce" else 0)
+            n_r, r_r, mode_now = S.rccl_info()
+            if n_r != world or r_r != rank:
+                raise RuntimeError("RCCL reports rank %d of %d, the launcher %d of %d" % (r_r, n_r, rank, world))
+            info["rccl_nranks"] = n_r
+            if want_mode < mode_now:
+                S.set_ghost_bands(band_lo, band_hi, want_mode)
+        except Exception as e:  # e.g. librccl.so.1 not loadable on some rank
+            print("rank %d: nlps_gpu_rccl_attach failed (%r)" % (rank, e), file=sys.stderr)
+            ok = 0
+        if ctx.reduce(ok, "min") == 0:  # all ranks fall back together to the callback through torch.distributed
+            S.rccl_detach()
+            impl = "torch"
+            info["rccl_nranks"] = None
+    if impl == "torch":
+        def exchange(dptr, nfield, elem, kind, phase):
+            return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind, phase)
+
+        S.set_halo_exchange(exchange)
+        S._bench_exchange = exchange  # keeps the closure alive with the solver
+        # the three exchanges of a step run behind the tiles that do not touch a ghost band (split launches at most:
+        # the single-launch form needs the library's own exchange stream)
+        S.set_ghost_bands(band_lo, band_hi, min(want_mode, 1))
+        # per-step nodal work only on the layers this rank can touch (the grid grows with the rank count)
+        S.set_node_window(lo[rank], hi[rank])
+    info["halo_impl"] = impl
+    info["halo_overlap_mode"] = S.rccl_info()[2] if impl == "c" else min(want_mode, 1)
+    return S, halo, info
+
+
+def floor_bcs(ctx, case, nsteps):
+    nodes = ctx.synth.plane_nodes(case["grid_n"], 2, 0)
+    return ctx.nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nsteps), dtype=np.int32),
+                             "value": np.zeros((3, nsteps))}])
+
+
+def warm_solver(ctx, case, cells_z, margin, nsteps, dt, bcs, warmup):
+    """Solver + exchange + warm-up steps, in the fastest overlap form that survives them: after the warm-up every rank
+    reads its status word; a halo flag (16: an exchange that never arrived, a particle outside the window) or an error out
+    of a step on ANY rank makes ALL ranks rebuild one form down, 2 -> 1 -> 0, in this process (nothing that has
+    touched the GPU is ever re-executed)."""
+    a, world = ctx.a, ctx.world
+    want = 2 if a.overlap else 0
+    tried = []
+    while True:
+        S, halo, info = make_solver(ctx, case, cells_z, margin, nsteps, want)
+        ok, flags = 1, 0
+        try:
+            S.initialise_shapefun()
+            for t in range(warmup):
+                S.explicit_step(bcs, t, dt)
+            ctx.torch.cuda.synchronize()
+            flags = S.status_flags()
+        except Exception as e:
+            print("rank %d: warm-up failed in overlap form %s (%r)" % (ctx.rank, info["halo_overlap_mode"], e), file=sys.stderr)
+            ok = 0
+        bad = ctx.reduce(0 if (ok and not (flags & ST_HALO)) else 1, "max") != 0
+        tried.append({"halo_overlap_mode": info["halo_overlap_mode"], "ok": not bad})
+        if not bad:
+            info["overlap_forms_tried"] = tried
+            return S, halo, info, flags
+        mode_now = info["halo_overlap_mode"] or 0
+        try:
+            S.close()
+        except Exception:
+            pass
+        if world == 1 or mode_now == 0:
+            raise SystemExit("bench: the warm-up failed in every overlap form (%r)" % tried)
+        want = mode_now - 1
+
+
+def partition_check(ctx):
+    """N > 1, before anything is timed: a small cloud split into N slabs runs four steps over the REAL communicator and
+    exchange form of the run, and again as one cloud in one solver on rank 0; the partitioned fields must match
+    (index maps bit for bit).  -> dict for the JSON line"""
+    a, torch, dist, rank, world = ctx.a, ctx.torch, ctx.dist, ctx.rank, ctx.world
+    cells, margin, nsteps = 8, 5, 4
+    case = build_case(rank, world, cells, margin, cells)
+    case["cloud"]["vel"][:] = [1.0, 0.5, -10.0]
+    bc_nodes = ctx.synth.plane_nodes(case["grid_n"], 2, margin + 1)
+    bcs = ctx.nlps.BccSet([{"nodes": bc_nodes, "dim": 3, "dir": np.ones((3, nsteps), dtype=np.int32),
+                            "value": np.zeros((3, nsteps))}])
+    dt = 0.4 / 100.0
+    S, halo, info = make_solver(ctx, case, cells, margin, nsteps, 2 if a.overlap else 0)
+    S.set_resort_interval(2)
+    S.initialise_shapefun()
+    for t in range(nsteps):
+        S.explicit_step(bcs, t, dt)
+    flags = S.status_flags()
+    st = S.download_state(fields=["x", "vel", "F_n", "Stress", "I0"])
+    S.close()
+    mine = {k: st[k] for k in ("x", "vel", "F_n", "Stress", "I0")}
+    parts = [None] * world
+    dist.gather_object(mine, parts if rank == 0 else None, dst=0)
+    res = [0.0, 0.0, float(flags)]
+    if rank == 0:
+        clouds = [build_case(r, world, cells, margin, cells)["cloud"] for r in range(world)]
+        whole = {}
+        for k, v in clouds[0].items():
+            whole[k] = np.concatenate([c[k] for c in clouds]) if isinstance(v, np.ndarray) else v
+        whole["vel"][:] = [1.0, 0.5, -10.0]
+        G = ctx.nlps.Solver(3, case["grid_n"], case["origin"], case["h"], whole, case["materials"], nsteps=nsteps,
+                            stream=ctx.stream)
+        G.set_resort_interval(2)
+        G.initialise_shapefun()
+        for t in range(nsteps):
+            G.explicit_step(bcs, t, dt)
+        ref = G.download_state(fields=["x", "vel", "F_n", "Stress", "I0"])
+        G.close()
+        err = 0.0
+        for k in ("x", "vel", "F_n", "Stress"):
+            got = np.concatenate([p[k] for p in parts])
+            err = max(err, float(np.max(np.abs(got - ref[k])) / max(np.max(np.abs(ref[k])), 1e-300)))
+        res[0] = err
+        res[1] = 0.0 if np.array_equal(np.concatenate([p["I0"] for p in parts]), ref["I0"]) else 1.0
+    res = [ctx.reduce(v, "max") for v in res]
+    return {"max_rel_err": res[0], "index_maps_equal": res[1] == 0.0, "status_flags": int(res[2]), "steps": nsteps,
+            "particles": world * cells ** 3 * 8, "halo_impl": info["halo_impl"],
+            "halo_overlap_mode": info["halo_overlap_mode"], "rccl_nranks": info["rccl_nranks"],
+            "fields": "x, vel, F_n, Stress against one solver holding the whole cloud; I0 bit for bit"}
+
+
+def run_config(ctx, scaling, with_kernels=True):
+    """One timed configuration: `weak` (--cells^3 x 8 particles per rank, stacked along z) or `strong` (ONE cube of
+    --particles-total particles in N z-slabs).  Barrier + synchronise on both sides of exactly K steps, max over ranks.
+    -> (record for the JSON line, the solver's case, per-kernel ms of rank 0's further steps)"""
+    a, torch, rank, world = ctx.a, ctx.torch, ctx.rank, ctx.world
     margin = 5
     cells, cells_z = a.cells, a.cells
-    if a.scaling == "strong":  # one cube of --particles-total particles, z-slabs of equal thickness
+    if scaling == "strong":  # one cube of --particles-total particles, z-slabs of equal thickness
         cells = int(round((a.particles_total / 8.0) ** (1.0 / 3.0)))
         if cells < 8 * world:
             raise SystemExit("--scaling strong: %d cell layers are too few for %d ranks" % (cells, world))
         cells_z = [cells // world + (1 if r < cells % world else 0) for r in range(world)]  # 100 layers / 8 = 13,13,13,13,12,...
     case = build_case(rank, world, cells, margin, cells_z)
     total_steps = a.steps + a.warmup + 1
-    # One real (non-default) HIP stream shared by the library's kernels and the torch ops of the halo callback:
-    # on the legacy default stream every torch op would synchronise with the library's own stream across queues
-    # (measured: ~50 us per op).
-    work_stream = torch.cuda.Stream()
-    torch.cuda.set_stream(work_stream)
-    stream = work_stream.cuda_stream
-    S = nlps.Solver(3, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"],
-                    nsteps=total_steps, stream=stream)
-    nodes = synth.plane_nodes(case["grid_n"], 2, 0)
-    bcs = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, total_steps), dtype=np.int32),
-                        "value": np.zeros((3, total_steps))}])
-    halo_impl = "none"
-    if world > 1:
-        halo_mod = importlib.import_module("nl-partsol_amd.halo")
-        gn = case["grid_n"]
-        lo, hi = halo_mod.SlabHalo.layer_ranges(world, cells_z, margin, gn[2])
-        halo = halo_mod.SlabHalo(torch, dist, rank, world, gn[0] * gn[1], gn[2], lo, hi, mode=a.halo)  # migration helper
-        nnodes = gn[0] * gn[1] * gn[2]
-        halo_impl = a.halo_impl if backend == "nccl" else "torch"  # the gloo rehearsal has no RCCL
-        if halo_impl == "c":
-            # the library creates its own communicator: rank 0's ncclUniqueId reaches the others through the process group
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid = torch.tensor(list(nlps.Solver.rccl_unique_id()), dtype=torch.uint8, device="cuda")
-            dist.broadcast(uid, 0)
-            ok = 1
-            try:
-                S.rccl_attach(bytes(uid.cpu().tolist()), rank, world, lo, hi, mode=1 if a.halo == "allreduce" else 0)
-                if a.overlap == 0:
-                    S.set_ghost_bands(*halo.ghost_bands(rank), False)
-            except Exception as e:  # e.g. librccl.so.1 not loadable on some rank
-                print("rank %d: nlps_gpu_rccl_attach failed (%r)" % (rank, e), file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:  # all ranks fall back together to the callback through torch.distributed
-                S.rccl_detach()
-                halo_impl = "torch"
-        if halo_impl == "torch":
-            def exchange(dptr, nfield, elem, kind, phase):
-                return halo.exchange_ptr(dptr, nnodes * nfield, nfield, elem, kind, phase)
-
-            S.set_halo_exchange(exchange)
-            # the three exchanges of a step run behind the tiles that do not touch a ghost band
-            band_lo, band_hi = halo.ghost_bands(rank)
-            S.set_ghost_bands(band_lo, band_hi, a.overlap == 1)
-            # per-step nodal work only on the layers this rank can touch (the grid grows with the rank count)
-            S.set_node_window(lo[rank], hi[rank])
-    S.initialise_shapefun()
+    bcs = floor_bcs(ctx, case, total_steps)
     dt = 0.1 * case["h"] / 100.0  # CFL 0.1, celerity sqrt(E/rho) = 100
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    S, halo, info, _ = warm_solver(ctx, case, cells_z, margin, total_steps, dt, bcs, a.warmup)
 
     def step(t):
         if world > 1 and a.migrate_every > 0 and t % a.migrate_every == 0:
             cz = list(cells_z) if hasattr(cells_z, "__len__") else [cells_z] * world
-            halo.migrate(S, margin + sum(cz[:rank]) - 1 if rank > 0 else 0,
-                         margin + sum(cz[:rank + 1]) + 1 if rank + 1 < world else case["grid_n"][2] - 1)
+            keep = (margin + sum(cz[:rank]) - 1 if rank > 0 else 0,
+                    margin + sum(cz[:rank + 1]) + 1 if rank + 1 < world else case["grid_n"][2] - 1)
+            if info["halo_impl"] == "c":
+                S.rccl_migrate(*keep)   # select -> ncclSend / ncclRecv of counts and rows -> commit, inside the library
+            else:
+                halo.migrate(S, *keep)
         S.explicit_step(bcs, t, dt)
 
-    t = 0
-    for _ in range(a.warmup):
-        step(t)
-        t += 1
+    t = a.warmup
     torch.cuda.synchronize()
-    barrier()
+    ctx.barrier()
     torch.cuda.synchronize()
     # housekeeping of the hot path inside the timed region: the library's own periodic physical re-sort, with its
     # interval set so that it fires exactly once in the K timed steps (library default: one per 50 steps)
@@ -376,46 +523,104 @@ def main():
         step(t)
         t += 1
     torch.cuda.synchronize()
-    barrier()
+    ctx.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    flags = S.status_flags()
+    elapsed = ctx.reduce(time.perf_counter() - t0, "max")
+    flags = int(ctx.reduce(S.status_flags(), "max"))
     if flags:
         raise SystemExit("bench: particle failure flags 0x%x" % flags)
+    npart = case["cloud"]["x"].shape[0]
+    npart_total = int(ctx.reduce(npart, "sum"))
+    rec = {"scaling": scaling, "n_gpus": world, "particles_total": npart_total, "particles_rank0": npart,
+           "ms_per_step": 1e3 * elapsed / a.steps, "value": npart_total * a.steps / elapsed, "unit": "particle-steps/s",
+           "steps": a.steps, "warmup": a.warmup, "grid_nodes": int(np.prod(case["grid_n"])),
+           "cells": [cells, cells, int(sum(cells_z)) if hasattr(cells_z, "__len__") else int(cells_z) * world],
+           "halo": a.halo if world > 1 else "none", "halo_impl": info["halo_impl"],
+           "halo_overlap_mode": info["halo_overlap_mode"], "rccl_nranks": info["rccl_nranks"],
+           "overlap_forms_tried": info.get("overlap_forms_tried"), "resorts_in_timed_region": 1}
+    kms = None
+    if with_kernels:
+        # per-kernel times of further steps (HIP events on the launch stream), untimed.  Twenty of them: kernel time
+        # swings by +-6 % with the position of the falling cube in the lattice (period ~17 steps: whole layers of
+        # particles change tile together and break the memory-consecutive runs), so three steps read a phase, not the mean
+        S.set_timing(True)
+        kms = np.zeros(8)
+        reps = 20
+        for _ in range(reps):
+            S.explicit_step(bcs, min(t, total_steps - 1), dt)
+            kms += np.array(S.get_timing())
+        kms /= reps
+        S.set_timing(False)
+        # a bracket of two event records measures record + dispatch latency besides the kernel: take the calibration
+        # bracket (kms[5]: a do-nothing kernel of the same grid, measured in the same steps) off the single-kernel
+        # brackets so that they read like rocprofv3's kernel durations
+        ev_overhead = float(kms[5])
+        kms[:4] = np.maximum(kms[:4] - ev_overhead, 0.0)
+        names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update", "nodal",
+                 "event_overhead", "exchange_wait"]
+        rows = ctx.gather_rows(kms[:7])
+        rec["per_rank_kernel_ms"] = [{n: float(v) for n, v in zip(names, r)} for r in rows]
+    S.close()
+    return rec, case, kms
 
-    # per-kernel times of further steps (HIP events on the launch stream), untimed.  Twenty of them: kernel time
-    # swings by +-6 % with the position of the falling cube in the lattice (period ~17 steps: whole layers of
-    # particles change tile together and break the memory-consecutive runs), so three steps read a phase, not the mean
-    S.set_timing(True)
-    kms = np.zeros(8)
-    reps = 20
-    for _ in range(reps):
-        S.explicit_step(bcs, min(t, total_steps - 1), dt)
-        kms += np.array(S.get_timing())
-    kms /= reps
-    S.set_timing(False)
-    # a bracket of two event records measures record + dispatch latency besides the kernel: take the calibration
-    # bracket (kms[5]: a do-nothing kernel of the same grid, measured in the same steps) off the single-kernel
-    # brackets so that they read like rocprofv3's kernel durations
-    ev_overhead = float(kms[5])
-    kms[:4] = np.maximum(kms[:4] - ev_overhead, 0.0)
 
+def secondary_2d(ctx):
+    """SECONDARY figure (not the headline): the same fused step in 2-D, 1 M particles (500^2 cells x 4, LME gamma = 3,
+    Neo-Hookean), where the path sits near the roofline ridge: 810 algorithmic bytes per particle-step."""
+    a, torch = ctx.a, ctx.torch
+    cells, margin = 500, 5
+    gc = [cells + 2 * margin] * 2
+    cloud = ctx.synth.make_cloud(2, gc, [margin] * 2, [cells] * 2, h=1.0, jitter=0.05, seed=12345, velocity=[0.0, -10.0])
+    nsteps = a.steps + a.warmup + 1
+    S = ctx.nlps.Solver(2, ctx.synth.grid_nodes(gc), [0.0, 0.0], 1.0, cloud, [{"type": 0, "E": 1.0e7, "nu": 0.3}],
+                        nsteps=nsteps, stream=ctx.stream)
+    nodes = ctx.synth.plane_nodes(ctx.synth.grid_nodes(gc), 1, 0)
+    bcs = ctx.nlps.BccSet([{"nodes": nodes, "dim": 2, "dir": np.ones((2, nsteps), dtype=np.int32),
+                            "value": np.zeros((2, nsteps))}])
+    S.initialise_shapefun()
+    dt = 0.1 / 100.0
+    for t in range(a.warmup):
+        S.explicit_step(bcs, t, dt)
+    S.set_resort_interval(a.steps // 2 + 1)
+    S.set_adaptive_resort(0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(a.warmup, a.warmup + a.steps):
+        S.explicit_step(bcs, t, dt)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / a.steps
+    flags = S.status_flags()
+    npart = cloud["x"].shape[0]
+    S.close()
+    gbs = npart * 810.0 / (ms * 1e-3) / 1e9
+    return {"workload": "2-D, %d particles (%d^2 cells x 4), LME gamma=3, Neo-Hookean, explicit step" % (npart, cells),
+            "ms_per_step": ms, "value": npart / (ms * 1e-3), "unit": "particle-steps/s", "steps": a.steps,
+            "algorithmic_bytes_per_particle_step": 810, "achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+            "status_flags": flags, "resorts_in_timed_region": 1}
+
+
+def main():
+    a = parse()
+    if a.workload == "tangent":
+        return bench_tangent(a)
+    ctx = Ctx(a)
+    rank, world = ctx.rank, ctx.world
+    check = partition_check(ctx) if world > 1 and not a.no_partition_check else None
+    if check is not None and (check["max_rel_err"] > 1e-9 or not check["index_maps_equal"] or check["status_flags"]):
+        raise SystemExit("bench: the partitioned run does not reproduce the single-solver run: %r" % check)
+    rec, case, kms = run_config(ctx, a.scaling)
+    other = "strong" if a.scaling == "weak" else "weak"
+    rec_other = None
+    if not a.no_second_scaling:
+        rec_other, _, _ = run_config(ctx, other, with_kernels=world > 1)
     stirred = None
+    second = None
     if world == 1 and not a.no_stirred:
-        stirred = stirred_figure(nlps, synth, a, stream)
-
-    # particles of the whole job (ranks may hold slabs of unequal thickness)
-    npart_total = case["cloud"]["x"].shape[0]
-    if world > 1:
-        nt = torch.tensor([npart_total], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
-        npart_total = int(nt.item())
+        stirred = stirred_figure(ctx.nlps, ctx.synth, a, ctx.stream)
+    if world == 1 and not a.no_secondary:
+        second = secondary_2d(ctx)
     if rank == 0:
-        npart = case["cloud"]["x"].shape[0]
+        npart = rec["particles_rank0"]
         names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update", "nodal"]
         kern = ["k_search", "k2_tile", "k3_tile", "k5_tile", None]
         alg = [0, BYTES_3D["S1"] + BYTES_3D["S2"], BYTES_3D["S3"] + BYTES_3D["S4"], BYTES_3D["S5"], 0]
@@ -428,14 +633,18 @@ def main():
             except Exception:
                 pass
         per_kernel = {}
+        scale = npart / 1.0e6
         for i in range(4):
             t_s = kms[i] * 1e-3
             if t_s <= 0:
                 continue
             e = {"kernel_ms": float(kms[i]), "algorithmic_bytes_per_particle": alg[i],
                  "hbm_frac": npart * alg[i] / t_s / 1e9 / HBM_PEAK_GBS}
+            tr = pmc.get(names[i])
+            if tr is not None:  # counter bytes (FETCH_SIZE + WRITE_SIZE passes) / live kernel time / peak
+                e["traffic_bytes"] = tr * scale
+                e["traffic_frac"] = tr * scale / t_s / 1e9 / HBM_PEAK_GBS
             sq = pmc.get(kern[i] or "", {}) if isinstance(pmc.get(kern[i] or ""), dict) else {}
-            scale = npart / 1.0e6
             if "valu_insts" in sq:  # SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)
                 e["fp64_issue_frac"] = sq["valu_insts"] * scale * 4.0 / (1024 * 2.4e9 * t_s)
             if "lds_idx_active" in sq:  # SQ_LDS_IDX_ACTIVE (LDS-array cycles, summed over CUs) / (256 CUs x 2.4 GHz x time)
@@ -445,46 +654,55 @@ def main():
             per_kernel[names[i]] = e
         dom = int(np.argmax(kms[:4]))
         achieved = npart * alg[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        traffic = pmc.get(names[dom])
-        if traffic is not None:
-            traffic = traffic * npart / 1.0e6
         domk = per_kernel.get(names[dom], {})
+        cz = rec["cells"]
         out = {
-            "metric": "particle-steps/sec (P2G+stress+G2P)", "value": npart_total * a.steps / elapsed,
+            "metric": "particle-steps/sec (P2G+stress+G2P)", "value": rec["value"],
             "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": a.scaling,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-D elastic cube impact, %d particles/GPU (%dx%dx%d cells x 8), LME gamma=3, "
+            "config": {"workload": "3-D elastic cube impact, %d particles/GPU (%dx%dx%d cells x 8 over %d rank(s)), LME gamma=3, "
                                    "Neo-Hookean E=1e7 nu=0.3, explicit predictor-corrector step, 1xMI355X per rank; "
-                                   "z-slabs for N>1 (%s scaling)" % (npart, cells, cells, case["cells"][2] - 2 * margin if world == 1 else
-                                                                      (cells_z[0] if hasattr(cells_z, "__len__") else cells_z), a.scaling),
-                       "particles_total": npart_total, "grid_nodes": int(np.prod(case["grid_n"])),
-                       "halo": a.halo if world > 1 else "none", "halo_impl": halo_impl,
-                       "halo_overlap": bool(a.overlap) if world > 1 else None,
+                                   "z-slabs for N>1 (%s scaling)" % (npart, cz[0], cz[1], cz[2], world, a.scaling),
+                       "particles_total": rec["particles_total"], "grid_nodes": rec["grid_nodes"],
+                       "halo": rec["halo"], "halo_impl": rec["halo_impl"],
+                       "halo_overlap": bool(rec["halo_overlap_mode"]) if world > 1 else None,
+                       "halo_overlap_mode": rec["halo_overlap_mode"], "rccl_nranks": rec["rccl_nranks"],
+                       "overlap_forms_tried": rec["overlap_forms_tried"],
                        "resorts_in_timed_region": 1, "library_default_resort_interval": 50},
             "roofline": {"bound": domk.get("bound", "hbm"), "kernel": names[dom], "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": domk.get("traffic_bytes"), "traffic_frac": domk.get("traffic_frac"),
                          "algorithmic_bytes_per_particle": alg[dom], "kernel_ms": float(kms[dom]),
-                         "event_overhead_ms": ev_overhead,
+                         "event_overhead_ms": float(kms[5]),
                          "hbm_frac": domk.get("hbm_frac"), "fp64_issue_frac": domk.get("fp64_issue_frac"),
                          "lds_busy_frac": domk.get("lds_busy_frac"),
                          "note": "achieved/peak/frac are the HBM roofline of the dominant kernel (algorithmic bytes / "
-                                 "live kernel time); bound names the LARGEST of the three fractions: hbm, fp64_issue "
-                                 "(SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x time)) and lds "
+                                 "live kernel time); traffic_frac is the same with the HBM bytes the counters saw "
+                                 "(profiles/hbm_traffic.json); bound names the LARGEST of the three fractions: hbm, "
+                                 "fp64_issue (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x time)) and lds "
                                  "(SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x time)); the SQ counts come from "
                                  "profiles/sq_counters.json (rocprofv3 PMC passes of this command)"},
             "kernel_ms_all": {names[i]: float(kms[i]) for i in range(5)},
+            "exchange_wait_ms": float(kms[6]),
             "per_kernel": per_kernel,
+            a.scaling: {k: v for k, v in rec.items()},
         }
+        if rec_other is not None:
+            out[other] = rec_other
+        if check is not None:
+            out["partition_check"] = check
         if stirred is not None:
             out["stirred_ms_per_step"] = stirred["ms_per_step"]
             out["stirred"] = stirred
+        if second is not None:
+            out["secondary"] = second
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_cells)
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

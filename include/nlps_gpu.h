@@ -163,6 +163,14 @@ int nlps_gpu_local_search(nlps_gpu *h);
 
 /* get_active_nodes__MeshTools__ + get_active_dofs__MeshTools__ (Nodes/Nodes-Tools.c:46-156).
  * nodes2mask[nnodes] / dofs2mask[nactive*ndim] may be NULL (kept on the device only). */
+/* Node order of the masked numbering.  get_active_nodes__MeshTools__ hands out its running index in the order of the
+ * mesh file's nodes (Nodes/Nodes-Tools.c:46-66); the library works in lattice numbering (x fastest), which is the same
+ * thing only for a file numbered that way.  lattice_of_file[A] = lattice node of file node A (the map
+ * nlps_host_lattice_from_nodes returns; nnodes entries, copied): from now on Nodes2Mask -- and with it every masked
+ * vector, the dof mask and the COO rows / columns of the tangent -- counts the active nodes in FILE order, and the
+ * nodes2mask array of nlps_gpu_active_masks is indexed by file node.  Everything else of this interface that names a
+ * node (I0, lists, Dirichlet node sets, h_avg, active flags) stays in lattice numbering.  NULL = lattice order. */
+int nlps_gpu_set_node_numbering(nlps_gpu *h, const int *lattice_of_file);
 int nlps_gpu_active_masks(nlps_gpu *h, const nlps_bcc *bcc, int nbcc, int step, int *nactive,
                           int *nfree_dofs, int *nodes2mask, int *dofs2mask);
 
@@ -216,7 +224,9 @@ int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force
  * every `every_n_steps` steps (default 50, 0 = never). */
 int nlps_gpu_resort(nlps_gpu *h);
 int nlps_gpu_set_resort_interval(nlps_gpu *h, int every_n_steps);
-/* Adaptive re-sort of the fused explicit step (off by default): the search stage counts the particles that are no
+/* Adaptive re-sort of the fused explicit step (ON by default with budget 0.8, min_steps 4, whenever the interval above
+ * is not 0; off in deterministic mode: the trigger reads a count the device publishes asynchronously, so the step that
+ * re-sorts -- never a result beyond rounding -- can differ from run to run): the search stage counts the particles that are no
  * longer in the tile their memory slot was sorted into; every step adds that share of the cloud to a debt, and when
  * the debt since the last re-sort exceeds `budget` (and at least min_steps steps have passed) the step re-sorts ahead
  * of the interval above.  budget = 0 switches it off; an interval of 0 switches every re-sort off.  A budget of 0.6
@@ -244,6 +254,9 @@ int nlps_gpu_rccl_attach_comm(nlps_gpu *h, void *nccl_comm, int rank, int world,
                               const int *layer_hi, int mode);
 int nlps_gpu_rccl_detach(nlps_gpu *h);
 int nlps_gpu_rccl_reduce(nlps_gpu *h, double *vec, size_t n, int root);
+/* What the attached communicator reports (ncclCommCount, ncclCommUserRank) and the overlap choreography in force
+ * (0 blocking exchanges, 1 split launches, 2 one launch per stage); any pointer may be NULL. */
+int nlps_gpu_rccl_info(nlps_gpu *h, int *nranks, int *rank, int *overlap_mode);
 /* world-size-1 self-test of the exchange (one-GPU boxes): the rank is its own two neighbours -- the lowest three
  * layers of its range are exchanged with the highest three by ncclSend / ncclRecv to itself; overlap = the two-phase
  * (side-stream) form. */
@@ -340,6 +353,14 @@ int nlps_gpu_migration_select(nlps_gpu *h, int keep_lo, int keep_hi, int *n_down
  * or device pointers, may be NULL/0) join; the arrays are re-sorted.  Capacity is fixed at create:
  * np + max(np/4, 1024) particles. */
 int nlps_gpu_migration_commit(nlps_gpu *h, const void *rows_a, int n_a, const void *rows_b, int n_b);
+/* Both steps with the transport in between done by the library over the communicator of nlps_gpu_rccl_attach (a C driver
+ * needs nothing else): select and pack, the row counts and then the rows exchanged with rank - 1 / rank + 1 by
+ * ncclSend / ncclRecv on the handle's stream, commit.  Collective over the communicator: every rank calls it at the
+ * same step.  An edge rank's keep range is clamped to the grid on its outer side.  Any output may be NULL. */
+int nlps_gpu_rccl_migrate(nlps_gpu *h, int keep_lo, int keep_hi, int *sent_down, int *sent_up, int *received);
+/* world-size-1 self-test of that transport (one-GPU boxes): the rank is its own two neighbours, the particles that
+ * leave the keep range come straight back as immigrants (no clamping). */
+int nlps_gpu_rccl_selftest_migrate(nlps_gpu *h, int keep_lo, int keep_hi, int *sent_down, int *sent_up, int *received);
 /* current number of particles of this handle */
 int nlps_gpu_num_particles(nlps_gpu *h, int *np);
 /* global particle ids (default: the index in the arrays given to nlps_gpu_create).  After the first migration

@@ -132,6 +132,11 @@ static nlps_particles nlps_glue_particles(Particle MPM_Mesh) {
 int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Params Parameters_Solver) {
   nlps_grid g;
   memset(G, 0, sizeof *G);
+  if (strcmp(wrapper_LME, "Newton-Raphson") != 0) { /* LME.c:97-101: Nelder-Mead also changes the initial lambda */
+    fprintf(stderr, "" RED "nlps_glue: wrapper_LME = %s stays on the CPU path (the GPU path restates Newton-Raphson)" RESET "\n",
+            wrapper_LME);
+    return EXIT_FAILURE;
+  }
   if (nlps_glue_lattice(G, &FEM_Mesh, &g) == EXIT_FAILURE) return EXIT_FAILURE;
   /* snapshot of the globals the level-A functions read implicitly (Globals.h:33-58) */
   nlps_params prm = {gamma_LME, TOL_zero_LME, TOL_wrapper_LME, max_iter_LME, TOL_Radial_Returning,
@@ -178,8 +183,15 @@ int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Pa
   p.I0 = G->I0_l;
   const int STATUS = nlps_gpu_create(&G->gpu, &g, &prm, mats, Nmat, &p, Parameters_Solver.NumTimeStep, NULL);
   free(mats);
-  if (STATUS != EXIT_SUCCESS)
+  if (STATUS != EXIT_SUCCESS) {
     fprintf(stderr, "" RED "%s" RESET "\n", G->gpu ? nlps_gpu_last_error(G->gpu) : "nlps_gpu_create");
+    return STATUS;
+  }
+  /* a mesh file that is not numbered x-fastest: the masked numbering follows the FILE's node order (Nodes-Tools.c:46-66) */
+  if (!G->identity && nlps_gpu_set_node_numbering(G->gpu, G->canon) != EXIT_SUCCESS) {
+    fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(G->gpu));
+    return EXIT_FAILURE;
+  }
   return STATUS;
 }
 
@@ -223,14 +235,9 @@ int nlps_glue_masks(const nlps_glue *G, Mesh FEM_Mesh, const nlps_bcc *bcc, int 
     fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(GPU));
     return EXIT_FAILURE;
   }
-  if (!G->identity) { /* the library's Nodes2Mask is indexed by lattice node: back to the mesh file's numbering.  The
-                         masked indices themselves (and with them every masked Vec) keep the library's order. */
-    int *tmp = (int *)malloc((size_t)G->N * sizeof(int));
-    if (tmp == NULL) return EXIT_FAILURE;
-    memcpy(tmp, ActiveNodes->Nodes2Mask, (size_t)G->N * sizeof(int));
-    for (int A = 0; A < G->N; A++) ActiveNodes->Nodes2Mask[A] = tmp[G->canon[A]];
-    free(tmp);
-  }
+  /* (for a mesh file that is not numbered x-fastest nlps_glue_create has handed the file's node order to the library,
+   * nlps_gpu_set_node_numbering: Nodes2Mask arrives indexed by file node with the running index in file order, exactly
+   * the array of get_active_nodes__MeshTools__, and the dof mask -- indexed by MASKED node, Nodes-Tools.c:96-135 -- with it) */
   ActiveNodes->Nactivenodes = Nactivenodes;
   ActiveDOFs->Nactivenodes = Nfree;
   return EXIT_SUCCESS;

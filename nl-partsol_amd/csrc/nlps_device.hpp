@@ -209,6 +209,46 @@ __device__ __forceinline__ double rcond_ref(const double* A) {
   return (1.0 / inorm) / anorm;
 }
 
+// The gate `rcond__TensorLib__(J) < 1E-8` of the Newton iteration (LME.c:308) without evaluating rcond_ref, whenever
+// a rigorous lower bound of it already clears the threshold.  With L = unit lower part of A, U = upper part of A
+// (what dgecon sees in the unfactored matrix), m = min |diagonal|, q = max |strict upper| / m:
+//   ||(L U)^-1||_1 <= ||U^-1||_1 ||L^-1||_1,   ||U^-1||_1 <= (1 + q)^(N-1) / m,
+//   ||L^-1||_1 <= 1 + sum |strict lower| + |a10 a21|  (N = 3; 1 + |a10| for N = 2),
+// hence rcond_ref >= m^N / (||A||_1 NL (m + qmax)^(N-1)).  Twice the threshold pays for the rounding of the bound
+// itself; NaNs, zeros and badly scaled matrices fail the comparison and take the exact evaluation.  The result is
+// the boolean the reference computes, for ~25 instructions instead of ~150 per Newton pass.
+template <int N>
+__device__ __forceinline__ bool rcond_below_gate(const double* A) {
+  double anorm = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) s += fabs(A[i * N + j]);
+    anorm = s > anorm ? s : anorm;
+  }
+  double m = fabs(A[0]), qmax = 0.0, nl = 1.0;
+#pragma unroll
+  for (int i = 1; i < N; i++) m = fmin(m, fabs(A[i * N + i]));
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      if (j > i) qmax = fmax(qmax, fabs(A[i * N + j]));
+      if (j < i) nl += fabs(A[i * N + j]);
+    }
+  if (N == 3) nl += fabs(A[3 % (N * N)] * A[7 % (N * N)]);
+  const double mq = m + qmax;
+  const double lhs = (N == 3) ? m * m * m : m * m;
+  const double rhs = 2.0e-8 * anorm * nl * ((N == 3) ? mq * mq : mq);
+  bool sure = (lhs >= rhs) && (m > 1.0e-90) && (anorm < 1.0e90);
+#if NLPS_RCOND_EXACT
+  sure = false;
+#endif
+  if (__builtin_amdgcn_ballot_w64(!sure) == 0ull) return false;  // wave-uniform: every lane is surely above the gate
+  return rcond_ref<N>(A) < 1E-8;
+}
+
 // Symmetric eigen-decomposition by cyclic Jacobi, all in registers (replaces LAPACKE_dsyev,
 // TensorLib.c:208 / Drucker-Prager.c:635).  Eigenvector A = COLUMN A of v, eigenvalues ascending like dsyev.
 template <int N>
@@ -1127,6 +1167,16 @@ __device__ __forceinline__ unsigned plane_bits(const Lme<ND>& c, int k) {
 __device__ __forceinline__ double masked_weight(double e, unsigned bits, int i) {
   const int m = __builtin_amdgcn_sbfe((int)bits, (unsigned)i, 1u);
   return __hiloint2double(__double2hiint(e) & m, __double2loint(e));
+}
+
+// The same with an EXACT zero for a non-member (both words cleared): for values that are stored or accumulated on
+// their own, where a denormal left-over would survive (the window scatters in their branch-free form).
+#ifndef NLPS_SCATTER_BRANCHFREE
+#define NLPS_SCATTER_BRANCHFREE 0
+#endif
+__device__ __forceinline__ double masked_zero(double e, unsigned bits, int i) {
+  const int m = __builtin_amdgcn_sbfe((int)bits, (unsigned)i, 1u);
+  return __hiloint2double(__double2hiint(e) & m, __double2loint(e) & m);
 }
 
 // Wave-uniform test "does any lane of the wave hold a member in this stencil row".  The particles of a wave

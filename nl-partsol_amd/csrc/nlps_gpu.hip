@@ -86,6 +86,11 @@ struct NView {
   unsigned char* active;  // [nnodes]
   unsigned char* seed;    // [nnodes] 1 where some particle has this node as I0 (dilate_node turns it into `active`)
   const double* h_avg;    // [nnodes]
+  // [nnodes] {beta, T2, Ra, -}: beta__LME__ of a particle whose closest node this is (gamma / h_avg^2, LME.c:177-185),
+  // the cut-off radius Ra of the NEXT list built with that beta (LME.c:1052) and its exact squared form T2 =
+  // max{t : fl(sqrt(t)) <= Ra}; functions of the node alone, made once at create by the device functions K2 would
+  // otherwise call per particle and step (two divisions and three or more square roots)
+  const double4* beta_t2;
   double* nm;             // [nnodes][1+ND]
   double* dU;             // [nnodes][ND]
   double* force;          // [nnodes][ND]
@@ -139,10 +144,15 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
     const int layer = I0 / tc.plane, nl = g.n[ND - 1];
     const int s_lo = layer - 2 < 0 ? 0 : layer - 2, s_hi = layer + 2 > nl - 1 ? nl - 1 : layer + 2;
     if (s_lo < tc.win_lo || s_hi > tc.win_hi) {
+      // flagged AND left out of the lists: its stencil holds nodes nothing of this rank resets or exchanges (the per-node
+      // counters of the canonical lists among them), so no kernel may take it; it keeps its state, the re-sort keeps it
+      // (k_append_unbinned), a migration hands it on
       atomicOr(&P.status[p], ST_HALO);
       atomicOr(tc.gstatus, ST_HALO);
+      t = -1;
+      valid = false;
     }
-    if (t < tc.tile0 || t >= tc.tile0 + tc.ntw) {  // not binned: its tile is never launched
+    if (valid && (t < tc.tile0 || t >= tc.tile0 + tc.ntw)) {  // not binned: its tile is never launched
       t = -1;
       valid = false;
     }
@@ -1071,6 +1081,35 @@ __global__ void k_gather(T* __restrict__ out, const T* __restrict__ in, const in
   if (i < n) out[i] = in[idx[i]];
 }
 
+template <class T>
+__global__ void k_scatter(T* __restrict__ out, const T* __restrict__ in, const int* __restrict__ idx, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[idx[i]] = in[i];
+}
+
+// The tile lists only hold the particles the search could bin (tile >= 0).  Before the lists serve as the permutation
+// of a re-sort, the particles it flagged instead (ST_CONNECT, ST_HALO: tile = -1) are appended behind them, so the
+// permutation covers the whole cloud whatever the status word says (a flagged particle carries no order-dependent
+// sum: the positions among themselves come from a counter).
+// last_start / last_count: scan entry of the last tile of the node window (their sum = number of binned particles).
+__global__ void k_append_unbinned(int np, const int* __restrict__ tile, const int* __restrict__ last_start,
+                                  const int* __restrict__ last_count, int* __restrict__ counter, int* __restrict__ order) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np || tile[p] >= 0) return;
+  const int pos = *last_start + *last_count + atomicAdd(counter, 1);
+  if (pos < np) order[pos] = p;
+}
+
+__global__ void k_node_tables(int nn, const double* __restrict__ h_avg, double gamma_lme, double neg_log_tol_zero,
+                              double4* __restrict__ out) {
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nn) return;
+  const double hv = h_avg[A];
+  const double beta = gamma_lme / (hv * hv);
+  const double Ra = sqrt(neg_log_tol_zero / beta);
+  out[A] = make_double4(beta, sqrt_threshold(Ra), Ra, 0.0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1095,6 +1134,7 @@ struct nlps_gpu {
   std::vector<int> perm;  // sorted slot -> caller's particle index
   NView N;
   double* h_avg_d;
+  double4* beta_t2_d = nullptr;  // NView::beta_t2
   MatD* mats_d;
   int nmats;
   int uniform_law;  // material law shared by every particle, or -1
@@ -1106,6 +1146,10 @@ struct nlps_gpu {
   // masks
   int* n2m_d;
   int* d2m_d;
+  // nlps_gpu_set_node_numbering: lattice node of file node A (canon_d), and the scratch of the file-order mask scan
+  int* canon_d = nullptr;
+  unsigned char* mask_flags_d = nullptr;
+  int* mask_idx_d = nullptr;
   unsigned char* fixedm_d;
   int* bsum_d;
   int* total_d;
@@ -1199,6 +1243,8 @@ struct nlps_gpu {
 
   bool timing;
   hipEvent_t ev[8];
+  hipEvent_t evw[12] = {};  // brackets of the exchanges a step waits for (timing only)
+  int nwait = 0;
   float ms[8];
   int slab_lo, slab_hi;
   int win_lo, win_hi;  // node window (layers of the slowest axis) the per-step nodal work is limited to
@@ -1549,6 +1595,11 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     else host_h_avg(*grid, h->tab, hv);
     HIPCHK(hipMemcpy(h->h_avg_d, hv.data(), nn * sizeof(double), hipMemcpyHostToDevice));
     h->N.h_avg = h->h_avg_d;
+    HIPCHK(hipMalloc((void**)&h->beta_t2_d, nn * sizeof(double4)));
+    hipLaunchKernelGGL(k_node_tables, dim3(nblk((int)nn)), dim3(BLK), 0, 0, (int)nn, (const double*)h->h_avg_d,
+                       h->prm.gamma_lme, h->prm.neg_log_tol_zero, h->beta_t2_d);
+    HIPCHK(hipGetLastError());
+    h->N.beta_t2 = h->beta_t2_d;
   }
   // materials
   h->nmats = nmats;
@@ -1747,7 +1798,7 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
   // 64 distinct window rows -- so the periodic re-sort of the fused step takes them as its permutation: no keys, no
   // radix sort.  Otherwise (first sort, migration, level-B callers): sort by (tile, corner type, node).
   const bool from_lists = !leaving && live_only && h->binned && h->order2_d && (h->tile_ordering || h->deterministic) &&
-                          h->resort_from_lists;
+                          h->resort_from_lists && h->ntw > 0;
   if (!from_lists) {
     TileCnt tc;
     for (int a = 0; a < 3; a++) tc.nt[a] = h->nt[a];
@@ -1760,6 +1811,12 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
     size_t bytes = h->cub_tmp_bytes;
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
                                               h->stream));
+  }
+  if (from_lists) {  // particles the search flagged instead of binning go behind the lists (k_append_unbinned)
+    HIPCHK(hipMemsetAsync(h->mig_cnt_d, 0, sizeof(int), h->stream));
+    const int last = h->tile0 + h->ntw - 1;
+    hipLaunchKernelGGL(k_append_unbinned, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, (const int*)h->P.tile,
+                       (const int*)h->tile_start_d + last, (const int*)h->tile_count_d + last, h->mig_cnt_d, h->order2_d);
   }
   const int* idx = from_lists ? h->order2_d : h->sval2_d;  // new slot -> old slot
   const size_t npad = h->P.npad;
@@ -1973,7 +2030,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   (void)nlps_gpu_rccl_detach(h);
   (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
-                  h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->n2m_d, h->d2m_d,
+                  h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
@@ -1983,6 +2040,8 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
     if (b.dnodes) (void)hipFree(b.dnodes);
   if (h->foreign_h) (void)hipHostFree(h->foreign_h);
   for (int i = 0; i < 8; i++) (void)hipEventDestroy(h->ev[i]);
+  for (hipEvent_t e : h->evw)
+    if (e) (void)hipEventDestroy(e);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -2112,6 +2171,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 static RcclApi g_rccl;
 static const char* rccl_load() {  // nullptr = loaded
@@ -2134,6 +2195,8 @@ static const char* rccl_load() {  // nullptr = loaded
   NLPS_SYM(AllReduce, "ncclAllReduce")
   NLPS_SYM(Reduce, "ncclReduce")
   NLPS_SYM(GetErrorString, "ncclGetErrorString")
+  NLPS_SYM(CommCount, "ncclCommCount")
+  NLPS_SYM(CommUserRank, "ncclCommUserRank")
 #undef NLPS_SYM
   g_rccl.lib = L;
   return nullptr;
@@ -2153,6 +2216,7 @@ struct RcclHalo {
   };
   std::map<const void*, Ev> ev;  // one pair of events per nodal array, re-recorded every step
   bool self_loop = false;        // world 1 self-test: the rank is its own two neighbours
+  int* mig_cnt_d = nullptr;      // nlps_gpu_rccl_migrate: {rows to below, rows to above, rows from below, rows from above}
   // single-launch overlap (TileD::sig_flag): counters in device memory, flags in signal memory, one pair per stage
   unsigned* sig_cnt = nullptr;   // [2]
   unsigned* sig_flag[2] = {nullptr, nullptr};
@@ -2162,12 +2226,13 @@ struct RcclHalo {
 
 // Holds the exchange stream until the boundary tiles of the launch in flight on the handle's stream have published
 // `seq` (tile_signal).  One lane polls an agent-scope load with s_sleep in between; it occupies one wave slot of one CU
-// and depends on nothing but the flag, and it gives up after ~1 s so that a launch that never happens cannot hang it
-// (hipStreamWaitValue32 does the same through the host: measured 55 us from the store to the next command, against
-// a few us for this kernel).
+// and depends on nothing but the flag, and it gives up after about one second of the constant 100 MHz clock
+// (wall_clock64), so that a launch that never happens cannot hang it (hipStreamWaitValue32 does the same through the
+// host: measured 55 us from the store to the next command, against a few us for this kernel).
 __global__ void k_wait_flag(const unsigned* __restrict__ flag, unsigned seq, int* __restrict__ gstatus) {
   if (threadIdx.x != 0) return;
-  for (long long it = 0; it < 20000000ll; it++) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 100000000ull) {
     const unsigned v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     if ((int)(v - seq) >= 0) return;
     __builtin_amdgcn_s_sleep(32);
@@ -2257,7 +2322,15 @@ static int rccl_exchange_on(nlps_gpu* h, void* dptr, int nfield, int elem, int k
 static int rccl_halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase) {
   RcclHalo* R = h->rccl;
   // (a rank without neighbours still goes through the stream choreography: that is how a one-GPU box rehearses it)
-  if (phase == 0) return rccl_exchange_on(h, dptr, nfield, elem, kind, h->stream);
+  if (phase == 0) {
+    // the receive buffers are shared with the side stream: an exchange still pending there finishes first
+    for (auto& kv : R->ev)
+      if (kv.second.pending) {
+        HIPCHK(hipStreamWaitEvent(h->stream, kv.second.done, 0));
+        kv.second.pending = false;
+      }
+    return rccl_exchange_on(h, dptr, nfield, elem, kind, h->stream);
+  }
   RcclHalo::Ev& e = R->ev[dptr];
   if (!e.start) {
     HIPCHK(hipEventCreateWithFlags(&e.start, hipEventDisableTiming));
@@ -2294,6 +2367,7 @@ extern "C" int nlps_gpu_rccl_unique_id(void* id128) {
   return 0;
 }
 
+extern "C" int nlps_gpu_rccl_detach(nlps_gpu* h);
 static int rccl_attach_common(nlps_gpu* h, ncclComm_t comm, bool own, int rank, int world, const int* layer_lo,
                               const int* layer_hi, int mode) {
   if (h->rccl) {
@@ -2327,7 +2401,11 @@ static int rccl_attach_common(nlps_gpu* h, ncclComm_t comm, bool own, int rank, 
       h->err = "nlps_gpu_rccl_attach: slabs too thin (a rank overlaps its second neighbour)";
       return 1;
     }
-  HIPCHK(hipStreamCreateWithFlags(&R->side, hipStreamNonBlocking));
+  if (hipStreamCreateWithFlags(&R->side, hipStreamNonBlocking) != hipSuccess) {
+    delete R;
+    h->err = "nlps_gpu_rccl_attach: hipStreamCreateWithFlags failed";
+    return 1;
+  }
   {
     bool ok = hipMalloc((void**)&R->sig_cnt, 2 * sizeof(unsigned)) == hipSuccess &&
               hipMemset(R->sig_cnt, 0, 2 * sizeof(unsigned)) == hipSuccess;
@@ -2345,7 +2423,15 @@ static int rccl_attach_common(nlps_gpu* h, ncclComm_t comm, bool own, int rank, 
   h->band_hi = rank + 1 < world && R->lo[rank + 1] <= R->hi[rank] ? band_hi : (1 << 30);
   // 2: one launch per stage, the exchange released by the boundary tiles through signal memory; 1: split launches
   h->overlap = world > 1 ? (R->can_wait_value ? 2 : 1) : 0;
-  if (world > 1 && nlps_gpu_set_node_window(h, R->lo[rank], R->hi[rank])) return 1;
+  if (world > 1 && nlps_gpu_set_node_window(h, R->lo[rank], R->hi[rank])) {
+    // the handle must not keep a half-attached exchange: the caller still owns `comm` (it destroys its own, or the
+    // wrapper below destroys the one it made), so the detach here must leave it alone
+    const std::string err = h->err;
+    R->own_comm = false;
+    (void)nlps_gpu_rccl_detach(h);
+    h->err = err;
+    return 1;
+  }
   return 0;
 }
 
@@ -2353,6 +2439,10 @@ extern "C" int nlps_gpu_rccl_attach(nlps_gpu* h, const void* id128, int rank, in
                                     const int* layer_hi, int mode) {
   if (const char* e = rccl_load()) {
     h->err = e;
+    return 1;
+  }
+  if (h->rccl) {  // before the collective below: a second attach must not block on (or create) a communicator
+    h->err = "nlps_gpu_rccl_attach: a communicator is attached already (nlps_gpu_rccl_detach first)";
     return 1;
   }
   ncclUniqueId id;
@@ -2388,6 +2478,7 @@ extern "C" int nlps_gpu_rccl_detach(nlps_gpu* h) {
     if (R->sig_flag[k]) (void)hipFree(R->sig_flag[k]);
   }
   if (R->sig_cnt) (void)hipFree(R->sig_cnt);
+  if (R->mig_cnt_d) (void)hipFree(R->mig_cnt_d);
   if (R->side) (void)hipStreamDestroy(R->side);
   if (R->own_comm && R->comm) (void)g_rccl.CommDestroy(R->comm);
   delete R;
@@ -2430,7 +2521,122 @@ extern "C" int nlps_gpu_rccl_selftest_exchange(nlps_gpu* h, void* dptr, int nfie
   return st;
 }
 
+static int halo_dispatch(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase);
+// What the attached communicator says about itself (ncclCommCount / ncclCommUserRank: the rank count RCCL really
+// runs with, not the one the caller asked for) and the overlap choreography in force (0 blocking, 1 split launches,
+// 2 one launch per stage).
+extern "C" int nlps_gpu_rccl_info(nlps_gpu* h, int* nranks, int* rank, int* overlap_mode) {
+  RcclHalo* R = h->rccl;
+  if (!R) {
+    h->err = "nlps_gpu_rccl_info: no communicator attached";
+    return 1;
+  }
+  int n = 0, r = 0;
+  RCCLCHK(g_rccl.CommCount(R->comm, &n));
+  RCCLCHK(g_rccl.CommUserRank(R->comm, &r));
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (overlap_mode) *overlap_mode = h->overlap;
+  return 0;
+}
+
+// Particle migration between slab ranks with the transport inside the library (a C driver needs no Python):
+// select + pack (nlps_gpu_migration_select), the row counts and then the rows themselves exchanged with the two
+// neighbours by ncclSend / ncclRecv on the handle's stream, commit.  self_loop (world 1 only): the rank is its own two
+// neighbours, so what leaves comes straight back -- every call on the wire runs on a one-GPU box.
+static int rccl_migrate(nlps_gpu* h, int keep_lo, int keep_hi, int* sent_down, int* sent_up, int* received, bool self_loop) {
+  RcclHalo* R = h->rccl;
+  if (!R) {
+    h->err = "nlps_gpu_rccl_migrate: no communicator attached (nlps_gpu_rccl_attach)";
+    return 1;
+  }
+  if (self_loop && R->world != 1) {
+    h->err = "nlps_gpu_rccl_selftest_migrate: needs an attached communicator of world size 1";
+    return 1;
+  }
+  const int nl = h->g.n[h->nd - 1];
+  if (!self_loop) {  // an edge rank has no neighbour on its outer side: nothing may be selected towards it
+    if (R->rank == 0) keep_lo = 0;
+    if (R->rank == R->world - 1) keep_hi = nl - 1;
+  }
+  int n_out[2] = {0, 0}, rw = 0;
+  void* rows_out[2] = {nullptr, nullptr};
+  if (nlps_gpu_migration_select(h, keep_lo, keep_hi, &n_out[0], &n_out[1], &rw, &rows_out[0], &rows_out[1])) return 1;
+  if (sent_down) *sent_down = n_out[0];
+  if (sent_up) *sent_up = n_out[1];
+  if (received) *received = 0;
+  int peer[2] = {R->rank - 1, R->rank + 1};
+  bool has[2] = {peer[0] >= 0, peer[1] < R->world};
+  if (self_loop) {
+    peer[0] = peer[1] = R->rank;
+    has[0] = has[1] = true;
+  }
+  if (!has[0] && !has[1]) return nlps_gpu_migration_commit(h, nullptr, 0, nullptr, 0);
+  if (!R->mig_cnt_d) HIPCHK(hipMalloc((void**)&R->mig_cnt_d, 4 * sizeof(int)));
+  // 1. how many rows come from each neighbour
+  int cnt[4] = {n_out[0], n_out[1], 0, 0};
+  HIPCHK(hipMemcpyAsync(R->mig_cnt_d, cnt, 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  RCCLCHK(g_rccl.GroupStart());
+  for (int k = 0; k < 2; k++) {
+    if (!has[k]) continue;
+    // (self-loop: sends and receives between one pair match in the order posted, so what went "down" arrives as
+    // "from below" -- which neighbour it stands for does not matter to the commit)
+    RCCLCHK(g_rccl.Send(R->mig_cnt_d + k, 1, ncclInt32, peer[k], R->comm, h->stream));
+    RCCLCHK(g_rccl.Recv(R->mig_cnt_d + 2 + k, 1, ncclInt32, peer[k], R->comm, h->stream));
+  }
+  RCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipMemcpyAsync(cnt, R->mig_cnt_d, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int n_in[2] = {cnt[2], cnt[3]};
+  if (n_in[0] < 0 || n_in[1] < 0 || (size_t)h->P.np + n_in[0] + n_in[1] > h->P.npad) {
+    h->err = "nlps_gpu_rccl_migrate: more immigrants than the capacity reserved at create (np + max(np/4, 1024))";
+    return 1;
+  }
+  // 2. the rows
+  double* rows_in[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; k++)
+    if (n_in[k] > 0) HIPCHK(hipMalloc((void**)&rows_in[k], (size_t)n_in[k] * rw * sizeof(double)));
+  RCCLCHK(g_rccl.GroupStart());
+  for (int k = 0; k < 2; k++) {
+    if (!has[k]) continue;
+    if (n_out[k] > 0) RCCLCHK(g_rccl.Send(rows_out[k], (size_t)n_out[k] * rw, ncclDouble, peer[k], R->comm, h->stream));
+    if (n_in[k] > 0) RCCLCHK(g_rccl.Recv(rows_in[k], (size_t)n_in[k] * rw, ncclDouble, peer[k], R->comm, h->stream));
+  }
+  RCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int st = nlps_gpu_migration_commit(h, rows_in[0], n_in[0], rows_in[1], n_in[1]);
+  for (int k = 0; k < 2; k++)
+    if (rows_in[k]) (void)hipFree(rows_in[k]);
+  if (received) *received = n_in[0] + n_in[1];
+  return st;
+}
+extern "C" int nlps_gpu_rccl_migrate(nlps_gpu* h, int keep_lo, int keep_hi, int* sent_down, int* sent_up, int* received) {
+  return rccl_migrate(h, keep_lo, keep_hi, sent_down, sent_up, received, false);
+}
+extern "C" int nlps_gpu_rccl_selftest_migrate(nlps_gpu* h, int keep_lo, int keep_hi, int* sent_down, int* sent_up,
+                                              int* received) {
+  return rccl_migrate(h, keep_lo, keep_hi, sent_down, sent_up, received, true);
+}
+
 static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase = 0) {
+  // (with timing on, the exchanges the handle's stream has to wait for -- blocking ones, and the pick-up of overlapped
+  // ones -- are bracketed: their sum is what a step loses to communication, nlps_gpu_get_timing slot 6)
+  const bool bracket = h->timing && (phase == 0 || phase == 2) && (h->rccl || h->halo) && h->nwait < 6;
+  if (bracket) {
+    if (!h->evw[2 * h->nwait]) {
+      HIPCHK(hipEventCreate(&h->evw[2 * h->nwait]));
+      HIPCHK(hipEventCreate(&h->evw[2 * h->nwait + 1]));
+    }
+    HIPCHK(hipEventRecord(h->evw[2 * h->nwait], h->stream));
+  }
+  const int st_ = halo_dispatch(h, dptr, nfield, elem, kind, phase);
+  if (bracket) {
+    HIPCHK(hipEventRecord(h->evw[2 * h->nwait + 1], h->stream));
+    h->nwait++;
+  }
+  return st_;
+}
+static int halo_dispatch(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int phase) {
   if (h->rccl) return rccl_halo(h, dptr, nfield, elem, kind, phase);
   if (!h->halo) return 0;
   int st = h->halo(h->halo_ctx, dptr, nfield, elem, kind, phase);
@@ -2445,10 +2651,54 @@ static int halo(nlps_gpu* h, void* dptr, int nfield, int elem, int kind, int pha
 
 static int compute_node_mask(nlps_gpu* h) {
   int nn = h->g.nnodes, nb = (nn + 1023) / 1024;
+  if (h->canon_d) {
+    // the running index of get_active_nodes__MeshTools__ (Nodes-Tools.c:46-66) follows the mesh FILE's node order: scan
+    // the flags in that order, then hand every lattice node its index
+    hipLaunchKernelGGL(k_gather<unsigned char>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, h->mask_flags_d,
+                       (const unsigned char*)h->N.active, (const int*)h->canon_d, nn);
+    hipLaunchKernelGGL(k_scan_count, dim3(nb), dim3(256), 0, h->stream, h->mask_flags_d, nn, 0, h->bsum_d);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, h->stream, h->bsum_d, nb, h->total_d);
+    hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(256), 0, h->stream, h->mask_flags_d, nn, 0, h->bsum_d, h->mask_idx_d);
+    hipLaunchKernelGGL(k_scatter<int>, dim3(nblk(nn)), dim3(BLK), 0, h->stream, h->n2m_d, (const int*)h->mask_idx_d,
+                       (const int*)h->canon_d, nn);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_scan_count, dim3(nb), dim3(256), 0, h->stream, h->N.active, nn, 0, h->bsum_d);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, h->stream, h->bsum_d, nb, h->total_d);
   hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(256), 0, h->stream, h->N.active, nn, 0, h->bsum_d, h->n2m_d);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Masked numbering in the node order of the mesh file (see include/nlps_gpu.h)
+extern "C" int nlps_gpu_set_node_numbering(nlps_gpu* h, const int* lattice_of_file) {
+  const int nn = h->g.nnodes;
+  h->masks_valid = false;
+  if (!lattice_of_file) {
+    if (h->canon_d) {
+      HIPCHK(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->canon_d);
+      h->canon_d = nullptr;
+    }
+    return 0;
+  }
+  std::vector<unsigned char> seen(nn, 0);
+  for (int A = 0; A < nn; A++) {
+    const int l = lattice_of_file[A];
+    if (l < 0 || l >= nn || seen[l]) {
+      h->err = "nlps_gpu_set_node_numbering: lattice_of_file is not a permutation of the grid's nodes";
+      return 1;
+    }
+    seen[l] = 1;
+  }
+  if (!h->canon_d) {
+    HIPCHK(hipMalloc((void**)&h->canon_d, (size_t)nn * sizeof(int)));
+    if (!h->mask_flags_d) HIPCHK(hipMalloc((void**)&h->mask_flags_d, (size_t)nn));
+    if (!h->mask_idx_d) HIPCHK(hipMalloc((void**)&h->mask_idx_d, (size_t)nn * sizeof(int)));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->canon_d, lattice_of_file, (size_t)nn * sizeof(int), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -2729,7 +2979,9 @@ extern "C" int nlps_gpu_active_masks(nlps_gpu* h, const nlps_bcc* bcc, int nbcc,
   if (order == 0) h->nfree = 0;
   if (nactive) *nactive = h->nactive;
   if (nfree_dofs) *nfree_dofs = h->nfree;
-  if (nodes2mask) HIPCHK(hipMemcpy(nodes2mask, h->n2m_d, (size_t)nn * sizeof(int), hipMemcpyDeviceToHost));
+  // (with a file numbering set, Nodes2Mask is indexed by the file's node, like the reference's array)
+  if (nodes2mask)
+    HIPCHK(hipMemcpy(nodes2mask, h->canon_d ? h->mask_idx_d : h->n2m_d, (size_t)nn * sizeof(int), hipMemcpyDeviceToHost));
   if (dofs2mask && order) HIPCHK(hipMemcpy(dofs2mask, h->d2m_d, (size_t)order * sizeof(int), hipMemcpyDeviceToHost));
   h->masks_valid = true;
   return 0;
@@ -3033,6 +3285,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (resort(h, nullptr, true)) return 1;
   }
   h->steps_since_sort++;
+  h->nwait = 0;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   // With a halo callback and ghost bands set, every exchange is started right after the tiles that touch a
   // ghost band have produced their part and is waited for only before those tiles need the result; the tiles
@@ -3288,6 +3541,12 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     h->ms[2] = t34;
     h->ms[3] = t56;
     h->ms[4] = t23 + t45;
+    h->ms[6] = 0.f;  // time the handle's stream spent in / waiting for the ghost-layer exchanges of this step
+    for (int q = 0; q < h->nwait; q++) {
+      float tw = 0.f;
+      HIPCHK(hipEventElapsedTime(&tw, h->evw[2 * q], h->evw[2 * q + 1]));
+      h->ms[6] += tw;
+    }
   }
   return 0;
 }

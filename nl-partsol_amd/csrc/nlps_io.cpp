@@ -629,6 +629,11 @@ extern "C" int nlps_host_read_deck(const char* path, nlps_deck* d) {
         return 1;
       if ((!strcmp(d->shape_fun, "LME") || !strcmp(d->shape_fun, "aLME")) && d->gamma_lme == 0)
         return fail("GramsShapeFun: gamma parameter required for LME !!!");
+      // wrapper=Nelder-Mead makes initialize__LME__ start lambda from initialise_lambda__LME__ (LME.c:97-101, 189-268:
+      // a simplex of the particle's element in the file's connectivity order; exit(0) for 8-node elements), which this
+      // path does not restate: say so instead of running Newton from lambda = 0 as if nothing had been asked
+      if (d->wrapper_lme[0] && strcmp(d->wrapper_lme, "Newton-Raphson"))
+        return fail("GramsShapeFun: wrapper=Newton-Raphson is the only LME wrapper of the GPU path (Nelder-Mead stays on the CPU path)");
     } else if (!strcmp(w[0], "GramsBox")) {
       copy.assign(in.buf.begin(), in.buf.begin() + strlen(in.buf.data()) + 1);
       if (tokens(copy.data(), " =,()\r\n\t", w) < 5 || strcmp(w[1], "Type") || strcmp(w[3], "File"))

@@ -361,7 +361,7 @@ __global__ void k_fill_order(int np, const int* __restrict__ tile, const int* __
 template <int ND, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, const int* order_in, int* order) {
   constexpr int TB = TileCfg<ND>::TB, NN = (ND == 3) ? TB * TB * TB : TB * TB;
-  constexpr int CAP = EXACT ? 4096 : 1536, LMAX = 32;  // larger tiles / deeper nodes keep the order of the binning
+  constexpr int CAP = EXACT ? 4096 : 1536, LMAX = 32;  // larger tiles / deeper nodes: order of the binning (EXACT: by slot index)
   __shared__ int cnt[NN];
   __shared__ unsigned short tbl[LMAX][NN];
   __shared__ int lsize[LMAX + 1];
@@ -372,8 +372,19 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
   const int tile = td.work[0][wb].x;
   const int n = td.count[tile];
   const int start = td.start[tile];
-  if (n > CAP || n <= 1) {  // keeps the order of the binning
-    if (order_in != order)
+  if (n > CAP || n <= 1) {
+    if (EXACT && n > 1) {
+      // deterministic mode, tile too large for the LDS sort: ascending slot index, ranks counted straight from the
+      // binned list (O(n^2) reads of an L1-resident list: slow, but the list is a function of the particle arrays alone)
+      for (int s = threadIdx.x; s < n; s += 256) {
+        const int p = order_in[start + s];
+        int r = 0;
+        for (int q = 0; q < n; q++) r += (order_in[start + q] < p) ? 1 : 0;
+        order[start + r] = p;
+      }
+      return;
+    }
+    if (order_in != order)  // keeps the order of the binning
       for (int s = threadIdx.x; s < n; s += 256) order[start + s] = order_in[start + s];
     return;
   }
@@ -406,6 +417,15 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
   __syncthreads();
   const int nl = maxc;
   if (nl > LMAX) {  // uniform: every thread reads the same maxc
+    if (EXACT) {  // a closest node deeper than the layer table: ascending slot index (deterministic, see above)
+      for (int s = threadIdx.x; s < n; s += 256) {
+        const int p = pp[s];
+        int r = 0;
+        for (int q = 0; q < n; q++) r += (pp[q] < p) ? 1 : 0;  // LDS broadcast reads
+        order[start + r] = p;
+      }
+      return;
+    }
     if (order_in != order)
       for (int s = threadIdx.x; s < n; s += 256) order[start + s] = pp[s];
     return;
@@ -435,6 +455,71 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
   for (int s = threadIdx.x; s < n; s += 256) {
     const int node = keys[s] & 0xFFFF, r = keys[s] >> 16;
     order[start + lsize[r] + tbl[r][node]] = pp[s];
+  }
+}
+
+// Developer ablations (tools/kbench.py, never in the product build): NLPS_ABL_ATOM = 1 keeps the arithmetic of the window
+// scatters but issues no LDS atomic (the test value never occurs); NLPS_ABL_GATHER = 1 replaces the window reads of the
+// gathers by a register constant.  They bound what the LDS work of a kernel costs beside its arithmetic.
+#ifndef NLPS_K3_TWOPASS_ALL
+#define NLPS_K3_TWOPASS_ALL 0
+#endif
+#ifndef NLPS_ABL_ATOM
+#define NLPS_ABL_ATOM 0
+#endif
+#ifndef NLPS_ABL_GATHER
+#define NLPS_ABL_GATHER 0
+#endif
+__device__ __forceinline__ void lds_add(double* a, double v) {
+#if NLPS_ABL_ATOM
+  if (v == 1.2345e300)
+#endif
+    atomicAdd(a, v);
+}
+
+// ---- 3-D window helpers without divisions: the 8 x 8 x 8 window is walked as r = lx + 8 (ly + 8 lz) -----------------
+#ifndef NLPS_FAST_WINDOWS
+#define NLPS_FAST_WINDOWS 1
+#endif
+// global node of window cell r (3-D); inside = false outside the grid
+__device__ __forceinline__ int window_cell3(const GridD& g, const int* w0, int r, bool& inside) {
+  const int gi = w0[0] + (r & 7), gj = w0[1] + ((r >> 3) & 7), gk = w0[2] + (r >> 6);
+  inside = gi >= 0 && gi < g.n[0] && gj >= 0 && gj < g.n[1] && gk >= 0 && gk < g.n[2];
+  return gi + g.n[0] * (gj + g.n[1] * gk);
+}
+// active flags of the 3-D window as one bit row per (y,z) line: four threads share a line (two nodes each), the bits meet
+// through two lane exchanges -- no LDS atomics, no zeroing pass, byte loads of runs of the node array
+template <int NT>
+__device__ __forceinline__ void window_actrows3(const GridD& g, const int* w0, const unsigned char* __restrict__ active,
+                                                unsigned* actrow) {
+  for (int t = threadIdx.x; t < 256; t += NT) {
+    const int row = t >> 2, q = t & 3;
+    const int gj = w0[1] + (row & 7), gk = w0[2] + (row >> 3), gi = w0[0] + 2 * q;
+    const bool rin = gj >= 0 && gj < g.n[1] && gk >= 0 && gk < g.n[2];
+    const size_t n0 = (size_t)g.n[0] * ((size_t)gj + (size_t)g.n[1] * (size_t)gk);
+    unsigned bits = 0u;
+    if (rin && gi >= 0 && gi < g.n[0] && active[n0 + gi]) bits |= 1u << (2 * q);
+    if (rin && gi + 1 >= 0 && gi + 1 < g.n[0] && active[n0 + gi + 1]) bits |= 2u << (2 * q);
+    bits |= __shfl_xor(bits, 1);
+    bits |= __shfl_xor(bits, 2);
+    if (q == 0) actrow[row] = bits;
+  }
+}
+// flush of a 3-D accumulator window (WA / PSA layout, NF fields per node contiguous in `out`): consecutive lanes take
+// consecutive doubles of `out` (field fastest, then the 8 nodes of a window row), so one wave-instruction of atomics
+// covers runs of 8 NF doubles
+template <int NF, int NT>
+__device__ __forceinline__ void window_flush3(const GridD& g, const int* w0, const double* acc, double* __restrict__ out) {
+  constexpr int WA = TileCfg<3>::WA, PSA = TileCfg<3>::PSA, NWA = TileCfg<3>::NWA;
+#pragma unroll 2
+  for (int e = threadIdx.x; e < 512 * NF; e += NT) {
+    const int r = e / NF, f = e - r * NF;
+    const double v = acc[f * NWA + (r & 7) + WA * ((r >> 3) & 7) + PSA * (r >> 6)];
+    if (v != 0.0) {
+      bool in;
+      const int node = window_cell3(g, w0, r, in);
+      if (in) atomic_add_f64(out + (size_t)node * NF + f, v);
+    }
   }
 }
 
@@ -487,15 +572,21 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
   PH_INIT
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int r = threadIdx.x; r < NROWS; r += NT) actrow[r] = 0u;
-  if (P2G)
-    for (int idx = threadIdx.x; idx < NF * NWA; idx += NT) acc[idx] = 0.0;
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < NW; idx += NT) {
-    bool in;
-    int row, col;
-    int node = window_node<ND>(g, w0, idx, in, &row, &col);
-    if (in && N.active[node]) atomicOr(&actrow[row], 1u << col);
+  if (ND == 3 && NLPS_FAST_WINDOWS) {
+    if (P2G)
+      for (int idx = threadIdx.x; idx < NF * NWA; idx += NT) acc[idx] = 0.0;
+    window_actrows3<NT>(g, w0, N.active, actrow);
+  } else {
+    for (int r = threadIdx.x; r < NROWS; r += NT) actrow[r] = 0u;
+    if (P2G)
+      for (int idx = threadIdx.x; idx < NF * NWA; idx += NT) acc[idx] = 0.0;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NW; idx += NT) {
+      bool in;
+      int row, col;
+      int node = window_node<ND>(g, w0, idx, in, &row, &col);
+      if (in && N.active[node]) atomicOr(&actrow[row], 1u << col);
+    }
   }
   __syncthreads();
   const int start = td.start[tile];
@@ -521,8 +612,19 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
     const int bx = c.ijk[0] - w0[0], by = c.ijk[1] - w0[1], bz = (ND == 3) ? c.ijk[2] - w0[2] : 0;
     const int base = bx + WA * by + (ND == 3 ? PSA * bz : 0);  // slot of I0 in the accumulator window
     const double beta_prev = PF(P, F_BETA, p);
-    const double Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052
-    const double T2 = sqrt_threshold(Ra);                       // sqrt(|l|^2) <= Ra  <=>  |l|^2 <= T2
+    // beta of this step and the squared cut-off that belongs to it come from the node table; the list of THIS step is
+    // cut with the beta of the previous one (LME.c:973,983-984), which is the same number whenever the old and the new
+    // closest node have the same h_avg -- everywhere but beside the grid boundary and at the first search (beta = 0)
+    const double4 bt = N.beta_t2[I0];
+    const double beta = bt.x;
+    double Ra, T2;
+    if (__builtin_amdgcn_ballot_w64(beta_prev != beta) == 0ull) {
+      T2 = bt.y;
+      Ra = bt.z;
+    } else {
+      Ra = sqrt(prm.neg_log_tol_zero / beta_prev);  // LME.c:1052
+      T2 = sqrt_threshold(Ra);                       // sqrt(|l|^2) <= Ra  <=>  |l|^2 <= T2
+    }
     double lx2[5], ly2[5], lz2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < 5; i++) {
@@ -563,8 +665,6 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
       atomicOr(gstatus, ST_CONNECT);
       continue;
     }
-    const double hv = N.h_avg[I0];
-    const double beta = prm.gamma_lme / (hv * hv);
     PH(1)
     int st = 0, NumIter = 0;
     double Zinv = 0.0;
@@ -577,7 +677,7 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
 #pragma unroll
       for (int a = 0; a < ND; a++) aux += dsqr(r[a]);
       if (sqrt(aux) > prm.tol_wrapper) {
-        if (rcond_ref<ND>(J) < 1E-8 || !inverse<ND>(Jm1, J)) {
+        if (rcond_below_gate<ND>(J) || !inverse<ND>(Jm1, J)) {
           st |= ST_NEWTON;
           break;
         }
@@ -668,13 +768,23 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
         const double w = wz * ey5[j];
 #pragma unroll
         for (int i = 0; i < 5; i++)
+#if NLPS_SCATTER_BRANCHFREE
+        {  // every window slot of the stencil exists: non-members add an exact zero instead of branching around
+          const int li = basek + (i - 2) + WA * (j - 2);
+          const double v0 = w * masked_zero(c.ex[i], bits, i);
+          lds_add(&acc[li], v0);
+#pragma unroll
+          for (int a = 0; a < ND; a++) lds_add(&acc[(1 + a) * NWA + li], v0 * dd[a]);
+        }
+#else
           if ((bits >> i) & 1u) {
             const int li = basek + (i - 2) + WA * (j - 2);
             const double v0 = w * c.ex[i];
-            atomicAdd(&acc[li], v0);
+            lds_add(&acc[li], v0);
 #pragma unroll
-            for (int a = 0; a < ND; a++) atomicAdd(&acc[(1 + a) * NWA + li], v0 * dd[a]);
+            for (int a = 0; a < ND; a++) lds_add(&acc[(1 + a) * NWA + li], v0 * dd[a]);
           }
+#endif
       }
     }
     PH(3)
@@ -687,15 +797,20 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
     for (int q = threadIdx.x; q < NWA * NF; q += NT) out[q] = acc[q];
     return;
   }
-  for (int q = threadIdx.x; q < NWA * NF; q += NT) {
-    int f = q % NF, idx = q / NF;
-    double v = acc[f * NWA + idx];
-    if (v != 0.0) {
-      bool in;
-      int node = window_node_a<ND>(g, w0, idx, in);
-      if (in) atomic_add_f64(N.nm + (size_t)node * NF + f, v);
+  if (ND == 3 && NLPS_FAST_WINDOWS) {
+    window_flush3<NF, NT>(g, w0, acc, N.nm);
+  } else {
+    for (int q = threadIdx.x; q < NWA * NF; q += NT) {
+      int f = q % NF, idx = q / NF;
+      double v = acc[f * NWA + idx];
+      if (v != 0.0) {
+        bool in;
+        int node = window_node_a<ND>(g, w0, idx, in);
+        if (in) atomic_add_f64(N.nm + (size_t)node * NF + f, v);
+      }
     }
   }
+  PH(5)
   tile_signal(td, wb, nbnd);
 }
 
@@ -786,9 +901,16 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
   }
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int idx = threadIdx.x; idx < NW; idx += NT) {
+  for (int idx0 = threadIdx.x; idx0 < ((ND == 3 && NLPS_FAST_WINDOWS) ? 512 : NW); idx0 += NT) {
     bool in;
-    int node = window_node<ND>(g, w0, idx, in);
+    int node, idx;
+    if (ND == 3 && NLPS_FAST_WINDOWS) {
+      node = window_cell3(g, w0, idx0, in);
+      idx = (idx0 & 63) + PS * (idx0 >> 6);
+    } else {
+      idx = idx0;
+      node = window_node<ND>(g, w0, idx, in);
+    }
     duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
     duxy[2 * idx + 1] = in ? N.dU[(size_t)node * ND + 1] : 0.0;
     if (ND == 3) duz[(ND == 3) ? idx : 0] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
@@ -832,7 +954,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
     // which is what lets the elastic laws run at three waves per SIMD; it costs ~350 more VALU instructions a particle.
     // (the level-B modes keep the single pass: with and without rate tensors they must give the same F bit for bit)
     // and the laws that stay at two waves per SIMD keep it too: there the second set of masked weights only costs)
-    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN;
+    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && (LAW == NLPS_MAT_NEO_HOOKEAN || NLPS_K3_TWOPASS_ALL);
     if (TWOPASS) {
 #pragma unroll 1
       for (int k = 0; k < KN; k++) {
@@ -851,8 +973,13 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
 #pragma unroll
           for (int i = 0; i < 5; i++) {
             const int li = basek + (i - 2) + W * (j - 2);
+#if NLPS_ABL_GATHER
+            const double2 u01 = make_double2(c.lx[2] + (double)li, c.ly[2]);
+            const double u2 = c.lx[3];
+#else
             const double2 u01 = du2[li];
             const double u2 = duz[(ND == 3) ? li : 0];
+#endif
             const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
             for (int a = 0; a < ND; a++) {
@@ -1188,12 +1315,21 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
           for (int a = 0; a < ND; a++) cr[a] = fma(hB[a * ND + 1], (double)(j - 2), cz[a]);
 #pragma unroll
           for (int i = 0; i < 5; i++)
+#if NLPS_SCATTER_BRANCHFREE
+          {
+            const int li = basek + (i - 2) + WA * (j - 2);
+            const double we = w * masked_zero(c.ex[i], bits, i);
+#pragma unroll
+            for (int a = 0; a < ND; a++) lds_add(&fac[a * NWA + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
+          }
+#else
             if ((bits >> i) & 1u) {
               const int li = basek + (i - 2) + WA * (j - 2);
               const double we = w * c.ex[i];
 #pragma unroll
-              for (int a = 0; a < ND; a++) atomicAdd(&fac[a * NWA + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
+              for (int a = 0; a < ND; a++) lds_add(&fac[a * NWA + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
             }
+#endif
         }
       }
     } else {
@@ -1213,15 +1349,20 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
     for (int qq = threadIdx.x; qq < NWA * ND; qq += NT) out[qq] = fac[qq];
     return;
   }
-  for (int qq = threadIdx.x; qq < NWA * ND; qq += NT) {
-    int f = qq % ND, idx = qq / ND;
-    double v = fac[f * NWA + idx];
-    if (v != 0.0) {
-      bool in;
-      int node = window_node_a<ND>(g, w0, idx, in);
-      if (in) atomic_add_f64(N.force + (size_t)node * ND + f, v);
+  if (ND == 3 && NLPS_FAST_WINDOWS) {
+    window_flush3<ND, NT>(g, w0, fac, N.force);
+  } else {
+    for (int qq = threadIdx.x; qq < NWA * ND; qq += NT) {
+      int f = qq % ND, idx = qq / ND;
+      double v = fac[f * NWA + idx];
+      if (v != 0.0) {
+        bool in;
+        int node = window_node_a<ND>(g, w0, idx, in);
+        if (in) atomic_add_f64(N.force + (size_t)node * ND + f, v);
+      }
     }
   }
+  PH(14)
   tile_signal(td, wb, nbnd);
 }
 
@@ -1279,9 +1420,16 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
   const int cnt = td.count[tile];
   int w0[3];
   tile_origin<ND>(td, tile, w0);
-  for (int idx = threadIdx.x; idx < NW; idx += K5_BLK) {
+  for (int idx0 = threadIdx.x; idx0 < ((ND == 3 && NLPS_FAST_WINDOWS) ? 512 : NW); idx0 += K5_BLK) {
     bool in;
-    int node = window_node<ND>(g, w0, idx, in);
+    int node, idx;
+    if (ND == 3 && NLPS_FAST_WINDOWS) {
+      node = window_cell3(g, w0, idx0, in);
+      idx = (idx0 & 63) + PS * (idx0 >> 6);
+    } else {
+      idx = idx0;
+      node = window_node<ND>(g, w0, idx, in);
+    }
     axy[2 * idx] = in ? N.accel[(size_t)node * ND + 0] : 0.0;
     axy[2 * idx + 1] = in ? N.accel[(size_t)node * ND + 1] : 0.0;
     if (ND == 3) az[(ND == 3) ? idx : 0] = in ? N.accel[(size_t)node * ND + (2 % ND)] : 0.0;

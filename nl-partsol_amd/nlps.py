@@ -64,12 +64,13 @@ _LIB = None
 SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_gpu_synchronize",
            "nlps_gpu_download_state", "nlps_gpu_download_lists", "nlps_gpu_download_active",
            "nlps_gpu_status_flags", "nlps_gpu_initialize_lme", "nlps_gpu_local_search", "nlps_gpu_active_masks",
+           "nlps_gpu_set_node_numbering",
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
            "nlps_gpu_internal_forces", "nlps_gpu_nodal_traction_forces", "nlps_gpu_roll_state", "nlps_gpu_update_kinetics",
            "nlps_gpu_explicit_step", "nlps_gpu_num_active", "nlps_gpu_explicit_nodal", "nlps_gpu_set_halo_exchange",
            "nlps_gpu_resort", "nlps_gpu_set_resort_interval", "nlps_gpu_set_adaptive_resort", "nlps_gpu_set_law_launch_mode", "nlps_gpu_set_deterministic",
            "nlps_gpu_rccl_unique_id", "nlps_gpu_rccl_attach", "nlps_gpu_rccl_attach_comm", "nlps_gpu_rccl_detach",
-           "nlps_gpu_rccl_reduce", "nlps_gpu_rccl_selftest_exchange", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
+           "nlps_gpu_rccl_reduce", "nlps_gpu_rccl_info", "nlps_gpu_rccl_migrate", "nlps_gpu_rccl_selftest_migrate", "nlps_gpu_rccl_selftest_exchange", "nlps_gpu_touched_layers", "nlps_gpu_set_node_window", "nlps_gpu_set_ghost_bands",
            "nlps_gpu_form_initial_guess", "nlps_gpu_nodal_kinetic_increments", "nlps_gpu_nodal_inertial_forces",
            "nlps_gpu_tangent_assemble", "nlps_gpu_tangent_set_grouped", "nlps_gpu_tangent_coo",
            "nlps_gpu_sparsity_pattern",
@@ -108,8 +109,12 @@ def lib():
         L.nlps_gpu_rccl_attach_comm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int]
         L.nlps_gpu_rccl_detach.argtypes = [C.c_void_p]
         L.nlps_gpu_rccl_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.nlps_gpu_rccl_info.argtypes = [C.c_void_p, _ip, _ip, _ip]
+        L.nlps_gpu_rccl_migrate.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _ip]
+        L.nlps_gpu_rccl_selftest_migrate.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _ip]
         L.nlps_gpu_rccl_selftest_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_set_node_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.nlps_gpu_set_node_numbering.argtypes = [C.c_void_p, _ip]
         L.nlps_gpu_set_ghost_bands.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.nlps_gpu_form_initial_guess.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                                   C.POINTER(Bcc), C.c_int, C.c_int]
@@ -462,6 +467,20 @@ class Solver:
     def rccl_reduce(self, dptr, n, root=-1):
         self._chk(self.L.nlps_gpu_rccl_reduce(self.h, _vp(dptr), int(n), int(root)))
 
+    def rccl_info(self):
+        """-> (nranks, rank) as RCCL reports them, overlap mode in force (0 blocking, 1 split launches, 2 one launch per stage)"""
+        n, r, m = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.L.nlps_gpu_rccl_info(self.h, C.byref(n), C.byref(r), C.byref(m)))
+        return n.value, r.value, m.value
+
+    def rccl_migrate(self, keep_lo, keep_hi, selftest=False):
+        """Migration with the transport inside the library (ncclSend / ncclRecv): -> (sent_down, sent_up, received)"""
+        d, u, g = C.c_int(0), C.c_int(0), C.c_int(0)
+        fn = self.L.nlps_gpu_rccl_selftest_migrate if selftest else self.L.nlps_gpu_rccl_migrate
+        self._chk(fn(self.h, int(keep_lo), int(keep_hi), C.byref(d), C.byref(u), C.byref(g)))
+        self.num_particles()
+        return d.value, u.value, g.value
+
     def rccl_selftest_exchange(self, dptr, nfield, elem_bytes, kind, overlap):
         self._chk(self.L.nlps_gpu_rccl_selftest_exchange(self.h, _vp(dptr), int(nfield), int(elem_bytes), int(kind),
                                                          1 if overlap else 0))
@@ -543,6 +562,11 @@ class Solver:
     def set_ghost_bands(self, band_lo, band_hi, overlap=True):
         """overlap: False / 0 blocking exchanges, True / 1 split launches, 2 one launch per stage (library RCCL only)"""
         self._chk(self.L.nlps_gpu_set_ghost_bands(self.h, int(band_lo), int(band_hi), int(overlap)))
+
+    def set_node_numbering(self, lattice_of_file):
+        """Masked numbering in the node order of a mesh file (None = lattice order): include/nlps_gpu.h"""
+        a = None if lattice_of_file is None else np.ascontiguousarray(lattice_of_file, dtype=np.int32)
+        self._chk(self.L.nlps_gpu_set_node_numbering(self.h, _i(a)))
 
     def set_node_window(self, layer_lo, layer_hi):
         self._chk(self.L.nlps_gpu_set_node_window(self.h, int(layer_lo), int(layer_hi)))

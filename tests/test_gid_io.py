@@ -413,6 +413,7 @@ def test_command_file_subset(tmp_path):
                      (DECK.replace("NLPS-Solver (Type=NPC-FS) {", "NLPS-Solver (Kind=NPC-FS) {"), "Type=string"),
                      (DECK + "NLPS-Solver (Type=NPC-FS) {\n CFL=1\n Cel=1\n N=1\n}\n", "more than one solver"),
                      (DECK.replace("Type=GID", "Type=GMSH"), "Unrecognised kind of mesh"),
+                     (DECK.replace("\tMaxIter=20\n", "\tMaxIter=20\n\twrapper=Nelder-Mead\n"), "only LME wrapper of the GPU path"),
                      (DECK.replace("GPxElement=4", "Particles=4"), "GPxElement=int"),
                      (DECK.replace("Type=NPC-FS", "Type=Newmark-beta-Finite-Strains"), "needs Beta-Newmark-beta"),
                      (DECK.replace("gamma=2.3", "gamma=0"), "gamma parameter required")):

@@ -78,3 +78,37 @@ def test_deterministic_mixed_laws_and_oracle_order():
     ulp = np.abs(m_g - m_o) / np.maximum(np.spacing(np.abs(m_o)), 1e-300)
     assert ulp.max() <= 64, f"lumped mass: {ulp.max():.0f} ulp from the oracle's summation order"
     assert_close(na["force"], stepper.nodal("force"), 1e-9, "nodal force")
+
+
+def dense_case(copies):
+    """`copies` jittered clouds over the same cells: 8 x copies particles per cell, i.e. as many per closest node."""
+    case = make_case(3, [10, 10, 9], [3, 3, 2], [4, 4, 4], material=NH, velocity=[0.0, 0.0, -10.0])
+    parts = [make_case(3, [10, 10, 9], [3, 3, 2], [4, 4, 4], material=NH, velocity=[0.0, 0.0, -10.0],
+                       seed=100 + q, jitter=0.2)["cloud"] for q in range(copies)]
+    cloud = {}
+    for k, v in parts[0].items():
+        if isinstance(v, np.ndarray):
+            cloud[k] = np.ascontiguousarray(np.concatenate([c[k] for c in parts], axis=0))
+        else:
+            cloud[k] = v
+    for k in ("mass", "vol0"):
+        cloud[k] = cloud[k] / copies
+    case["cloud"] = cloud
+    return case
+
+
+def test_deterministic_mode_with_more_particles_per_node_than_the_layer_table():
+    """Clouds beyond the caps of the per-tile ordering (more than 32 particles on one closest node, more than 4096 in
+    one tile) used to keep the arrival order of the binning atomics: deterministic mode now orders such tiles by slot
+    index, so two runs still agree bit for bit."""
+    for copies in (5, 10):  # 40 per node (layer table overflows); 80 per node and > 4096 in the full tiles
+        case = dense_case(copies)
+        a, na = run(case, 3, True, resort=2)
+        b, nb = run(case, 3, True, resort=2)
+        for k in KEYS:
+            assert np.array_equal(a[k], b[k]), f"{k}: two deterministic runs differ ({copies} copies)"
+        for k in ("mass", "dU", "force", "accel"):
+            assert np.array_equal(na[k], nb[k]), f"nodal {k}: two deterministic runs differ ({copies} copies)"
+        c, nc = run(case, 3, False, resort=2)
+        for k in ("x", "vel", "F_n"):
+            assert_close(c[k], a[k], 1e-11, f"{k}: atomic vs deterministic accumulation, dense cloud")

@@ -169,6 +169,61 @@ def test_stage_functions(ndim, material):
 
 
 @pytest.mark.parametrize("ndim", [2, 3])
+def test_masked_numbering_follows_the_mesh_file_order(ndim):
+    """get_active_nodes__MeshTools__ hands out the masked index in the order of the mesh FILE's nodes (Nodes-Tools.c:46-66).
+    With a file that is not numbered x-fastest (nlps_gpu_set_node_numbering: lattice node of every file node) Nodes2Mask
+    comes back indexed by file node with the running index in file order, the dof mask follows the masked node, and every
+    masked vector of the stage functions is the oracle's vector for that numbering."""
+    o = orc()
+    n = nlps()
+    case = small_case(ndim, velocity=[1.0, -2.0] if ndim == 2 else [1.0, -2.0, 0.5])
+    nsteps = 2
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+    nn = S.nnodes
+    rng = np.random.default_rng(5)
+    lattice_of_file = rng.permutation(nn).astype(np.int32)
+    with pytest.raises(n.NlpsError):
+        S.set_node_numbering(np.zeros(nn, dtype=np.int32))  # not a permutation
+    S.set_node_numbering(lattice_of_file)
+    # the reference's loop, over the file's nodes
+    act = S.download_active()
+    n2m_file = np.full(nn, -1, dtype=np.int32)
+    run = 0
+    for A in range(nn):
+        if act[lattice_of_file[A]]:
+            n2m_file[A] = run
+            run += 1
+    n2m_lat = np.empty(nn, dtype=np.int32)
+    n2m_lat[lattice_of_file] = n2m_file  # the same map, indexed by lattice node: what the oracle's stages take
+    d2m_o, nfree = o.active_dofs(n2m_lat, run, ndim, o.BccSet(bcs_list), 1, nsteps)
+    n2m_g, d2m_g = S.active_masks(n.BccSet(bcs_list), 1)
+    assert S.nactive == run and S.nfree == nfree
+    assert np.array_equal(n2m_g, n2m_file), "Nodes2Mask is not the file-order numbering"
+    assert np.array_equal(d2m_g, d2m_o), "dof mask differs"
+    Mv_o = o.lumped_mass(P, M, n2m_lat, run)
+    Mv_g = S.compute_nodal_lumped_mass()
+    assert_close(Mv_g, Mv_o, TOL, "lumped mass in file-order numbering")
+    V_o, A_o = o.nodal_field_n(Mv_o, P, M, n2m_lat, d2m_o, run)
+    V_g, A_g = S.get_nodal_field_n(Mv_g)
+    assert_close(V_g, V_o, TOL, "nodal velocity in file-order numbering")
+    dU = 1e-3 * rng.normal(size=run * ndim)
+    assert o.compatibility(dU, None, P, M, n2m_lat) == 0
+    S.local_compatibility_conditions(dU)
+    assert o.constitutive(P, mats, prm) == 0
+    S.constitutive_update()
+    R_o, st = o.internal_forces(P, M, n2m_lat, d2m_o, run)
+    assert st == 0
+    R_g = S.nodal_internal_forces(np.zeros(run * ndim))
+    assert_close(R_g, R_o, TOL, "internal forces in file-order numbering")
+    # back to lattice order
+    S.set_node_numbering(None)
+    masks(S, M, bcs_list, 1, nsteps)
+    S.close()
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
 @pytest.mark.parametrize("stretch", [0.05, 0.01, -0.02])
 def test_drucker_prager_return_branches(ndim, stretch):
     """Uniform volumetric stretch fields (LME reproduces them exactly) drive every particle down one branch of
@@ -923,7 +978,7 @@ def test_bench_multi_rank_path_rehearsal(scaling):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = free_port()
-    extra = ["--cells", "16"] if scaling == "weak" else ["--scaling", "strong", "--particles-total", str(8 * 17 ** 3)]
+    extra = ["--cells", "16", "--particles-total", str(8 * 17 ** 3)] + ([] if scaling == "weak" else ["--scaling", "strong"])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "2", "--no-cpu-baseline"] + extra
@@ -934,6 +989,19 @@ def test_bench_multi_rank_path_rehearsal(scaling):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0
     assert out["config"]["particles_total"] == (2 * 16 ** 3 * 8 if scaling == "weak" else 8 * 17 ** 3)
+    # (a) the partitioned-vs-whole check ran over the communicator of the run, before anything was timed
+    chk = out["partition_check"]
+    assert chk["index_maps_equal"] and chk["max_rel_err"] < 1e-10 and chk["status_flags"] == 0 and chk["particles"] == 2 * 8 ** 3 * 8
+    # (b) the overlap form that survived the warm-up is recorded (the gloo stand-in has no single-launch form: 1)
+    assert out["config"]["halo_overlap_mode"] == 1 and out["config"]["overlap_forms_tried"][-1]["ok"]
+    assert out["config"]["halo_impl"] == "torch" and out["config"]["rccl_nranks"] is None
+    # (c) per-rank kernel times and the time the step waited for its exchanges
+    rows = out[scaling]["per_rank_kernel_ms"]
+    assert len(rows) == 2 and all(r["lists+newton+p2g_mass_mom"] > 0 and r["exchange_wait"] >= 0 for r in rows)
+    # (d) the weak AND the strong record in the one line (north_star: strong scaling at 8 M, here --particles-total)
+    assert out["weak"]["scaling"] == "weak" and out["strong"]["scaling"] == "strong"
+    assert out["weak"]["value"] > 0 and out["strong"]["value"] > 0
+    assert out[scaling]["value"] == out["value"] and out[scaling]["ms_per_step"] == out["ms_per_step"]
 
 
 @pytest.mark.parametrize("ndim", [2, 3])
@@ -1060,6 +1128,35 @@ def test_shuffled_upload_and_periodic_resort(ndim):
     assert np.array_equal(st["I0"], P["I0"]) and np.array_equal(nn, P["nn"]) and lists_equal(nn, lst, P["list"])
     for k, ok in (("x", "x"), ("vel", "vel"), ("Stress", "stress"), ("F_n", "F_n"), ("lambda", "lambda")):
         assert_close(st[k], P[ok], 1e-9, f"{k} after resorted steps")
+
+
+def test_periodic_resort_keeps_particles_the_search_could_not_bin():
+    """A particle the search flags instead of binning (here: closest node outside the rank's node window, status 16) is
+    in no tile list; the periodic re-sort takes the lists as its permutation and must still move the WHOLE cloud: every
+    particle comes back once, in the caller's order (the tail of the permutation used to be stale)."""
+    n = nlps()
+    case = small_case(3, velocity=[0.0, 0.0, -10.0])
+    npart = case["cloud"]["x"].shape[0]
+    case["cloud"]["mass"] = case["cloud"]["mass"] * (1.0 + 1e-3 * np.arange(npart))  # a tag that survives the steps
+    nsteps = 6
+    S = gpu_setup(case, nsteps=nsteps)
+    st0 = S.download_state(fields=["x_GC", "mass"])
+    z = st0["x_GC"][:, 2]
+    layer_hi = int(np.floor(0.5 * (z.min() + z.max()) / case["h"]))
+    S.set_node_window(0, layer_hi)  # the upper half of the cloud is outside from now on
+    S.set_resort_interval(2)
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, nsteps)])
+    for t in range(nsteps):
+        S.explicit_step(gb, t, 1e-4)
+    assert S.status_flags() & 16
+    st = S.download_state(fields=["x_GC", "mass", "Vol_0"])
+    assert np.array_equal(st["mass"], case["cloud"]["mass"]), "particles duplicated / dropped by the re-sort"
+    assert np.array_equal(st["Vol_0"], case["cloud"]["vol0"])
+    outside = z > (layer_hi - 1.0) * case["h"]  # closest node >= layer_hi - 1: the stencil reaches past the window
+    assert outside.any() and not outside.all()
+    assert np.array_equal(st["x_GC"][outside], st0["x_GC"][outside]), "a flagged particle is left out of the step"
+    assert not np.array_equal(st["x_GC"][~outside], st0["x_GC"][~outside])
+    S.close()
 
 
 def test_config1_2d_10k_parity():

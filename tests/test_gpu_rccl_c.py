@@ -128,3 +128,46 @@ def test_overlap_choreographies_world_1(mode):
     na, nb = S.explicit_nodal(), P.explicit_nodal()
     for k in ("mass", "force", "accel"):
         assert_close(na[k], nb[k], 1e-11, f"nodal {k}: overlap mode {mode} vs plain")
+
+
+def test_rccl_migrate_world_1_self_loop():
+    """nlps_gpu_rccl_migrate = select -> counts and rows over ncclSend / ncclRecv on the library's communicator ->
+    commit, with no Python in between.  One-GPU box: the rank is its own two neighbours (nlps_gpu_rccl_selftest_migrate),
+    so the particles that leave the keep range below AND above come straight back over the wire; stepping on must match a
+    solver that never migrated, particle by particle (matched by global id).  The plain entry on world 1 has no neighbour
+    and moves nothing."""
+    n = nlps()
+    case = make_case(3, [11, 10, 22], [3, 3, 3], [5, 4, 16], velocity=[1.0, 0.5, -10.0])
+    nsteps = 6
+    nl = case["grid_n"][2]
+    A = gpu_setup(case, init=False, nsteps=nsteps)
+    A.rccl_attach(n.Solver.rccl_unique_id(), 0, 1, [0], [nl - 1], mode=0)
+    assert A.rccl_info() == (1, 0, 0)  # ncclCommCount, ncclCommUserRank, overlap mode of a world without neighbours
+    A.initialise_shapefun()
+    B = gpu_setup(case, nsteps=nsteps)
+    npart = case["cloud"]["x"].shape[0]
+    ids = (np.arange(npart) * 3 + 1).astype(np.int32)
+    A.set_particle_ids(ids)
+    B.set_particle_ids(ids)
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, nsteps)])
+    z = case["cloud"]["x"][:, 2]
+    keep_lo, keep_hi = int(z.min()) + 2, int(z.max()) - 2  # (the immigrants must fit the capacity reserved at create)
+    moved = 0
+    for t in range(nsteps):
+        if t in (2, 4):
+            d, u, g = A.rccl_migrate(keep_lo, keep_hi, selftest=True)
+            assert d > 0 and u > 0 and g == d + u and A.num_particles() == npart
+            moved += g
+            assert A.rccl_migrate(keep_lo, keep_hi) == (0, 0, 0)  # world 1, no self-loop: the range is clamped, nobody leaves
+        A.explicit_step(gb, t, 2e-3)
+        B.explicit_step(gb, t, 2e-3)
+    assert moved > 0 and A.status_flags() == 0
+    a, b = A.download_state(), B.download_state()
+    ia, ib = A.download_ids(), B.download_ids()
+    assert np.array_equal(ia, np.sort(ids))
+    order_b = np.argsort(ib)
+    assert np.array_equal(a["I0"], b["I0"][order_b])
+    for k in ("x", "vel", "Stress", "F_n", "lambda"):
+        assert_close(a[k], b[k][order_b], 1e-12 if k != "lambda" else 1e-9, f"{k} after migration over the wire")
+    A.close()
+    B.close()

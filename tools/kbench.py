@@ -104,9 +104,9 @@ if a.phases:
     S.L.nlps_gpu_debug_phases(S.h, out.ctypes.data, 1)
     o = out.astype(np.float64) / a.steps
     nw = case["cloud"]["x"].shape[0] / 64
-    names = {0: "K2 prologue", 1: "K2 loads+mask", 2: "K2 newton", 3: "K2 predictor+scatter", 4: "K2 tail barrier+flush",
-              8: "K3 prologue", 9: "K3 loads+factors", 10: "K3 moments+gather",
-             11: "K3 F+stress+B", 12: "K3 scatter", 13: "K3 tail barrier+flush"}
+    names = {0: "K2 prologue", 1: "K2 loads+mask", 2: "K2 newton", 3: "K2 predictor+scatter", 4: "K2 end barrier", 5: "K2 flush",
+             8: "K3 prologue", 9: "K3 loads+factors", 10: "K3 moments+gather",
+             11: "K3 F+stress+B", 12: "K3 scatter", 13: "K3 end barrier", 14: "K3 flush"}
     print("  K2 Newton evaluations per particle %.3f" % (o[7] / case["cloud"]["x"].shape[0]))
     for kk, nm in names.items():
         print("  %-30s %10.0f cycles/wave" % (nm, o[kk] / nw))
