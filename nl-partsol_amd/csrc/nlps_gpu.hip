@@ -65,6 +65,8 @@ struct PView {
   size_t npad;
   double* d;  // [NFD][npad]
   int* I0;
+  int* I0n;  // closest node for the position the last explicit step wrote (k5_tile's search ahead); = I0 otherwise.  I0
+             // itself stays the node of the last search until the next one adopts I0n (downloads, migration see I0)
   int* mat;
   int* nn;
   int* status;
@@ -208,13 +210,15 @@ __device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
 // search seeds and tile counters and, for the fused explicit step, the nodal accumulators of the node window.
 template <int ND>
 __global__ void k_step_clear(int n0, int nnodes, NView N, int* __restrict__ tile_count, int ntiles, int nodal,
-                             int* __restrict__ node_cnt) {
+                             int* __restrict__ node_cnt, int bins) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < ntiles) tile_count[t] = 0;
+  if (bins && t < ntiles) tile_count[t] = 0;
   if (t >= nnodes) return;
   const size_t A = (size_t)n0 + t;
-  N.seed[A] = 0;  // Shape-Functions.c:38-46
-  if (node_cnt) node_cnt[A] = 0;
+  if (bins) {  // (not when the last step's k5_tile has done this step's search: its seeds and counters are the input)
+    N.seed[A] = 0;  // Shape-Functions.c:38-46
+    if (node_cnt) node_cnt[A] = 0;
+  }
   if (nodal) {
 #pragma unroll
     for (int a = 0; a < 1 + ND; a++) N.nm[A * (1 + ND) + a] = 0.0;
@@ -245,71 +249,97 @@ __device__ __forceinline__ void dilate_node(int A, const GridD& g, const NView& 
   N.active[A] = any ? 1 : 0;
 }
 
+// The closest-node update of local_search__LME__ (LME.c:924-930): argmin of the distance over the 1-ring of the
+// PREVIOUS closest node, ties by chain position (get_closest_node__MeshTools__, Nodes-Tools.c:476-538).
 template <int ND>
-__global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const uint8_t* __restrict__ rank1, TileCnt tc) {
+__device__ __forceinline__ int closest_node_update(const GridD& g, const uint8_t* __restrict__ rank1, const double* x, int I0) {
+  int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+  const uint8_t* rk = rank1 + 27 * class3_of<ND>(g, ijk);
+  // Of the 3^d candidates only those that can be the minimum are evaluated.  Along an axis where the particle is
+  // clearly closer to the old node's plane than to either neighbouring plane (|d| <= 0.49 h) a step to a neighbouring
+  // plane adds at least 0.02 h^2 to the squared distance -- orders of magnitude beyond rounding -- and along any axis
+  // the step AWAY from the particle adds more than h^2: such candidates lose in the reference's loop as well.  What is
+  // left is the old node and, per axis with |d| > 0.49 h, its neighbour on the particle's side: at most 2^d nodes,
+  // usually one.  Their squared distances are summed like point_distance__MeshTools__ (Nodes-Tools.c:397-420:
+  // DIST += pow(d,2) in axis order), the winner is the reference's: lexicographic minimum of (sqrt(D), chain position)
+  // = first strict minimum of the chain walk (Nodes-Tools.c:476-538).
+  int sgn[3] = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    const double d = x[a] - (g.o[a] + g.h * (double)ijk[a]);
+    if (fabs(d) > 0.49 * g.h) sgn[a] = d > 0.0 ? 1 : -1;
+  }
+  double best = 0.0;
+  int bestrank = 256, bi = ijk[0], bj = ijk[1], bk = ijk[2];
+#pragma unroll
+  for (int q = 0; q < (1 << ND); q++) {
+    const int di = (q & 1) ? sgn[0] : 0, dj = (q & 2) ? sgn[1] : 0, dk = (ND == 3 && (q & 4)) ? sgn[2] : 0;
+    // a combination that asks for a step along an axis that has none repeats another one
+    const bool dup = ((q & 1) && sgn[0] == 0) || ((q & 2) && sgn[1] == 0) || (ND == 3 && (q & 4) && sgn[2] == 0);
+    const int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
+    const bool ok = !dup && i >= 0 && i < g.n[0] && j >= 0 && j < g.n[1] && (ND == 2 || (k >= 0 && k < g.n[2]));
+    if (ok) {
+      double Dc = 0.0, t;
+      t = x[0] - (g.o[0] + g.h * (double)i);
+      Dc += t * t;
+      t = x[1] - (g.o[1] + g.h * (double)j);
+      Dc += t * t;
+      if (ND == 3) {
+        t = x[ND - 1] - (g.o[2] + g.h * (double)k);
+        Dc += t * t;
+      }
+      const double d = sqrt(Dc);
+      const int rank = rk[(di + 1) + 3 * (dj + 1) + 9 * (dk + 1)];
+      if (bestrank == 256 || d < best || (d == best && rank < bestrank)) {
+        best = d;
+        bestrank = rank;
+        bi = i;
+        bj = j;
+        bk = k;
+      }
+    }
+  }
+  return bi + g.n[0] * (bj + g.n[1] * bk);
+}
+
+// update != 0: the search proper.  update == 0: seeds and bins only, with the closest nodes as they are -- the last
+// kernel of the fused explicit step (k5_tile) has already updated them for the positions it wrote, and a second update
+// would start from the new node's 1-ring instead of the old one's (LME.c:927-929).
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_search(PView P, GridD g, NView N, const uint8_t* __restrict__ rank1, TileCnt tc,
+                                                int update) {
   const int p = blockIdx.x * BLK + threadIdx.x;
   const bool valid = p < P.np;
   int I0 = 0;
   if (valid) {
-    double x[ND], aux = 0.0;
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      x[a] = PF(P, F_X + a, p);
-      aux += dsqr(PF(P, F_DIS + a, p));
-    }
     I0 = P.I0[p];
-    if (sqrt(aux) > 0.0) {  // norm__MatrixLib__(dis_p,2) > 0, LME.c:924
-      int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
-      const uint8_t* rk = rank1 + 27 * class3_of<ND>(g, ijk);
-      // squared distances of the 3^d candidates, summed like point_distance__MeshTools__
-      // (Nodes-Tools.c:397-420: DIST += pow(d,2) in axis order)
-      double D[27];
-      double Dmin = 1.0e300;
+    if (update) {
+      double x[ND], aux = 0.0;
 #pragma unroll
-      for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
-#pragma unroll
-        for (int dj = -1; dj <= 1; dj++)
-#pragma unroll
-          for (int di = -1; di <= 1; di++) {
-            const int c = (di + 1) + 3 * (dj + 1) + 9 * (dk + 1);
-            const int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
-            const bool ok = i >= 0 && i < g.n[0] && j >= 0 && j < g.n[1] && (ND == 2 || (k >= 0 && k < g.n[2]));
-            double Dc = 0.0, t;
-            t = x[0] - (g.o[0] + g.h * (double)i);
-            Dc += t * t;
-            t = x[1] - (g.o[1] + g.h * (double)j);
-            Dc += t * t;
-            if (ND == 3) {
-              t = x[ND - 1] - (g.o[2] + g.h * (double)k);
-              Dc += t * t;
-            }
-            D[c] = ok ? Dc : 1.0e300;
-            Dmin = (ok && Dc < Dmin) ? Dc : Dmin;
-          }
-      // the reference compares sqrt(D) with strict '<' walking the chain (Nodes-Tools.c:476-538) ==
-      // lexicographic minimum of (sqrt(D), chain position).  sqrt is monotone, so only candidates within
-      // rounding reach of the minimum can tie after the square root: resolve just those exactly.
-      const double thr = Dmin * (1.0 + 1.0e-14);
-      double best = 0.0;
-      int bestrank = 256, bestc = 13;
-#pragma unroll
-      for (int c = (ND == 3 ? 0 : 9); c < (ND == 3 ? 27 : 18); c++) {
-        if (D[c] <= thr) {
-          const double d = sqrt(D[c]);
-          const int rank = rk[c];
-          if (bestrank == 256 || d < best || (d == best && rank < bestrank)) {
-            best = d;
-            bestrank = rank;
-            bestc = c;
-          }
-        }
+      for (int a = 0; a < ND; a++) {
+        x[a] = PF(P, F_X + a, p);
+        aux += dsqr(PF(P, F_DIS + a, p));
       }
-      I0 = (ijk[0] + bestc % 3 - 1) + g.n[0] * ((ijk[1] + (bestc / 3) % 3 - 1) + g.n[1] * (ijk[2] + bestc / 9 - 1));
-      P.I0[p] = I0;
+      if (sqrt(aux) > 0.0) {  // norm__MatrixLib__(dis_p,2) > 0, LME.c:924
+        I0 = closest_node_update<ND>(g, rank1, x, I0);
+        P.I0[p] = I0;
+      }
+      P.I0n[p] = I0;
+    } else {  // adopt the update the last explicit step made for the position it wrote
+      const int In = P.I0n[p];
+      if (In != I0) P.I0[p] = In;
+      I0 = In;
     }
-    N.seed[I0] = 1;
   }
   bin_particle<ND>(P, g, tc, p, I0, valid);
+  // (only a particle that is in a tile list activates nodes: one left out -- outside the node window -- takes no part)
+  if (valid && (!tc.count || P.tile[p] >= 0)) N.seed[I0] = 1;
+}
+
+// the closest nodes k5_tile found ahead become THE closest nodes (paths whose list kernels do not do it on their way)
+__global__ void k_commit_I0(int np, const int* __restrict__ I0n, int* __restrict__ I0) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < np) I0[p] = I0n[p];
 }
 
 // initialize__LME__ first loop (LME.c:63-115): element search + closest element node
@@ -367,6 +397,7 @@ __global__ __launch_bounds__(BLK) void k_init_I0(PView P, GridD g, NView N, Tile
           }
         }
       P.I0[p] = bestnode;
+      P.I0n[p] = bestnode;
       N.seed[bestnode] = 1;
     }
   }
@@ -732,11 +763,20 @@ __global__ void k_bc(const int* __restrict__ nodes, int n, int dim, int dirbits,
     }
 }
 
+// clr_* (search fused into k5_tile): this kernel runs in front of it and resets what that search accumulates into -- the
+// seeds and per-node counters of the nodes it visits, and (first launch of the stage only) the tile counters
 template <int ND>
-__global__ void k_nodal_accel(int n0, int nnodes, int n0b, int nnodesb, NView N, double g0, double g1, double g2) {  // U-Verlet.c:947-957
+__global__ void k_nodal_accel(int n0, int nnodes, int n0b, int nnodesb, NView N, double g0, double g1, double g2,
+                              int clr_seed, int* __restrict__ clr_node_cnt, int* __restrict__ clr_tile_count, int ntiles) {  // U-Verlet.c:947-957
   int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (clr_tile_count)
+    for (int t = A; t < ntiles; t += gridDim.x * blockDim.x) clr_tile_count[t] = 0;
   if (A >= nnodes + nnodesb) return;
   A = A < nnodes ? n0 + A : n0b + (A - nnodes);
+  if (clr_seed) {
+    N.seed[A] = 0;
+    if (clr_node_cnt) clr_node_cnt[A] = 0;
+  }
   double M = N.nm[(size_t)A * (1 + ND)];
   bool act = N.active[A] && M != 0.0;  // massless active node: see k_nodal_dU
   double gv[3] = {g0, g1, g2};
@@ -941,13 +981,18 @@ __global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD 
 // runs of memory-consecutive particles), order2 = canonical (TileTab).
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_fill_orders(int np, const int* __restrict__ tile, const int* __restrict__ rank,
-                                                     const int* __restrict__ nrank, const int* __restrict__ I0a,
+                                                     const int* __restrict__ nrank, int* __restrict__ I0a,
+                                                     const int* __restrict__ I0n,
                                                      const int* __restrict__ start, GridD g, TileTab tab,
                                                      int* __restrict__ order, int* __restrict__ order2) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np) return;
   const int t = tile[p];
   if (t < 0) return;
+  if (I0n) {  // the search was done ahead by k5_tile: its closest node becomes THE closest node (a particle that is in
+    const int In = I0n[p];  // no list was not visited: its I0n equals I0)
+    if (In != I0a[p]) I0a[p] = In;
+  }
   constexpr int TB = TileCfg<ND>::TB;
   const int s0 = start[t], pos = s0 + rank[p];
   order[pos] = p;
@@ -1048,6 +1093,7 @@ __global__ void k_mig_unpack(PView P, int first, int n, const double* __restrict
   for (int f = 0; f < NFD; f++) PF(P, mig_field(P, f), p) = row[f];
   const long long* w = reinterpret_cast<const long long*>(row + NFD);
   P.I0[p] = (int)w[0];
+  P.I0n[p] = (int)w[0];
   P.mat[p] = (int)w[1];
   P.nn[p] = (int)w[2];
   P.status[p] = (int)w[3];
@@ -1157,6 +1203,12 @@ struct nlps_gpu {
   int nactive, nfree;
   bool masks_valid;
   bool binned;  // order[] / tile tables describe the current I0s
+  // The last kernel of the fused explicit step (k5_tile<., ., true>) does the search of the NEXT step for the particles
+  // it moves.  searched: the closest nodes already belong to the current positions (a search that follows must not
+  // update them a second time, LME.c:927-929); ahead: seeds, tile counters, per-particle tile / rank and per-node
+  // counters of that search are in place, the next explicit step starts at the activation kernel.
+  bool searched = false, ahead = false;
+  int fuse_search = 1;  // developer switch NLPS_FUSE_SEARCH
   // migration
   int* gid_d = nullptr;               // global particle id (default: the caller's index)
   unsigned char* leaving_d = nullptr;  // 0 stay, 1 leaves downwards, 2 upwards (between select and commit)
@@ -1192,6 +1244,7 @@ struct nlps_gpu {
   // per-step tile binning
   int nt[3], ntiles;
   int* tile_count_d;
+  int* tile_count2_d = nullptr;  // the counters the search ahead (k5_tile) fills while tile_count_d still sizes the lists in use
   int* tile_start_d;
   int2 *work1_d = nullptr, *work2_d = nullptr;  // compacted (tile, part) work lists, see TileD
   int resort_from_lists = 1;     // developer switch NLPS_RESORT_FROM_LISTS (resort)
@@ -1432,6 +1485,7 @@ extern "C" int nlps_gpu_set_node_window(nlps_gpu* h, int layer_lo, int layer_hi)
   HIPCHK(hipMemsetAsync(h->tile_count_d, 0, ((size_t)h->ntiles + 1) * sizeof(int), h->stream));
   h->masks_valid = false;
   h->binned = false;
+  h->ahead = false;
   return 0;
 }
 
@@ -1564,6 +1618,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->P.erosion = prm->driver_eigenerosion != 0;
   if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
   if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
+  if (const char* e = getenv("NLPS_FUSE_SEARCH")) h->fuse_search = atoi(e);
 
   h->tab = nlps_host::build_tables(g.nd);
   HIPCHK(hipMalloc((void**)&h->rank1_d, 27 * 27));
@@ -1689,6 +1744,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   HIPCHK(hipMalloc((void**)&h->P.d, (size_t)NFD * h->P.npad * sizeof(double)));
   HIPCHK(hipMemset(h->P.d, 0, (size_t)NFD * h->P.npad * sizeof(double)));
   if (dev_alloc(h, &h->P.I0, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->P.I0n, h->P.npad)) return 1;
   if (dev_alloc(h, &h->P.mat, h->P.npad)) return 1;
   if (dev_alloc(h, &h->P.nn, h->P.npad)) return 1;
   if (dev_alloc(h, &h->P.status, h->P.npad)) return 1;
@@ -1698,6 +1754,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->P.rank, h->P.npad)) return 1;
   if (dev_alloc(h, &h->order_d, h->P.npad)) return 1;
   if (dev_alloc(h, &h->tile_count_d, (size_t)h->ntiles + 1)) return 1;
+  if (dev_alloc(h, &h->tile_count2_d, (size_t)h->ntiles + 1)) return 1;
   if (dev_alloc(h, &h->tile_start_d, (size_t)h->ntiles + 1)) return 1;
   if (dev_alloc(h, &h->work1_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
@@ -1762,6 +1819,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     if (host->I0) {
       for (int s = 0; s < np; s++) it[s] = host->I0[h->perm[s]];
       HIPCHK(hipMemcpy(h->P.I0, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(h->P.I0n, it.data(), h->P.npad * sizeof(int), hipMemcpyHostToDevice));
     }
   }
   // re-sort buffers
@@ -1845,7 +1903,7 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
                        h->Pd_alt, (const double*)h->P.d, idx, np, npad, nf);
   }
   std::swap(h->P.d, h->Pd_alt);
-  int* iarr[] = {h->P.I0, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
+  int* iarr[] = {h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
   for (int* a : iarr) {
     hipLaunchKernelGGL(k_gather<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (int*)h->gather_tmp, a, idx, np);
     hipLaunchKernelGGL(k_copy<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, a, (const int*)h->gather_tmp, np);
@@ -1858,6 +1916,7 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
   HIPCHK(hipGetLastError());
   h->perm_dirty = true;
   h->binned = false;
+  h->ahead = false;  // (the per-particle tile / rank of a search done ahead belong to the old slots)
   h->steps_since_sort = 0;
   h->rehome = true;  // the slots have new owners: the next search records their tiles
   h->debt = 0.0;
@@ -1970,6 +2029,7 @@ extern "C" int nlps_gpu_migration_commit(nlps_gpu* h, const void* rows_a, int n_
     first += cnt[k];
   }
   h->P.np = np + n_in;
+  h->searched = false;  // the immigrants' closest nodes are those of their last search: everyone searches again
   if (resort(h, h->leaving_d)) return 1;  // emigrants sort to the end ...
   h->P.np = np + n_in - n_out;           // ... and fall off
   h->migrated = true;
@@ -1982,6 +2042,7 @@ extern "C" int nlps_gpu_migration_commit(nlps_gpu* h, const void* rows_a, int n_
 extern "C" int nlps_gpu_resort(nlps_gpu* h) { return resort(h); }
 extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_set_tile_ordering(nlps_gpu* h, int on) {
   h->tile_ordering = on;  // developer switch (tools/kbench.py --no-order)
+  h->ahead = false;
   return 0;
 }
 extern "C" int nlps_gpu_set_law_launch_mode(nlps_gpu* h, int mode) {
@@ -1998,6 +2059,7 @@ extern "C" int nlps_gpu_set_law_launch_mode(nlps_gpu* h, int mode) {
 }
 extern "C" int nlps_gpu_set_deterministic(nlps_gpu* h, int on) {
   h->deterministic = on != 0;
+  h->ahead = false;
   h->rehome = true;
   h->debt = 0.0;
   return 0;
@@ -2014,6 +2076,7 @@ extern "C" int nlps_gpu_set_adaptive_resort(nlps_gpu* h, double budget, int min_
   }
   h->adaptive_resort = budget;
   h->adaptive_min_steps = min_steps;
+  h->ahead = false;
   h->rehome = true;
   h->debt = 0.0;
   return 0;
@@ -2029,10 +2092,10 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   if (!h) return 0;
   (void)nlps_gpu_rccl_detach(h);
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
+  void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2806,11 +2869,18 @@ static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm
 // flags runs behind the tiles that do not touch a ghost band.
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, int overlap = 0) {
   int np = h->P.np;
+  // ahead: the search of this step was done by the last kernel of the previous one (k5_tile<., ., true>); only the
+  // nodal accumulators are reset here
+  const bool ahead = h->ahead && !init;
+  if (ahead) std::swap(h->tile_count_d, h->tile_count2_d);  // the counters that search filled size the lists from here on
   LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
-            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0, node_lists(h) ? h->node_cnt_d : nullptr);
-  TileCnt tc = tile_cnt(h, true);
-  if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
-  else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc);
+            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0, node_lists(h) ? h->node_cnt_d : nullptr, ahead ? 0 : 1);
+  if (!ahead) {
+    TileCnt tc = tile_cnt(h, true);
+    if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
+    else LAUNCH_ND((k_search<2>), (k_search<3>), nblk(np), h->P, h->g, h->N, h->rank1_d, tc, h->searched ? 0 : 1);
+  }
+  h->searched = h->ahead = false;  // consumed
   {
     const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
     TileScanArgs ts{h->tile_count_d + h->tile0, h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB,
@@ -2837,9 +2907,11 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
     tab.node_cnt = h->node_cnt_d;
     tab.mask = h->tabm_d;
     tab.base = h->tabo_d;
-    if (h->nd == 2) hipLaunchKernelGGL(k_fill_orders<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
-    else hipLaunchKernelGGL(k_fill_orders<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
+    const int* adopt = ahead ? h->P.I0n : nullptr;
+    if (h->nd == 2) hipLaunchKernelGGL(k_fill_orders<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, adopt, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
+    else hipLaunchKernelGGL(k_fill_orders<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, adopt, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
   } else {
+    if (ahead) hipLaunchKernelGGL(k_commit_I0, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, (const int*)h->P.I0n, h->P.I0);
     hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
                        h->order_d);
     if (h->deterministic) {
@@ -3225,6 +3297,7 @@ extern "C" int nlps_gpu_roll_state(nlps_gpu* h) {
 extern "C" int nlps_gpu_update_kinetics(nlps_gpu* h, double alpha_blend, const double* dU, const double* Un_dt,
                                         const double* dU_dt, const double* dU_dt2) {
   if (need_masks(h, "nlps_gpu_update_kinetics")) return 1;
+  h->searched = h->ahead = false;  // the particles move: the next search is a search
   int ND = h->nd;
   size_t st = (size_t)h->g.nnodes * ND;
   // Un_dt = dU_dt = dU_dt2 = NULL: the quasi-static driver's __update_Particles (U-Static.c:1380-1470) moves the
@@ -3268,6 +3341,12 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   if (nbcc > 0 && check_step(h, step, "nlps_gpu_explicit_step")) return 1;
   if (ensure_bcs(h, bcc, nbcc)) return 1;
+  if (!h->Pd_alt && h->resort_every > 0 && h->P.np > 0) {
+    // the twin block of the periodic re-sort, at the first step of the fused scheme rather than inside the first
+    // re-sort: a hipMalloc of this size (1.3 GB per million particles) takes milliseconds, the re-sort itself 0.3
+    HIPCHK(hipMalloc((void**)&h->Pd_alt, (size_t)NFD * h->P.npad * sizeof(double)));
+    HIPCHK(hipMemsetAsync(h->Pd_alt, 0, (size_t)NFD * h->P.npad * sizeof(double), h->stream));
+  }
   if (!h->rolled && h->P.np > 0) {  // entering the fused scheme: rho J of every particle (see F_RHOJ)
     hipLaunchKernelGGL(k_init_rhoj, dim3(nblk(h->P.np)), dim3(BLK), 0, h->stream, h->P);
     HIPCHK(hipGetLastError());
@@ -3352,11 +3431,18 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
                            bcc[i].dim, bits, v[0], v[1], v[2], h->N, r0, r1, inside);
     }
   };
+  // the search of the next step rides on K5 (k5_tile<., ., true>) unless the lists must come from an exact sort
+  const bool fuse = h->fuse_search && h->P.np > 0;
+  bool tiles_cleared = false;
   auto nodal_accel = [&](int part) {
     const NodeRanges r = node_ranges(h, part);
-    if (r.an + r.bn == 0) return;
-    if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2]);
-    else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2]);
+    const bool fbin = fuse && h->fuse_search == 1;
+    int* ctile = (fbin && !tiles_cleared) ? h->tile_count2_d + h->tile0 : nullptr;
+    if (r.an + r.bn == 0 && !ctile) return;
+    tiles_cleared = true;
+    int* cnode = (fbin && node_lists(h)) ? h->node_cnt_d : nullptr;
+    if (ND == 2) hipLaunchKernelGGL(k_nodal_accel<2>, dim3(nblk(std::max(1, r.an + r.bn))), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2], fbin ? 1 : 0, cnode, ctile, h->ntw);
+    else hipLaunchKernelGGL(k_nodal_accel<3>, dim3(nblk(std::max(1, r.an + r.bn))), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->N, gv[0], gv[1], gv[2], fbin ? 1 : 0, cnode, ctile, h->ntw);
   };
   auto launch_k3 = [&](int cls, bool signal = false) {
     TileD td = tile_view(h, cls);
@@ -3440,12 +3526,25 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
 #undef NLPS_K3F
 #undef NLPS_K3
   };
+  K5Search ks;
+  ks.rank1 = h->rank1_d;
+  ks.bin = h->fuse_search == 1;
+  bool ks_made = false;
   auto launch_k5 = [&](int cls) {
     TileD td = tile_view(h, cls);
+    if (fuse && !ks_made) {  // (one TileCnt per step: it consumes the re-home flag of the adaptive re-sort)
+      ks.tc = tile_cnt(h, true);
+      ks.tc.count = h->tile_count2_d;  // (tile_count_d sizes the lists this very launch walks)
+      ks_made = true;
+    }
 #define NLPS_K5(NDv, LAWv)                                                                               \
   do {                                                                                                   \
-    hipLaunchKernelGGL((k5_tile<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g,      \
-                       h->N, td, dt, gamma_nm);                                                          \
+    if (fuse)                                                                                            \
+      hipLaunchKernelGGL((k5_tile<NDv, LAWv, true>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g, \
+                         h->N, td, dt, gamma_nm, ks);                                                    \
+    else                                                                                                 \
+      hipLaunchKernelGGL((k5_tile<NDv, LAWv, false>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g, \
+                         h->N, td, dt, gamma_nm, ks);                                                    \
   } while (0)
     const int law = h->uniform_law;
     if (ND == 2) {
@@ -3519,6 +3618,8 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }  // !ov2
   h->P.flip ^= 1;  // F_n <- F_n+1, b_e,n <- b_e,n+1 by renaming
   h->rolled = true;
+  h->searched = fuse;                      // K5 has updated the closest nodes for the positions it wrote ...
+  h->ahead = fuse && h->fuse_search == 1;  // ... and binned the particles for the next step
   if (h->timing) {
     HIPCHK(hipEventRecord(h->ev[6], h->stream));
     // calibration bracket: a kernel of K3's grid and argument block that does nothing; what it reads is the part of

@@ -1409,8 +1409,17 @@ __global__ void k_slab_gather(int a0, int an, int b0, int bn, GridD g, TileD td,
 // keeps {ax, ay} as one 16-B double2 per node (ds_read_b128) and az in a separate 8-B array, the layout that
 // is conflict-free for the tile's 64 I0 positions (see K3).
 // ------------------------------------------------------------------------------------------------
-template <int ND, int LAW>
-__global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm) {
+// SEARCH: the kernel also does the first stage of the NEXT step for the particles it has just moved -- closest-node
+// update from the new position (LME.c:924-930), activation seed, binning to tiles and per-node ranks (k_search) --
+// while x, dis and I0 are in registers: one launch and one pass over the particle arrays less per step.  The seeds and
+// counters it writes were reset by the nodal kernel in front of it (k_nodal_accel).
+struct K5Search {
+  const uint8_t* rank1;  // chain positions of the 3^d candidates per boundary class (get_closest_node tie-break)
+  TileCnt tc;
+  int bin;  // 0: closest-node update only (I0n); the seeds and bins are left to k_search in its adopt form
+};
+template <int ND, int LAW, bool SEARCH = false>
+__global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm, K5Search ks) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   __shared__ __attribute__((aligned(16))) double axy[2 * NW];
   __shared__ double az[(ND == 3) ? NW : 1];
@@ -1437,74 +1446,95 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
   __syncthreads();
   const double2* a2 = reinterpret_cast<const double2*>(axy);
   const int start = td.start[tile];
-  for (int s = part * K5_BLK + threadIdx.x; s < cnt; s += K5_BLK * nparts) {
-    const int p = td.order_m[start + s];
-    Lme<ND> c;
-    double lam[ND], beta;
-    if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
-    const int base = window_base<ND>(c.ijk, w0);
-    NLPS_YZ_LOCALS(c);
-    double Z = 0.0, sv[ND];
-#pragma unroll
-    for (int a = 0; a < ND; a++) sv[a] = 0.0;
-#if NLPS_K5_PREFETCH
-    // the operands of the corrector are requested before the gather loop, so that their latency runs under it
-    double dd_[ND], vel_[ND], dis_[ND];
-#pragma unroll
-    for (int a = 0; a < ND; a++) {
-      dd_[a] = PF(P, F_DDIS + a, p);
-      vel_[a] = PF(P, F_VEL + a, p);
-      dis_[a] = PF(P, F_DIS + a, p);
-    }
-#endif
-#pragma unroll NLPS_KUNROLL_K5
-    for (int k = 0; k < KN; k++) {
-      const unsigned pb = plane_bits<ND>(c, k);
-      const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
-      const double z0 = ez5[k];
-#pragma unroll NLPS_JUNROLL_K5
-      for (int j = 0; j < 5; j++) {
-        const unsigned bits = (pb >> (5 * j)) & 31u;
-        if (!wave_row_used(bits)) continue;
-        double A0 = 0.0, R[ND];
-#pragma unroll
-        for (int a = 0; a < ND; a++) R[a] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
-          const int li = basek + (i - 2) + W * (j - 2);
-          const double m0 = masked_weight(c.ex[i], bits, i);
-          A0 += m0;
-          const double2 v01 = a2[li];
-          R[0] = fma(m0, v01.x, R[0]);
-          R[1] = fma(m0, v01.y, R[1]);
-          if (ND == 3) R[2 % ND] = fma(m0, az[(ND == 3) ? li : 0], R[2 % ND]);
+  // (SEARCH: the binning is wave-cooperative, so every lane of a wave makes the same number of trips)
+  for (int s0 = part * K5_BLK; s0 < cnt; s0 += K5_BLK * nparts) {
+    const int s = s0 + (int)threadIdx.x;
+    const bool have = s < cnt;
+    if (!SEARCH && !have) continue;
+    const int p = have ? td.order_m[start + s] : 0;
+    int I0n = 0;
+    bool binned = false;
+    do {
+      if (!have) break;
+      Lme<ND> c;
+      double lam[ND], beta;
+      if (!load_lme<ND>(P, g, p, c, lam, beta)) {
+        if (SEARCH) {  // a particle without a neighbourhood does not move, but the next step still lists it
+          I0n = P.I0[p];
+          binned = true;
         }
-        const double w = ey5[j] * z0;
-        Z = fma(w, A0, Z);
-#pragma unroll
-        for (int a = 0; a < ND; a++) sv[a] = fma(w, R[a], sv[a]);
+        break;
       }
-    }
-    const double Zinv = 1.0 / Z;
+      const int base = window_base<ND>(c.ijk, w0);
+      NLPS_YZ_LOCALS(c);
+      double Z = 0.0, sv[ND];
 #pragma unroll
-    for (int a = 0; a < ND; a++) {
-#if NLPS_K5_PREFETCH
-      const double dd = dd_[a], av = sv[a] * Zinv;
-      PF(P, F_ACC + a, p) = av;
-      PF(P, F_VEL + a, p) = vel_[a] + gamma_nm * dt * av;
-      PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
-      PF(P, F_DIS + a, p) = dis_[a] + dd;
-#else
-      const double dd = PF(P, F_DDIS + a, p), av = sv[a] * Zinv;
-      PF(P, F_ACC + a, p) = av;
-      PF(P, F_VEL + a, p) = PF(P, F_VEL + a, p) + gamma_nm * dt * av;
-      PF(P, F_X + a, p) = PF(P, F_X + a, p) + dd;
-      PF(P, F_DIS + a, p) = PF(P, F_DIS + a, p) + dd;
-#endif
+      for (int a = 0; a < ND; a++) sv[a] = 0.0;
+      // the operands of the corrector are requested before the gather loop, so that their latency runs under it
+      double dd_[ND], vel_[ND], dis_[ND];
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        dd_[a] = PF(P, F_DDIS + a, p);
+        vel_[a] = PF(P, F_VEL + a, p);
+        dis_[a] = PF(P, F_DIS + a, p);
+      }
+#pragma unroll NLPS_KUNROLL_K5
+      for (int k = 0; k < KN; k++) {
+        const unsigned pb = plane_bits<ND>(c, k);
+        const int basek = base + (ND == 3 ? PS * (k - 2) : 0);
+        const double z0 = ez5[k];
+#pragma unroll NLPS_JUNROLL_K5
+        for (int j = 0; j < 5; j++) {
+          const unsigned bits = (pb >> (5 * j)) & 31u;
+          if (!wave_row_used(bits)) continue;
+          double A0 = 0.0, R[ND];
+#pragma unroll
+          for (int a = 0; a < ND; a++) R[a] = 0.0;
+#pragma unroll
+          for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
+            const int li = basek + (i - 2) + W * (j - 2);
+            const double m0 = masked_weight(c.ex[i], bits, i);
+            A0 += m0;
+            const double2 v01 = a2[li];
+            R[0] = fma(m0, v01.x, R[0]);
+            R[1] = fma(m0, v01.y, R[1]);
+            if (ND == 3) R[2 % ND] = fma(m0, az[(ND == 3) ? li : 0], R[2 % ND]);
+          }
+          const double w = ey5[j] * z0;
+          Z = fma(w, A0, Z);
+#pragma unroll
+          for (int a = 0; a < ND; a++) sv[a] = fma(w, R[a], sv[a]);
+        }
+      }
+      const double Zinv = 1.0 / Z;
+      double xn[ND], dn2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < ND; a++) {
+        const double dd = dd_[a], av = sv[a] * Zinv;
+        PF(P, F_ACC + a, p) = av;
+        PF(P, F_VEL + a, p) = vel_[a] + gamma_nm * dt * av;
+        xn[a] = PF(P, F_X + a, p) + dd;
+        PF(P, F_X + a, p) = xn[a];
+        const double dn = dis_[a] + dd;
+        PF(P, F_DIS + a, p) = dn;
+        dn2 += dsqr(dn);
+      }
+      // The roll of U-Verlet.c:1062-1075 costs no traffic here: F and b_e roll by renaming (the host swaps the roles of
+      // their two slots after this kernel, PView::flip; the stale slot is rewritten in full by the next K3), J, kappa and
+      // eps-bar were written to their n slots by K3 in the first place (stress_update LAZY).
+      if (SEARCH) {
+        I0n = c.I0;
+        if (sqrt(dn2) > 0.0) {  // norm__MatrixLib__(dis_p,2) > 0, LME.c:924
+          I0n = closest_node_update<ND>(g, ks.rank1, xn, c.I0);
+        }
+        P.I0n[p] = I0n;  // (P.I0 stays the node of the last search until the next one adopts this: downloads see it)
+        binned = true;
+      }
+    } while (false);
+    if (SEARCH && ks.bin) {
+      bin_particle<ND>(P, g, ks.tc, binned ? p : P.np, I0n, binned);
+      if (binned && P.tile[p] >= 0) N.seed[I0n] = 1;
     }
-    // The roll of U-Verlet.c:1062-1075 costs no traffic here: F and b_e roll by renaming (the host swaps the roles of
-    // their two slots after this kernel, PView::flip; the stale slot is rewritten in full by the next K3), J, kappa and
-    // eps-bar were written to their n slots by K3 in the first place (stress_update LAZY).
   }
 }
 
