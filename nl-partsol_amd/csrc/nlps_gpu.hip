@@ -203,6 +203,17 @@ __device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
   return c;
 }
 
+// in front of k_step_fused: its queue head, and what the search that rides on its K5 stage accumulates into
+__global__ void k_fused_prep(int n0, int nnodes, unsigned char* __restrict__ seed, int* __restrict__ node_cnt,
+                             int* __restrict__ tile_count, int ntiles, unsigned* __restrict__ q_head) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *q_head = 0u;
+  if (t < ntiles) tile_count[t] = 0;
+  if (t >= nnodes) return;
+  seed[(size_t)n0 + t] = 0;
+  if (node_cnt) node_cnt[(size_t)n0 + t] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // S1a: closest-node update (LME.c:913-945, Nodes-Tools.c:476-538) + 1-ring activation (LME.c:949-960)
 // ------------------------------------------------------------------------------------------------
@@ -1209,6 +1220,20 @@ struct nlps_gpu {
   // counters of that search are in place, the next explicit step starts at the activation kernel.
   bool searched = false, ahead = false;
   int fuse_search = 1;  // developer switch NLPS_FUSE_SEARCH
+  // k_step_fused (one launch for K2, K3, K5): queue head + per-tile flags, the step's sequence number, what the lazily
+  // run nodal kernels need to reproduce dU / accelerations / reactions for nlps_gpu_explicit_nodal
+  // OFF: on the GPU boxes of round 3 the launch never completed once a second stage had items, even with the stage bodies
+  // and every wait and publish taken out (while tools/fused_sync_test.hip, the same skeleton without the physics, ran
+  // in 0.1 ms): unfinished, kept behind the developer switch NLPS_FUSED_STEP=1 ("k_step_fused")
+  int fused_step = 0;
+  unsigned* fused_q_d = nullptr;
+  unsigned* fused_done_d = nullptr;  // [2][ntiles]
+  unsigned fused_seq = 0;
+  int ncu = 256;
+  bool nodal_stale = false;
+  BcStep last_bc;
+  const unsigned* last_bm = nullptr;
+  double last_gv[3] = {0, 0, 0};
   // migration
   int* gid_d = nullptr;               // global particle id (default: the caller's index)
   unsigned char* leaving_d = nullptr;  // 0 stay, 1 leaves downwards, 2 upwards (between select and commit)
@@ -1619,6 +1644,12 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
   if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
   if (const char* e = getenv("NLPS_FUSE_SEARCH")) h->fuse_search = atoi(e);
+  if (const char* e = getenv("NLPS_FUSED_STEP")) h->fused_step = atoi(e);
+  {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+      h->ncu = ncu;
+  }
 
   h->tab = nlps_host::build_tables(g.nd);
   HIPCHK(hipMalloc((void**)&h->rank1_d, 27 * 27));
@@ -2095,7 +2126,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->fused_q_d, h->fused_done_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2867,7 +2898,8 @@ static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm
 // S1: closest-node update + 1-ring activation + binning of the particles to I0-tiles, then lists, beta and the
 // Newton iteration (+ predictor and P2G of mass / m*dD when `p2g`).  With `overlap` the exchange of the active
 // flags runs behind the tiles that do not touch a ghost band.
-static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, int overlap = 0) {
+static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, int overlap = 0,
+                            bool launch_lists_kernel = true) {
   int np = h->P.np;
   // ahead: the search of this step was done by the last kernel of the previous one (k5_tile<., ., true>); only the
   // nodal accumulators are reset here
@@ -2933,7 +2965,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   } else if (overlap == 2) {  // the flags travelled behind the binning kernels; one launch, boundary tiles first
     if (halo(h, h->N.active, 1, 1, 1, 2)) return 1;
     launch_k2(h, p2g, 0, dt, gamma_nm, true);
-  } else {
+  } else if (launch_lists_kernel) {  // (k_step_fused runs K2 as the first stage of its own launch)
     launch_k2(h, p2g, 0, dt, gamma_nm);
   }
   HIPCHK(hipGetLastError());
@@ -3556,6 +3588,64 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     }
 #undef NLPS_K5
   };
+  // One launch for K2, K3 and K5 (k_step_fused): one GPU without a ghost exchange, 3-D, one law, the Dirichlet sets
+  // small enough to travel as kernel arguments.  The nodal kernels between the stages run lazily, only when somebody
+  // asks for the nodal arrays (nlps_gpu_explicit_nodal).
+  const bool fusedk = h->fused_step && fuse && h->fuse_search == 1 && ND == 3 && !det && !h->rccl && !h->halo &&
+                      h->uniform_law == NLPS_MAT_NEO_HOOKEAN && nbcc <= NLPS_MAX_BC_INLINE;
+  if (fusedk) {
+    if (search_and_lists(h, false, true, dt, gamma_nm, 0, false)) return 1;
+    if (h->timing) {
+      HIPCHK(hipEventRecord(h->ev[2], h->stream));
+      HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    }
+    if (!h->fused_q_d) {
+      HIPCHK(hipMalloc((void**)&h->fused_q_d, 64));
+      HIPCHK(hipMalloc((void**)&h->fused_done_d, 2 * (size_t)h->ntiles * sizeof(unsigned)));
+      HIPCHK(hipMemsetAsync(h->fused_done_d, 0, 2 * (size_t)h->ntiles * sizeof(unsigned), h->stream));
+    }
+    hipLaunchKernelGGL(k_fused_prep, dim3(nblk(std::max(h->nwn, h->ntw))), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N.seed,
+                       node_lists(h) ? h->node_cnt_d : nullptr, h->tile_count2_d + h->tile0, h->ntw, h->fused_q_d);
+    FusedStep fs;
+    fs.q_head = h->fused_q_d;
+    fs.done2 = h->fused_done_d;
+    fs.done3 = h->fused_done_d + h->ntiles;
+    if (++h->fused_seq == 0u) {  // (the flags compare modulo 2^32: restart them with the counter)
+      HIPCHK(hipMemsetAsync(h->fused_done_d, 0, 2 * (size_t)h->ntiles * sizeof(unsigned), h->stream));
+      h->fused_seq = 1u;
+    }
+    fs.seq = h->fused_seq;
+    fs.nstages = 3;
+    if (const char* e = getenv("NLPS_FUSED_STAGES")) fs.nstages = atoi(e);
+    fs.debug = 0;
+    if (const char* e = getenv("NLPS_FUSED_DEBUG")) fs.debug = atoi(e);
+    fs.bc.n = nbcc;
+    for (int i = 0; i < nbcc; i++) {
+      fs.bc.dim[i] = bcc[i].dim;
+      fs.bc.bits[i] = h->bcs[i].n > 0 ? dirbits_of(bcc[i], step, h->nsteps) : 0;
+      for (int k = 0; k < 3; k++) fs.bc.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
+    }
+    fs.bcmask = nbcc > 0 ? h->bcmask_d : nullptr;
+    for (int a = 0; a < 3; a++) fs.gv[a] = gv[a];
+    K5Search ksf;
+    ksf.rank1 = h->rank1_d;
+    ksf.bin = 1;
+    ksf.tc = tile_cnt(h, true);
+    ksf.tc.count = h->tile_count2_d;
+    const TileD tdf = tile_view(h, 0);
+    hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(3 * h->ncu), dim3(BLK), 0, h->stream, h->P, h->g, h->N, tdf,
+                       h->mats_d, h->prm, dt, gamma_nm, h->gstatus_d, ksf, fs);
+    HIPCHK(hipGetLastError());
+    if (h->timing) {
+      HIPCHK(hipEventRecord(h->ev[4], h->stream));
+      HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    }
+    h->nodal_stale = true;
+    h->last_bc = fs.bc;
+    h->last_bm = fs.bcmask;
+    for (int a = 0; a < 3; a++) h->last_gv[a] = gv[a];
+  } else {
+  h->nodal_stale = false;
   // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel; the nodal accumulators of
   // the node window are reset by k_step_clear inside search_and_lists)
   if (search_and_lists(h, false, true, dt, gamma_nm, ov2 ? 2 : (ov ? 1 : 0))) return 1;
@@ -3616,6 +3706,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   HIPCHK(hipGetLastError());
   }  // !ov2
+  }  // !fusedk
   h->P.flip ^= 1;  // F_n <- F_n+1, b_e,n <- b_e,n+1 by renaming
   h->rolled = true;
   h->searched = fuse;                      // K5 has updated the closest nodes for the positions it wrote ...
@@ -3642,6 +3733,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     h->ms[2] = t34;
     h->ms[3] = t56;
     h->ms[4] = t23 + t45;
+    h->ms[7] = fusedk ? 1.f : 0.f;  // 1: slot 2 is the whole of k_step_fused (K2 + K3 + K5 and the nodal work between them)
     h->ms[6] = 0.f;  // time the handle's stream spent in / waiting for the ghost-layer exchanges of this step
     for (int q = 0; q < h->nwait; q++) {
       float tw = 0.f;
@@ -3663,6 +3755,14 @@ extern "C" int nlps_gpu_num_active(nlps_gpu* h, int* nactive) {
 extern "C" int nlps_gpu_explicit_nodal(nlps_gpu* h, double* mass, double* dU, double* force, double* accel,
                                        double* reaction) {
   int ND = h->nd;
+  if (h->nodal_stale) {  // the last step ran as k_step_fused: dU, accelerations and reactions were never stored
+    const NodeRanges r = node_ranges(h, 0);
+    LAUNCH_ND((k_nodal_dU<2>), (k_nodal_dU<3>), nblk(r.an + r.bn), r.a0, r.an, r.b0, r.bn, h->N, h->last_bm, h->last_bc);
+    LAUNCH_ND((k_nodal_accel<2>), (k_nodal_accel<3>), nblk(r.an + r.bn), r.a0, r.an, r.b0, r.bn, h->N, h->last_gv[0],
+              h->last_gv[1], h->last_gv[2], 0, (int*)nullptr, (int*)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    h->nodal_stale = false;
+  }
   if (compute_node_mask(h)) return 1;
   HIPCHK(hipMemcpyAsync(&h->nactive, h->total_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -551,22 +551,133 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 };
 
 // ------------------------------------------------------------------------------------------------
+// One launch for the three tile stages of the explicit step (k_step_fused, one GPU, no ghost exchange).  A kernel ends
+// with a tail: the last workgroups of K2 run on a half-empty chip before K3 may start -- measured ~40 us per stage at
+// 1 M particles, a sixth of the step -- although a K3 tile only needs the nodal sums of its OWN window, i.e. the K2
+// tiles around it.  Persistent workgroups take work items from one queue, all K2 tiles first, then the K3 tiles, then
+// the K5 tiles; a tile publishes a per-tile sequence number once its window flush has reached L2, and a tile of the
+// next stage waits for the (up to 3^d) tiles whose windows overlap its own.  An item only ever waits for items taken
+// from the queue before it, by workgroups that are running: no assumption on dispatch order or co-residency.  The
+// nodal kernels between the stages (dU = sum m N dD / M with the Dirichlet values; a = g + f / M) become part of the
+// window loads of K3 and K5, read with agent-scope loads that bypass the L1 of the CU.
+// ------------------------------------------------------------------------------------------------
+struct FusedStep {
+  unsigned* q_head;      // work queue: items [0, n) K2, [n, 2n) K3, [2n, 3n) K5 over the n entries of the work list
+  unsigned* done2;       // [ntiles] sequence number of the last step whose K2 flush of this tile is in L2
+  unsigned* done3;       // the same for the force flush of K3
+  unsigned seq;          // this step's number (never 0)
+  int nstages;           // 3; developer switch NLPS_FUSED_STAGES runs the first stages only
+  int debug;
+  const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
+  BcStep bc;             // their components and values at this step
+  double gv[3];          // gravity
+};
+// one lane per neighbouring tile polls its flag (relaxed, L1-bypassing loads; s_sleep between polls); false after
+// ~0.2 s of the constant 100 MHz clock
+__device__ __forceinline__ bool fused_wait(const unsigned* flag, unsigned seq) {
+  const unsigned long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+    if (wall_clock64() - t0 > 20000000ull) return false;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return true;
+}
+// all threads of a workgroup, before a window load of a later stage: the flushes of the tiles around `tile` are visible
+// (consumer side of MI355X_MICROARCH.md "Valid forms": relaxed polls, ONE agent acquire by the polling wave, its wait,
+// the workgroup barrier; the window loads that follow bypass L1 anyway, coherent_load)
+template <int ND>
+__device__ __forceinline__ void fused_wait_neighbours(const TileD& td, int tile, const unsigned* done, unsigned seq,
+                                                      int* __restrict__ gstatus) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    if (t < (ND == 3 ? 27 : 9)) {
+      const int tx = tile % td.nt[0], ty = (tile / td.nt[0]) % td.nt[1], tz = tile / (td.nt[0] * td.nt[1]);
+      const int x = tx + t % 3 - 1, y = ty + (t / 3) % 3 - 1, z = (ND == 3) ? tz + t / 9 - 1 : 0;
+      if (x >= 0 && x < td.nt[0] && y >= 0 && y < td.nt[1] && z >= 0 && z < (ND == 3 ? td.nt[2] : 1)) {
+        const int nb = x + td.nt[0] * (y + td.nt[1] * z);
+        if (nb >= td.tile0 && nb < td.tile0 + td.ntw && td.count[nb] > 0)
+          if (!fused_wait(done + nb, seq)) atomicOr(gstatus, 32);  // ST_SYNC: reported, never a hang
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+// after a window flush: every wave drains its atomics, the workgroup meets, one lane releases at agent scope
+__device__ __forceinline__ void fused_publish(unsigned* flag, unsigned seq) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// a double that another workgroup's atomics may have changed since this CU last cached its line
+__device__ __forceinline__ double coherent_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// what k_nodal_dU makes of a node (U-Verlet.c:357-362 + :455-527), from the nodal sums as they stand in L2
+template <int ND>
+__device__ __forceinline__ void fused_nodal_dU(const NView& N, const FusedStep& fs, int A, double* val, bool* fix) {
+  const double M = coherent_load(N.nm + (size_t)A * (1 + ND));
+  const bool active = N.active[A];
+  const bool act = active && M != 0.0;
+#pragma unroll
+  for (int a = 0; a < ND; a++) {
+    val[a] = act ? coherent_load(N.nm + (size_t)A * (1 + ND) + 1 + a) / M : 0.0;
+    fix[a] = false;
+  }
+  const unsigned bm = (fs.bcmask && active) ? fs.bcmask[A] : 0u;
+  if (bm) {
+    for (int i = 0; i < fs.bc.n; i++) {
+      if (!((bm >> i) & 1u)) continue;
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        if (k < fs.bc.dim[i] && ((fs.bc.bits[i] >> k) & 1)) {
+          val[k] = fs.bc.v[i][k];
+          fix[k] = true;
+        }
+    }
+  }
+}
+// what k_nodal_accel makes of it (U-Verlet.c:947-957)
+template <int ND>
+__device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedStep& fs, int A, double* acc) {
+  double dU[ND];
+  bool fix[ND];
+  const double M = coherent_load(N.nm + (size_t)A * (1 + ND));
+  const bool act = N.active[A] && M != 0.0;
+  (void)dU;
+#pragma unroll
+  for (int a = 0; a < ND; a++) fix[a] = false;
+  const unsigned bm = (fs.bcmask && N.active[A]) ? fs.bcmask[A] : 0u;
+  if (bm) {
+    for (int i = 0; i < fs.bc.n; i++) {
+      if (!((bm >> i) & 1u)) continue;
+#pragma unroll
+      for (int k = 0; k < ND; k++)
+        if (k < fs.bc.dim[i] && ((fs.bc.bits[i] >> k) & 1)) fix[k] = true;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < ND; a++)
+    acc[a] = (act && !fix[a]) ? fs.gv[a] + coherent_load(N.force + (size_t)A * ND + a) / M : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
-// NT / SPLIT: threads per workgroup and workgroups per tile.  The default is (BLK, K2_SPLIT); deterministic mode runs one
-// wave per tile (64, 1): the sorted tile list is then accumulated in list order by a single instruction stream.
-template <int ND, bool P2G, int NT = BLK, int SPLIT = K2_SPLIT>
-__global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES)) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
-                                               double gamma_nm, int* __restrict__ gstatus) {
+// body of k2_tile for one work item; acc [NF * NWA] doubles and actrow [NROWS] words of LDS are the caller's.
+// fs != nullptr: part of k_step_fused (the tile publishes its flush instead of signalling an exchange stream, and
+// resets the search state of its own nodes for the search that rides on K5)
+template <int ND, bool P2G, int NT>
+__device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NView& N, const TileD& td, const ParamsD& prm,
+                                        double dt, double gamma_nm, int* __restrict__ gstatus, const TileWork& tw, int nbnd,
+                                        double* acc, unsigned* actrow, const FusedStep* fs) {
   constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
   constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
   constexpr int KN = Lme<ND>::KN;
-  __shared__ double acc[NF * NWA];
-  __shared__ unsigned actrow[NROWS];
-  const int nbnd = td.sig_flag ? td.range[4 + 2 * (SPLIT - 1) + 1] : 0;  // boundary workgroups come first (cls 0 view)
-  tile_signal_empty(td, nbnd);
-  TileWork tw;
-  if (!tile_work_item<SPLIT>(td, tw)) return;
   const int wb = tw.wb, tile = tw.tile, part = tw.part, nparts = tw.nparts;
   const int cnt = td.count[tile];
   PH_INIT
@@ -811,7 +922,20 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
     }
   }
   PH(5)
-  tile_signal(td, wb, nbnd);
+  if (!fs) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
+}
+// NT / SPLIT: threads per workgroup and workgroups per tile.  The default is (BLK, K2_SPLIT); deterministic mode runs one
+// wave per tile (64, 1): the sorted tile list is then accumulated in list order by a single instruction stream.
+template <int ND, bool P2G, int NT = BLK, int SPLIT = K2_SPLIT>
+__global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NLPS_K2_WAVES)) void k2_tile(PView P, GridD g, NView N, TileD td, ParamsD prm, double dt,
+                                               double gamma_nm, int* __restrict__ gstatus) {
+  __shared__ double acc[(1 + ND) * TileCfg<ND>::NWA];
+  __shared__ unsigned actrow[WinRows<ND>::NROWS];
+  const int nbnd = td.sig_flag ? td.range[4 + 2 * (SPLIT - 1) + 1] : 0;  // boundary workgroups come first (cls 0 view)
+  tile_signal_empty(td, nbnd);
+  TileWork tw;
+  if (!tile_work_item<SPLIT>(td, tw)) return;
+  k2_body<ND, P2G, NT>(P, g, N, td, prm, dt, gamma_nm, gstatus, tw, nbnd, acc, actrow, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,31 +954,46 @@ template <int ND, int LAW, int MODE>
 struct K3Waves {
   static constexpr int value = ND == 2 ? NLPS_K3_WAVES_2D : ((MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN) ? NLPS_K3_WAVES_NH : NLPS_K3_WAVES);
 };
-template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
-__global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value))) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
-                                               ParamsD prm, int* __restrict__ gstatus,
-                                               const double* __restrict__ dVgrid) {
+// the LDS of k3_tile, owned by the caller of k3_body (the kernel below, or k_step_fused, which shares one block of LDS
+// between its three stages)
+template <int ND, int MODE, bool FILT>
+struct K3Lds {
+  static constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA;
+  static constexpr bool RATES = (MODE == 2);
+  static constexpr int SELCAP = FILT ? 4096 : 1;
+  static constexpr int N_DVXY = RATES ? 2 * NW : 2, N_DVZ = (RATES && ND == 3) ? NW : 1, N_DUZ = (ND == 3) ? NW : 1;
+  double* dvxy;  // [N_DVXY], 16-byte aligned
+  double* dvz;   // [N_DVZ]
+  double* duxy;  // [2 NW], 16-byte aligned
+  double* duz;   // [N_DUZ]
+  double* fac;   // [ND NWA]
+  int* sel;      // [SELCAP]
+  int* nsel;     // [1]
+  int* wcnt;     // [NT / 64]
+};
+template <int ND, int LAW, int MODE, bool FILT, int NT>
+__device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NView& N, const TileD& td,
+                                        const MatD* __restrict__ mats, const ParamsD& prm, int* __restrict__ gstatus,
+                                        const double* __restrict__ dVgrid, const TileWork& tw, int nbnd,
+                                        const K3Lds<ND, MODE, FILT>& lds, const FusedStep* fs) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr bool RATES = (MODE == 2);
-  __shared__ __attribute__((aligned(16))) double dvxy[RATES ? 2 * NW : 2];
-  __shared__ double dvz[(RATES && ND == 3) ? NW : 1];
   // gather window of dU: {x,y} as one 16-B double2 per node (ds_read_b128) + z as a separate 8-B array
   // (ds_read_b64): with node strides of 16 B and 8 B the tile's 64 I0 positions hit distinct banks; a
   // padded 32-B AoS row put every second node on the same banks (41 % conflict cycles measured).
-  __shared__ __attribute__((aligned(16))) double duxy[2 * NW];
-  __shared__ double duz[(ND == 3) ? NW : 1];
+  double* const dvxy = lds.dvxy;
+  double* const dvz = lds.dvz;
+  double* const duxy = lds.duxy;
+  double* const duz = lds.duz;
+  double* const fac = lds.fac;
+  int* const sel = lds.sel;
+  int& nsel = *lds.nsel;
+  int* const wcnt = lds.wcnt;
   constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
-  __shared__ double fac[ND * NWA];
-  const int nbnd = (MODE == 1 && td.sig_flag) ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;
-  if (MODE == 1) tile_signal_empty(td, nbnd);
-  TileWork tw;
-  if (!tile_work_item<K3_SPLIT>(td, tw)) return;
   const int wb = tw.wb, tile = tw.tile, part = tw.part, nparts = tw.nparts;
   int cnt = td.count[tile];
   PH_INIT
   constexpr int SELCAP = FILT ? 4096 : 1;
-  __shared__ int sel[SELCAP];
-  __shared__ int nsel;
   bool listed = false;  // sel[] holds this launch's particles
   if (FILT) {
     const int start0 = td.start[tile];
@@ -863,7 +1002,6 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
     if (cnt <= SELCAP) {
       // ordered compaction (the selected particles keep the order of the tile list: runs of memory-consecutive
       // particles stay together, and the accumulation order is a function of the list alone)
-      __shared__ int wcnt[NT / 64];
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       for (int s0 = 0; s0 < cnt; s0 += NT) {  // uniform trip count
         const int s = s0 + threadIdx.x;
@@ -911,9 +1049,20 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
       idx = idx0;
       node = window_node<ND>(g, w0, idx, in);
     }
-    duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
-    duxy[2 * idx + 1] = in ? N.dU[(size_t)node * ND + 1] : 0.0;
-    if (ND == 3) duz[(ND == 3) ? idx : 0] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
+    if (fs) {  // (k_step_fused: the nodal kernel's job, on the sums the K2 tiles around have published)
+      double val[ND];
+      bool fix[ND];
+#pragma unroll
+      for (int a = 0; a < ND; a++) val[a] = 0.0;
+      if (in) fused_nodal_dU<ND>(N, *fs, node, val, fix);
+      duxy[2 * idx] = val[0];
+      duxy[2 * idx + 1] = val[1];
+      if (ND == 3) duz[(ND == 3) ? idx : 0] = val[2 % ND];
+    } else {
+      duxy[2 * idx] = in ? N.dU[(size_t)node * ND + 0] : 0.0;
+      duxy[2 * idx + 1] = in ? N.dU[(size_t)node * ND + 1] : 0.0;
+      if (ND == 3) duz[(ND == 3) ? idx : 0] = in ? N.dU[(size_t)node * ND + (2 % ND)] : 0.0;
+    }
     if (RATES) {
       dvxy[RATES ? 2 * idx : 0] = in ? dVgrid[(size_t)node * ND + 0] : 0.0;
       dvxy[RATES ? 2 * idx + 1 : 1] = in ? dVgrid[(size_t)node * ND + 1] : 0.0;
@@ -1363,7 +1512,27 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
     }
   }
   PH(14)
-  tile_signal(td, wb, nbnd);
+  if (!fs) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
+}
+template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
+__global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value))) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+                                               ParamsD prm, int* __restrict__ gstatus,
+                                               const double* __restrict__ dVgrid) {
+  using L = K3Lds<ND, MODE, FILT>;
+  __shared__ __attribute__((aligned(16))) double dvxy[L::N_DVXY];
+  __shared__ double dvz[L::N_DVZ];
+  __shared__ __attribute__((aligned(16))) double duxy[2 * L::NW];
+  __shared__ double duz[L::N_DUZ];
+  __shared__ double fac[ND * L::NWA];
+  __shared__ int sel[L::SELCAP];
+  __shared__ int nsel;
+  __shared__ int wcnt[NT / 64];
+  const int nbnd = (MODE == 1 && td.sig_flag) ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;
+  if (MODE == 1) tile_signal_empty(td, nbnd);
+  TileWork tw;
+  if (!tile_work_item<K3_SPLIT>(td, tw)) return;
+  const L lds{dvxy, dvz, duxy, duz, fac, sel, &nsel, wcnt};
+  k3_body<ND, LAW, MODE, FILT, NT>(P, g, N, td, mats, prm, gstatus, dVgrid, tw, nbnd, lds, nullptr);
 }
 
 // Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)
@@ -1418,13 +1587,11 @@ struct K5Search {
   TileCnt tc;
   int bin;  // 0: closest-node update only (I0n); the seeds and bins are left to k_search in its adopt form
 };
-template <int ND, int LAW, bool SEARCH = false>
-__global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm, K5Search ks) {
+template <int ND, int LAW, bool SEARCH>
+__device__ __forceinline__ void k5_body(const PView& P, const GridD& g, const NView& N, const TileD& td, double dt,
+                                        double gamma_nm, const K5Search& ks, const TileWork& tw, double* axy, double* az,
+                                        const FusedStep* fs, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
-  __shared__ __attribute__((aligned(16))) double axy[2 * NW];
-  __shared__ double az[(ND == 3) ? NW : 1];
-  TileWork tw;
-  if (!tile_work_item<K5_SPLIT>(td, tw)) return;
   const int tile = tw.tile, part = tw.part, nparts = tw.nparts;
   const int cnt = td.count[tile];
   int w0[3];
@@ -1439,9 +1606,19 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
       idx = idx0;
       node = window_node<ND>(g, w0, idx, in);
     }
-    axy[2 * idx] = in ? N.accel[(size_t)node * ND + 0] : 0.0;
-    axy[2 * idx + 1] = in ? N.accel[(size_t)node * ND + 1] : 0.0;
-    if (ND == 3) az[(ND == 3) ? idx : 0] = in ? N.accel[(size_t)node * ND + (2 % ND)] : 0.0;
+    if (fs) {  // (k_step_fused: the nodal kernel's job, on the forces the K3 tiles around have published)
+      double av[ND];
+#pragma unroll
+      for (int a = 0; a < ND; a++) av[a] = 0.0;
+      if (in) fused_nodal_accel<ND>(N, *fs, node, av);
+      axy[2 * idx] = av[0];
+      axy[2 * idx + 1] = av[1];
+      if (ND == 3) az[(ND == 3) ? idx : 0] = av[2 % ND];
+    } else {
+      axy[2 * idx] = in ? N.accel[(size_t)node * ND + 0] : 0.0;
+      axy[2 * idx + 1] = in ? N.accel[(size_t)node * ND + 1] : 0.0;
+      if (ND == 3) az[(ND == 3) ? idx : 0] = in ? N.accel[(size_t)node * ND + (2 % ND)] : 0.0;
+    }
   }
   __syncthreads();
   const double2* a2 = reinterpret_cast<const double2*>(axy);
@@ -1535,6 +1712,76 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
       bin_particle<ND>(P, g, ks.tc, binned ? p : P.np, I0n, binned);
       if (binned && P.tile[p] >= 0) N.seed[I0n] = 1;
     }
+  }
+}
+
+template <int ND, int LAW, bool SEARCH = false>
+__global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm, K5Search ks) {
+  __shared__ __attribute__((aligned(16))) double axy[2 * TileCfg<ND>::NW];
+  __shared__ double az[(ND == 3) ? TileCfg<ND>::NW : 1];
+  TileWork tw;
+  if (!tile_work_item<K5_SPLIT>(td, tw)) return;
+  k5_body<ND, LAW, SEARCH>(P, g, N, td, dt, gamma_nm, ks, tw, axy, az, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_step_fused: K2, K3 and K5 of the explicit step as ONE launch of persistent workgroups (see FusedStep)
+// ------------------------------------------------------------------------------------------------
+template <int ND, int LAW>
+__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+                                                                                 ParamsD prm, double dt, double gamma_nm,
+                                                                                 int* __restrict__ gstatus, K5Search ks, FusedStep fs) {
+  static_assert(K3_BLK == BLK && K5_BLK == BLK && K2_SPLIT == 1 && K3_SPLIT == 1 && K5_SPLIT == 1, "one work list, one block size");
+  using L3 = K3Lds<ND, 1, false>;
+  constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA, NROWS = WinRows<ND>::NROWS;
+  // one block of LDS for the three stages: K2 {acc[(1+ND) NWA], actrow}, K3 {duxy, duz, fac, ...}, K5 {axy, az}
+  constexpr int N2 = (1 + ND) * NWA + (NROWS + 1) / 2;
+  constexpr int N3 = 2 * NW + L3::N_DUZ + ND * NWA + 2 + 2 + 8;
+  constexpr int N5 = 2 * NW + ((ND == 3) ? NW : 1);
+  constexpr int NSH = (N2 > N3 ? (N2 > N5 ? N2 : N5) : (N3 > N5 ? N3 : N5));
+  __shared__ __attribute__((aligned(16))) double sh[NSH];
+  __shared__ int s_item;
+  const int w_lo = td.range[0], nwork = td.range[1] - td.range[0];
+  while (true) {
+    if (threadIdx.x == 0) s_item = (int)atomicAdd(fs.q_head, 1u);
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(s_item);  // wave-uniform by construction: scalar branches below
+    __syncthreads();  // (s_item is rewritten at the top of the next trip; the stage bodies re-initialise their LDS)
+    if (item >= fs.nstages * nwork) break;
+    const int stage = item / nwork;
+    TileWork tw;
+    tw.wb = w_lo + (item - stage * nwork);
+    const int2 wk = td.work[0][tw.wb];
+    tw.tile = wk.x;
+    tw.part = 0;
+    tw.nparts = 1;
+    if (fs.debug == 1) continue;
+    // a tile of a later stage reads nodal sums of its window: the flushes of the tiles around it must have landed
+    if (stage == 1 && fs.debug != 7 && fs.debug < 10) fused_wait_neighbours<ND>(td, tw.tile, fs.done2, fs.seq, gstatus);
+    if (stage == 2 && fs.debug != 7) fused_wait_neighbours<ND>(td, tw.tile, fs.done3, fs.seq, gstatus);
+    if (stage == 0) {
+      double* acc = sh;
+      unsigned* actrow = reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA);
+      k2_body<ND, true, BLK>(P, g, N, td, prm, dt, gamma_nm, gstatus, tw, 0, acc, actrow, &fs);
+    } else if (stage == 1 && fs.debug >= 9) {
+      // (developer: the stage without its body)
+    } else if (stage == 1) {
+      double* duxy = sh;                       // 16-byte aligned (NW is even)
+      double* duz = duxy + 2 * NW;
+      double* fac = duz + L3::N_DUZ;
+      double* dvxy = fac + ND * NWA;           // MODE 1 has no rate windows: two placeholders each
+      double* dvz = dvxy + 2;
+      int* ints = reinterpret_cast<int*>(dvz + 2);
+      const L3 lds{dvxy, dvz, duxy, duz, fac, ints, ints + 2, ints + 4};
+      k3_body<ND, LAW, 1, false, BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, 0, lds, &fs);
+    } else {
+      double* axy = sh;
+      double* az = axy + 2 * NW;
+      k5_body<ND, (LAW == NLPS_MAT_NEO_HOOKEAN || LAW == NLPS_MAT_HENCKY) ? 0 : 2, true>(P, g, N, td, dt, gamma_nm, ks, tw, axy, az, &fs, gstatus);
+    }
+    if (fs.debug == 11 && stage == 1) {
+      __syncthreads();
+    } else if (stage < 2 && fs.debug != 8) fused_publish((stage == 0 || fs.debug == 10 ? fs.done2 : fs.done3) + tw.tile, fs.seq);
   }
 }
 

@@ -98,8 +98,12 @@ for t in range(5, 5 + a.steps):
     k += np.array(S.get_timing())
 k /= a.steps
 k[:4] = np.maximum(k[:4] - k[5], 0)
-print("%s law=%s cells=%d: search %.3f K2 %.3f K3 %.3f K5 %.3f nodal %.3f sum %.3f ms | flags %x" %
-      (a.tag, a.law, a.cells, k[0], k[1], k[2], k[3], k[4], k[:5].sum(), S.status_flags()), flush=True)
+if k[7] > 0.5:  # k_step_fused: one launch for K2 + K3 + K5 (its time sits in the K3 slot)
+    print("%s law=%s cells=%d: search %.3f fused K2+K3+K5 %.3f sum %.3f ms | flags %x" %
+          (a.tag, a.law, a.cells, k[0], k[2], k[:5].sum(), S.status_flags()), flush=True)
+else:
+    print("%s law=%s cells=%d: search %.3f K2 %.3f K3 %.3f K5 %.3f nodal %.3f sum %.3f ms | flags %x" %
+          (a.tag, a.law, a.cells, k[0], k[1], k[2], k[3], k[4], k[:5].sum(), S.status_flags()), flush=True)
 if a.phases:
     S.L.nlps_gpu_debug_phases(S.h, out.ctypes.data, 1)
     o = out.astype(np.float64) / a.steps
