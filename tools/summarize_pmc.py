@@ -24,6 +24,10 @@ def counters(d):
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(out, "%s_bench_kernel_stats.csv" % tag))
+for law in ("hencky", "dp"):  # kernel stats of tools/kbench.py --law ... (tools/profile.sh step 4)
+    g = glob.glob(os.path.join(src, "stats_" + law, "*", "*kernel_stats.csv"))
+    if g:
+        shutil.copy(g[0], os.path.join(out, "%s_kbench_%s_kernel_stats.csv" % (tag, law)))
 cf, cw = counters("calib_fetch"), counters("calib_write")
 known = (1 << 27) * 8 / 1024.0  # KiB read and written by tools/hbm_calib.hip per launch
 kf = [v for k, v in cf.items() if "copy8" in k][0]
