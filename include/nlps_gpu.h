@@ -68,6 +68,8 @@ typedef struct {
   double tol_radial_returning;   /* TOL_Radial_Returning            */
   int max_iter_radial_returning; /* Max_Iterations_Radial_Returning */
   int driver_eigenerosion;       /* Driver_EigenErosion (Globals.h): the damage hooks of the level-B stages (0 = off) */
+  int driver_eigensoftening;     /* Driver_EigenSoftening: the same hooks with Eigensoftening__Constitutive__ (0 = off;
+                                    both on = eigenerosion, like the if / else if of Constitutive.c:395-412) */
 } nlps_params;
 
 /* Material, Types.h:359-458 (members read by the three laws) */
@@ -84,6 +86,8 @@ typedef struct {
    * Generate-One-Phase-Analysis.c:620-626).  Their readers set TOL_Radial_Returning / Max_Iterations_Radial_Returning
    * to 1e-10 / 20 (Matsuoka-Nakai) and 1e-14 / 10 (Lade-Duncan): nlps_params carries them */
   double cohesion, alpha_borja, a_borja[3];
+  double ft, heps, wcrit; /* eigensoftening (Types.h:386-390, EigenSoftening.c:67-69): tensile strength, band width of the
+                             cohesive fracture, critical opening displacement */
 } nlps_material;
 
 /* Particle fields, Types.h:184-283 / 548-623: HOST pointers to the reference's row-major arrays
@@ -118,6 +122,8 @@ typedef struct {
   double *Back_stress;  /* [np][3] optional (0): principal back stress of Von-Mises (Phi.Back_stress), in/out */
   double *Damage_n;     /* [np] optional (0): Phi.Damage_n  (eigenerosion, driver_eigenerosion != 0) */
   double *Damage_n1;    /* [np] optional (Damage_n): Phi.Damage_n1 */
+  double *Strain_f_n;   /* [np] optional (0): Phi.Strain_f_n  (eigensoftening: strain at the onset of fracture) */
+  double *Strain_f_n1;  /* [np] optional (Strain_f_n): Phi.Strain_f_n1 -- the one Eigensoftening reads AND writes */
 } nlps_particles;
 
 /* Dirichlet boundary = Load of FEM_Mesh.Bounds (Types.h:296-351), flattened:

@@ -125,6 +125,8 @@ static nlps_particles nlps_glue_particles(Particle MPM_Mesh) {
   p.Back_stress = MPM_Mesh.Phi.Back_stress.nV;
   p.Damage_n = MPM_Mesh.Phi.Damage_n;
   p.Damage_n1 = MPM_Mesh.Phi.Damage_n1;
+  p.Strain_f_n = MPM_Mesh.Phi.Strain_f_n;
+  p.Strain_f_n1 = MPM_Mesh.Phi.Strain_f_n1;
   return p;
 }
 
@@ -140,7 +142,7 @@ int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Pa
   if (nlps_glue_lattice(G, &FEM_Mesh, &g) == EXIT_FAILURE) return EXIT_FAILURE;
   /* snapshot of the globals the level-A functions read implicitly (Globals.h:33-58) */
   nlps_params prm = {gamma_LME, TOL_zero_LME, TOL_wrapper_LME, max_iter_LME, TOL_Radial_Returning,
-                     Max_Iterations_Radial_Returning, Driver_EigenErosion ? 1 : 0};
+                     Max_Iterations_Radial_Returning, Driver_EigenErosion ? 1 : 0, Driver_EigenSoftening ? 1 : 0};
   const int Nmat = MPM_Mesh.NumberMaterials;
   nlps_material *mats = (nlps_material *)calloc((size_t)Nmat, sizeof(nlps_material));
   if (mats == NULL) return EXIT_FAILURE;
@@ -168,6 +170,9 @@ int nlps_glue_create(nlps_glue *G, Mesh FEM_Mesh, Particle MPM_Mesh, Time_Int_Pa
     mats[m].delta_voce = M->delta_Hardening_Voce;
     mats[m].Ceps = M->Ceps;
     mats[m].Gf = M->Gf;
+    mats[m].ft = M->ft;
+    mats[m].heps = M->heps;
+    mats[m].wcrit = M->wcrit;
     mats[m].cohesion = M->Cohesion;
     mats[m].alpha_borja = M->alpha_Hardening_Borja;
     for (int k = 0; k < 3; k++) mats[m].a_borja[k] = M->a_Hardening_Borja[k];

@@ -39,6 +39,7 @@ struct MatD {
   double kappa_0, exp_param, eps_0, p_ref;
   double H, theta, K_0, K_inf, delta;  // Von-Mises.c:246-253 (sigma_y = kappa_0)
   double Ceps, Gf;                     // eigenerosion (EigenErosion.c:63-64)
+  double ft, heps, wcrit;              // eigensoftening (EigenSoftening.c:67-69)
   // Matsuoka-Nakai (surface 0) / Lade-Duncan (surface 1): type = NLPS_KLAW_FRICTIONAL for both
   int surface;
   double c_cotphi, alpha_b, a_b[3];

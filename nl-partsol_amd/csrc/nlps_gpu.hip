@@ -56,8 +56,9 @@ enum {
   F_RHOJ = 89,
   F_CEP = 90,   // C_ep[ndim*ndim] (Drucker-Prager / Von-Mises tangent moduli, implicit driver only)
   F_DTFN = 99, F_DTFN1 = 108, F_DTDF = 117,  // rate tensors (level-B compatibility with dU_dt)
-  F_DMG = 126, F_DMG1 = 127,                 // Damage_n, Damage_n1 (eigenerosion, level B only)
-  NFD = 128
+  F_DMG = 126, F_DMG1 = 127,                 // Damage_n, Damage_n1 (eigenerosion / eigensoftening, level B only)
+  F_STRF = 128, F_STRF1 = 129,               // Strain_f_n, Strain_f_n1 (eigensoftening)
+  NFD = 130
 };
 
 struct PView {
@@ -75,7 +76,8 @@ struct PView {
   int* tile;  // tile of I0 (per-step binning)
   int* rank;  // arrival rank inside the tile
   int flip;   // 1: the n / n+1 slots of F and b_e are swapped (the explicit step rolls them by renaming)
-  int erosion;  // Driver_EigenErosion: the damage hooks of the level-B stages are on
+  int erosion;  // Driver_EigenErosion or Driver_EigenSoftening: the damage hooks of the level-B stages are on
+  int softening;  // ... with Eigensoftening__Constitutive__ (Driver_EigenSoftening and not Driver_EigenErosion)
 };
 #define PF(P, f, p) ((P).d[(size_t)(f) * (P).npad + (size_t)(p)])
 // first component of F_n, F_n+1, b_e,n, b_e,n+1 under the current renaming
@@ -607,6 +609,134 @@ __global__ __launch_bounds__(BLK) void k_damage(PView P, GridD g, const MatD* __
   for (int s = 0; s < T; s++) PF(P, F_TAU + s, p) = PF(P, F_TAU + s, p) * sc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Eigensoftening: the same hook with Driver_EigenSoftening -> Eigensoftening__Constitutive__
+// (EigenSoftening.c:27-163), restated AS WRITTEN: "first principal" value = eigval[0] of the ascending dsyev order (the
+// smallest, :60, :106); the neighbour loop ASSIGNS its term (no +=, :118); StrainF_n and StrainF_n1 are one array
+// (Constitutive.c:418-419).
+// The reference's loop runs one particle after the other and scales every Kirchhoff stress in place while later
+// particles still read it; two passes give the same numbers in parallel:
+//   pass 1 (per particle, no neighbour): the smallest principal Kirchhoff stress T0 of the UNSCALED stress, and the
+//           damage update of the second branch (:146-160), which reads the particle's own strain and history only;
+//   pass 2 (first branch, :71-144): mass sum over the epsilon-neighbourhood and the ONE neighbour term that survives the
+//           assignment of :118 -- the first particle of compute_Beps's walk (chain of NodalLocality_0[I0_p], inside a
+//           node descending particle index, Beps.c:49-70) with Damage_n < 1 -- whose stress counts scaled by
+//           (1 - Damage_n1) iff its index in the CALLER's order is below p's (it came earlier in the reference's loop);
+//           then every stress is scaled in place (U-Newmark-beta.c:1321-1330).
+// Lists: with this driver Beps is never initialised (U-Newmark-beta.c:182 tests Driver_EigenErosion only), a particle
+// whose total displacement is <= 1e-6 has an empty list (Beps.c:30-36), any other the list of its current position.
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__device__ __forceinline__ double almansi_min_principal(const double* F) {  // eulerian_almansi__Particles__ + eigval[0]
+  double b[ND * ND], bm1[ND * ND], e[ND * ND], w[3] = {0.0, 0.0, 0.0}, v[ND * ND];
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int j = 0; j < ND; j++) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < ND; k++) a += F[i * ND + k] * F[j * ND + k];
+      b[i * ND + j] = a;
+    }
+  inverse<ND>(bm1, b);
+#pragma unroll
+  for (int i = 0; i < ND; i++)
+#pragma unroll
+    for (int j = 0; j < ND; j++) e[i * ND + j] = 0.5 * ((i == j ? 1.0 : 0.0) - bm1[i * ND + j]);
+  sym_eigen<ND>(w, v, e);
+  return w[0];
+}
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_soften_pass1(PView P, const MatD* __restrict__ mats, double* __restrict__ T0) {
+  const int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  double tau[ND * ND], z, w[3] = {0.0, 0.0, 0.0}, v[ND * ND];
+  load_block<ND>(P, F_TAU, p, tau, z);
+  sym_eigen<ND>(w, v, tau);
+  T0[p] = w[0];
+  const double Dn = PF(P, F_DMG, p), sf = PF(P, F_STRF1, p);
+  if (Dn == 0.0 && w[0] > 0.0) return;  // first branch: pass 2
+  if (Dn != 1.0 && sf > 0.0) {          // :146-160
+    double F[ND * ND], fz;
+    load_block<ND>(P, fFN1(P), p, F, fz);
+    const MatD m = mats[P.mat[p]];
+    const double aux = (almansi_min_principal<ND>(F) - sf) * m.heps / m.wcrit;
+    const double mx = aux > Dn ? aux : Dn;
+    PF(P, F_DMG1, p) = 1.0 < mx ? 1.0 : mx;
+  }
+}
+template <int ND>
+__global__ __launch_bounds__(BLK) void k_soften_pass2(PView P, GridD g, const MatD* __restrict__ mats, const int* __restrict__ first,
+                                                      const int* __restrict__ last, const int* __restrict__ sorted,
+                                                      const uint8_t* __restrict__ rank1, const int* __restrict__ orig,
+                                                      const double* __restrict__ T0, double DeltaX) {
+  const int p = blockIdx.x * BLK + threadIdx.x;
+  if (p >= P.np) return;
+  constexpr int T = (ND == 2) ? 5 : 9;
+  const double Dn = PF(P, F_DMG, p), T0p = T0[p];
+  if (Dn == 0.0 && T0p > 0.0) {
+    const MatD m = mats[P.mat[p]];
+    const double m_p = PF(P, F_MASS, p);
+    double sum_m = m_p, term = m_p * T0p;
+    double xp[ND], d2p = 0.0;
+#pragma unroll
+    for (int a = 0; a < ND; a++) {
+      xp[a] = PF(P, F_X + a, p);
+      d2p += dsqr(PF(P, F_DIS + a, p));
+    }
+    if (sqrt(d2p) > 0.000001) {  // Beps.c:30-36 (lists are never initialised with this driver: empty otherwise)
+      const double eps = m.Ceps * DeltaX;
+      const int I0 = P.I0[p], op = orig[p];
+      int ijk[3] = {I0 % g.n[0], (I0 / g.n[0]) % g.n[1], I0 / (g.n[0] * g.n[1])};
+      const uint8_t* rk = rank1 + 27 * class3_of<ND>(g, ijk);
+      long long bestkey = 0x7fffffffffffffffll;
+      int bestq = -1;
+      for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
+        for (int dj = -1; dj <= 1; dj++)
+          for (int di = -1; di <= 1; di++) {
+            const int i = ijk[0] + di, j = ijk[1] + dj, k = ijk[2] + dk;
+            if (i < 0 || i >= g.n[0] || j < 0 || j >= g.n[1] || (ND == 3 && (k < 0 || k >= g.n[2]))) continue;
+            const int A = i + g.n[0] * (j + g.n[1] * k);
+            const long long nodekey = (long long)rk[(di + 1) + 3 * (dj + 1) + 9 * (dk + 1)] << 32;
+            for (int s = first[A]; s < last[A]; s++) {
+              const int q = sorted[s];
+              double d2 = 0.0;
+#pragma unroll
+              for (int a = 0; a < ND; a++) {
+                const double d = xp[a] - PF(P, F_X + a, q);
+                d2 += d * d;
+              }
+              if (sqrt(d2) <= eps) {  // q = p included, like the reference's list
+                sum_m += PF(P, F_MASS, q);
+                if (PF(P, F_DMG, q) < 1.0) {
+                  // the walk visits the nodes in chain order and a node's particles in descending caller index; the
+                  // reference's assignment keeps the FIRST such particle of the walk
+                  const long long key = nodekey + (long long)(0x7fffffff - orig[q]);
+                  if (key < bestkey) {
+                    bestkey = key;
+                    bestq = q;
+                  }
+                }
+              }
+            }
+          }
+      if (bestq >= 0) {
+        const double sc = (orig[bestq] < op) ? (1.0 - PF(P, F_DMG1, bestq)) : 1.0;  // scaled in place already, or not yet
+        term = PF(P, F_MASS, bestq) * (T0[bestq] * sc);
+      }
+    }
+    const double Teps = term / sum_m;
+    if (Teps > m.ft) {
+      double F[ND * ND], fz;
+      load_block<ND>(P, fFN1(P), p, F, fz);
+      PF(P, F_STRF1, p) = almansi_min_principal<ND>(F);
+    }
+  }
+  const double sc = 1.0 - PF(P, F_DMG1, p);  // kirchhoff_p[i] *= (1 - Damage_n1[p]), in place (:1321-1330)
+#pragma unroll
+  for (int s = 0; s < T; s++) PF(P, F_TAU + s, p) = PF(P, F_TAU + s, p) * sc;
+}
+
 // __constitutive_update (U-Newmark-beta.c:1208-1242)
 template <int ND, bool FRIC>
 __global__ __launch_bounds__(BLK) void k_stress(PView P, const MatD* __restrict__ mats, ParamsD prm,
@@ -693,6 +823,7 @@ __global__ __launch_bounds__(BLK) void k_roll(PView P) {
   PF(P, F_KN, p) = PF(P, F_KN1, p);
   PF(P, F_EN, p) = PF(P, F_EN1, p);
   if (P.erosion) PF(P, F_DMG, p) = PF(P, F_DMG1, p);  // U-Newmark-beta.c:1950-1953
+  if (P.softening) PF(P, F_STRF, p) = PF(P, F_STRF1, p);  // :1954-1956
   constexpr int T = (ND == 2) ? 5 : 9;
 #pragma unroll
   for (int s = 0; s < T; s++) {
@@ -1383,6 +1514,9 @@ static MatD make_mat(const nlps_material& m, int nd) {
   d.K_inf = m.Kinf_voce;
   d.delta = m.delta_voce;
   d.Ceps = m.Ceps;
+  d.ft = m.ft;
+  d.heps = m.heps;
+  d.wcrit = m.wcrit;
   d.Gf = m.Gf;
   if (m.type == NLPS_MAT_MATSUOKA_NAKAI || m.type == NLPS_MAT_LADE_DUNCAN) {  // one kernel law, two surfaces
     d.type = NLPS_KLAW_FRICTIONAL;
@@ -1640,7 +1774,8 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->prm.max_iter_lme = prm->max_iter_lme;
   h->prm.tol_radial = prm->tol_radial_returning;
   h->prm.max_iter_radial = prm->max_iter_radial_returning;
-  h->P.erosion = prm->driver_eigenerosion != 0;
+  h->P.erosion = prm->driver_eigenerosion != 0 || prm->driver_eigensoftening != 0;
+  h->P.softening = prm->driver_eigensoftening != 0 && prm->driver_eigenerosion == 0;
   if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
   if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
   if (const char* e = getenv("NLPS_FUSE_SEARCH")) h->fuse_search = atoi(e);
@@ -1839,6 +1974,8 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
     if (upload_field(h, F_BACK, 3, host->Back_stress, 3, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_DMG, 1, host->Damage_n, 1, tmp, nullptr, 0.0)) return 1;
     if (upload_field(h, F_DMG1, 1, host->Damage_n1 ? host->Damage_n1 : host->Damage_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_STRF, 1, host->Strain_f_n, 1, tmp, nullptr, 0.0)) return 1;
+    if (upload_field(h, F_STRF1, 1, host->Strain_f_n1 ? host->Strain_f_n1 : host->Strain_f_n, 1, tmp, nullptr, 0.0)) return 1;
     if (h->P.erosion) h->level_b_fields = true;  // the damage fields travel with the re-sort
     if (host->dt_F_n || host->dt_F_n1 || host->dt_DF) h->level_b_fields = true;
     if (host->dt_F_n && upload_field(h, F_DTFN, T, host->dt_F_n, T, tmp, nullptr, 0.0)) return 1;
@@ -2189,6 +2326,8 @@ extern "C" int nlps_gpu_download_state(nlps_gpu* h, nlps_particles* o) {
   if (download_field(h, F_BACK, 3, o->Back_stress, 3, tmp)) return 1;
   if (download_field(h, F_DMG, 1, o->Damage_n, 1, tmp)) return 1;
   if (download_field(h, F_DMG1, 1, o->Damage_n1, 1, tmp)) return 1;
+  if (download_field(h, F_STRF, 1, o->Strain_f_n, 1, tmp)) return 1;
+  if (download_field(h, F_STRF1, 1, o->Strain_f_n1, 1, tmp)) return 1;
   if (o->I0) {
     std::vector<int> it(np);
     HIPCHK(hipMemcpy(it.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
@@ -3220,7 +3359,14 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 32,
                                               h->stream));
     hipLaunchKernelGGL(k_node_ranges, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->skey2_d, h->dmg_first_d, h->dmg_last_d);
-    LAUNCH_ND((k_damage<2>), (k_damage<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->sval2_d, h->g.h);
+    if (h->P.softening) {
+      double* T0 = reinterpret_cast<double*>(h->gather_tmp);  // [npad] scratch of the re-sort, idle here
+      LAUNCH_ND((k_soften_pass1<2>), (k_soften_pass1<3>), nblk(np), h->P, h->mats_d, T0);
+      LAUNCH_ND((k_soften_pass2<2>), (k_soften_pass2<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->sval2_d,
+                (const uint8_t*)h->rank1_d, (const int*)h->perm_d, (const double*)T0, h->g.h);
+    } else {
+      LAUNCH_ND((k_damage<2>), (k_damage<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->sval2_d, h->g.h);
+    }
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));

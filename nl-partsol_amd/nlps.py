@@ -30,7 +30,8 @@ class Grid(C.Structure):
 class Params(C.Structure):
     _fields_ = [("gamma_lme", C.c_double), ("tol_zero_lme", C.c_double), ("tol_wrapper_lme", C.c_double),
                 ("max_iter_lme", C.c_int), ("tol_radial_returning", C.c_double),
-                ("max_iter_radial_returning", C.c_int), ("driver_eigenerosion", C.c_int)]
+                ("max_iter_radial_returning", C.c_int), ("driver_eigenerosion", C.c_int),
+                ("driver_eigensoftening", C.c_int)]
 
 
 class Material(C.Structure):
@@ -39,7 +40,8 @@ class Material(C.Structure):
                 ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
                 ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
                 ("delta_voce", C.c_double), ("Ceps", C.c_double), ("Gf", C.c_double),
-                ("cohesion", C.c_double), ("alpha_borja", C.c_double), ("a_borja", C.c_double * 3)]
+                ("cohesion", C.c_double), ("alpha_borja", C.c_double), ("a_borja", C.c_double * 3),
+                ("ft", C.c_double), ("heps", C.c_double), ("wcrit", C.c_double)]
 
 
 _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e_n1", "J_n", "J_n1", "rho",
@@ -49,7 +51,8 @@ _PD = ["x_GC", "dis", "vel", "acc", "F_n", "F_n1", "DF", "Stress", "b_e_n", "b_e
 class Particles(C.Structure):
     _fields_ = ([("np", C.c_int)] + [(k, _dp) for k in _PD] +
                 [("MatIdx", _ip), ("I0", _ip), ("lambda_", _dp), ("Beta", _dp), ("dt_F_n", _dp), ("dt_F_n1", _dp),
-                 ("dt_DF", _dp), ("C_ep", _dp), ("Back_stress", _dp), ("Damage_n", _dp), ("Damage_n1", _dp)])
+                 ("dt_DF", _dp), ("C_ep", _dp), ("Back_stress", _dp), ("Damage_n", _dp), ("Damage_n1", _dp),
+                 ("Strain_f_n", _dp), ("Strain_f_n1", _dp)])
 
 
 class Bcc(C.Structure):
@@ -157,7 +160,7 @@ def lib():
 
 
 def default_params():
-    return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10, 0)
+    return Params(3.0, 1e-6, 1e-10, 10, 1e-14, 10, 0, 0)
 
 
 def host_stencil_tables(ndim):
@@ -239,14 +242,15 @@ class Solver:
                                float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)),
                                float(m.get("Ceps", 0.0)), float(m.get("Gf", 0.0)), float(m.get("cohesion", 0.0)),
                                float(m.get("alpha_borja", 0.0)),
-                               (C.c_double * 3)(*[float(v) for v in m.get("a_borja", (0.0, 0.0, 0.0))]))
+                               (C.c_double * 3)(*[float(v) for v in m.get("a_borja", (0.0, 0.0, 0.0))]),
+                               float(m.get("ft", 0.0)), float(m.get("heps", 0.0)), float(m.get("wcrit", 1.0)))
         self._host = {}
         hp = Particles()
         hp.np = self.np
         keymap = {"x_GC": "x", "dis": "dis", "vel": "vel", "acc": "acc", "F_n": "F_n", "b_e_n": "b_e_n",
                   "J_n": "J_n", "rho": "rho", "mass": "mass", "Vol_0": "vol0", "Kappa_n": "kappa_n",
                   "EPS_n": "eps_n", "lambda_": "lambda", "Beta": "beta", "dt_F_n": "dt_F_n",
-                  "Back_stress": "back_stress", "Damage_n": "damage_n"}
+                  "Back_stress": "back_stress", "Damage_n": "damage_n", "Strain_f_n": "strain_f_n"}
         for ck, k in keymap.items():
             if k in cloud and cloud[k] is not None:
                 a = np.ascontiguousarray(cloud[k], dtype=np.float64)
@@ -367,7 +371,8 @@ class Solver:
              "Kappa_n": np.zeros(n), "Kappa_n1": np.zeros(n), "EPS_n": np.zeros(n), "EPS_n1": np.zeros(n),
              "lambda_": np.zeros((n, d)), "Beta": np.zeros(n), "dt_F_n": np.zeros((n, T)),
              "dt_F_n1": np.zeros((n, T)), "dt_DF": np.zeros((n, T)), "C_ep": np.zeros((n, d * d)),
-             "Back_stress": np.zeros((n, 3)), "Damage_n": np.zeros(n), "Damage_n1": np.zeros(n)}
+             "Back_stress": np.zeros((n, 3)), "Damage_n": np.zeros(n), "Damage_n1": np.zeros(n),
+             "Strain_f_n": np.zeros(n), "Strain_f_n1": np.zeros(n)}
         if fields is not None:
             alias = {"x": "x_GC", "lambda": "lambda_", "beta": "Beta"}
             want = {alias.get(k, k) for k in fields}

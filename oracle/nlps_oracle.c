@@ -1714,6 +1714,76 @@ int orc_eigenerosion_hook(double *damage_n1, const double *damage_n, orc_particl
   return STATUS;
 }
 
+/* The same hook with Driver_EigenSoftening: compute_damage__Constitutive__ (Constitutive.c:412-432) ->
+ * eulerian_almansi__Particles__ (compute-Strains.c:388-429: e = (I - b^-1) / 2, b = F_n1 F_n1^T) ->
+ * Eigensoftening__Constitutive__ (EigenSoftening.c:27-163), then the in-place scaling of U-Newmark-beta.c:1321-1330.
+ * Restated AS WRITTEN, one particle after the other like the reference at one thread:
+ *   - "first principal" = eigval[0] of the ascending dsyev order, i.e. the SMALLEST principal value (:60, :106);
+ *   - the neighbour loop ASSIGNS sum_m_x_T_ppal = m_q T_q (no +=, :118): what survives is the term of the LAST list
+ *     entry with Damage_n < 1 (chain order = reverse of the walk of compute_Beps, so: the first such particle of the
+ *     walk), or the particle's own term when there is none;
+ *   - Stress[q] is read while this very loop scales the stresses in place: a neighbour that came earlier in the loop
+ *     enters with its Kirchhoff stress already multiplied by (1 - Damage_n1[q]), a later one unscaled;
+ *   - StrainF_n and StrainF_n1 are the same array (Constitutive.c:418-419).
+ * Beps: with this driver the lists are never initialised (U-Newmark-beta.c:182 tests Driver_EigenErosion only) and
+ * compute_Beps (:213-215) only fills the list of a particle that has moved by more than 1e-6: the caller passes
+ * orc_compute_beps(..., initialize = 0) over lists that start empty. */
+int orc_eigensoftening_hook(double *damage_n1, const double *damage_n, double *strain_f_n1, orc_particles *P,
+                            const orc_material *mats, const int *beps_n, const int *beps, int stride) {
+  const int ndim = P->ndim, T = P->T;
+  int STATUS = 0;
+  for (int p = 0; p < P->np; p++) {
+    const orc_material *mat = &mats[P->matidx[p]];
+    double *Stress_p = &P->stress[p * T];
+    double eigval_stress_p[3] = {0.0, 0.0, 0.0}, eigval_stress_q[3], eigval_strain_p[3] = {0.0, 0.0, 0.0}, eigvec[9], blk[9];
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) blk[i * ndim + j] = Stress_p[i * ndim + j];
+    if (orc_sym_eigen(eigval_stress_p, eigvec, blk, ndim)) STATUS = 1;
+    if (ndim == 2) eigval_stress_p[2] = Stress_p[4];
+    /* eulerian_almansi__Particles__ on the d x d block of F_n1 */
+    double b[9], b_m1[9], Strain_p[9];
+    const double *F = &P->F_n1[p * T];
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) {
+        double v = 0.0;
+        for (int k = 0; k < ndim; k++) v += F[i * ndim + k] * F[j * ndim + k]; /* left_Cauchy_Green, compute-Strains.c:365-384 */
+        b[i * ndim + j] = v;
+      }
+    if (orc_inverse(b_m1, b, ndim)) STATUS = 1;
+    for (int i = 0; i < ndim; i++)
+      for (int j = 0; j < ndim; j++) Strain_p[i * ndim + j] = 0.5 * ((i == j ? 1.0 : 0.0) - b_m1[i * ndim + j]);
+    const double ft_p = mat->ft, heps_p = mat->heps, wcrit_p = mat->wcrit;
+    if ((damage_n[p] == 0.0) && (eigval_stress_p[0] > 0.0)) {
+      const double m_p = P->mass[p];
+      double sum_m = m_p, sum_m_x_T_ppal = m_p * eigval_stress_p[0];
+      for (int a = 0; a < beps_n[p]; a++) {
+        const int q = beps[(size_t)p * stride + a];
+        const double m_q = P->mass[q];
+        sum_m += m_q;
+        if (damage_n[q] < 1.0) {
+          const double *Stress_q = &P->stress[q * T];
+          for (int i = 0; i < ndim; i++)
+            for (int j = 0; j < ndim; j++) blk[i * ndim + j] = Stress_q[i * ndim + j];
+          if (orc_sym_eigen(eigval_stress_q, eigvec, blk, ndim)) STATUS = 1;
+          sum_m_x_T_ppal = m_q * eigval_stress_q[0];
+        }
+      }
+      const double Teps_p = sum_m_x_T_ppal / sum_m;
+      if (Teps_p > ft_p) {
+        if (orc_sym_eigen(eigval_strain_p, eigvec, Strain_p, ndim)) STATUS = 1;
+        strain_f_n1[p] = eigval_strain_p[0];
+      }
+    } else if ((damage_n[p] != 1.0) && (strain_f_n1[p] > 0)) {
+      if (orc_sym_eigen(eigval_strain_p, eigvec, Strain_p, ndim)) STATUS = 1;
+      const double aux = (eigval_strain_p[0] - strain_f_n1[p]) * heps_p / wcrit_p;
+      const double mx = aux > damage_n[p] ? aux : damage_n[p];
+      damage_n1[p] = 1.0 < mx ? 1.0 : mx; /* DMIN(1.0, DMAX(aux, Damage_n[p])) */
+    }
+    for (int i = 0; i < T; i++) Stress_p[i] *= (1.0 - damage_n1[p]);
+  }
+  return STATUS;
+}
+
 /* __nodal_internal_forces, U-Newmark-beta.c:1257-1374 + push_forward_dN__MeshTools__,
  * Shape-Functions.c:405-448 */
 int orc_internal_forces(double *R, const orc_particles *P, const orc_mesh *M, const int *nodes2mask,

@@ -80,6 +80,7 @@ typedef struct {
   double cohesion;              /* Cohesion */
   double alpha_borja;           /* alpha_Hardening_Borja */
   double a_borja[3];            /* a_Hardening_Borja */
+  double ft, heps, wcrit;       /* eigensoftening (Types.h:386-390): tensile strength, band width, critical opening */
 } orc_material;
 
 /* Globals snapshot: Globals.h:21,33-58; defaults InOutFun/Read_GramsShapeFun.c:100-104 */
@@ -159,6 +160,11 @@ int orc_compute_beps(int *beps_n, int *beps, int stride, const orc_particles *P,
 int orc_constitutive_eroded(orc_particles *P, const orc_material *mats, const orc_params *prm, const double *damage_n);
 int orc_eigenerosion_hook(double *damage_n1, const double *damage_n, orc_particles *P, const orc_material *mats,
                           const int *beps_n, const int *beps, int stride, double DeltaX);
+/* Eigensoftening (Constitutive/Fracture/EigenSoftening.c:27-163 behind compute_damage__Constitutive__,
+ * Constitutive.c:412-432): the same hook of __nodal_internal_forces with Driver_EigenSoftening.  strain_f_n1[np] is
+ * Phi.Strain_f_n1 (read and written: the reference passes it as both StrainF_n and StrainF_n1). */
+int orc_eigensoftening_hook(double *damage_n1, const double *damage_n, double *strain_f_n1, orc_particles *P,
+                            const orc_material *mats, const int *beps_n, const int *beps, int stride);
 void orc_set_tangent_damage(const double *damage_n1); /* NULL = off: orc_tangent_matrix scales by (1 - damage) */
 int orc_update_kinetics(double alpha_blend, const double *dU, const double *Un_dt,
                         const double *dU_dt, const double *dU_dt2, orc_particles *P,

@@ -43,7 +43,8 @@ class Material(C.Structure):
                 ("eps_0", C.c_double), ("p_ref", C.c_double), ("hardening_modulus", C.c_double),
                 ("theta_voce", C.c_double), ("K0_voce", C.c_double), ("Kinf_voce", C.c_double),
                 ("delta_voce", C.c_double), ("Ceps", C.c_double), ("Gf", C.c_double),
-                ("cohesion", C.c_double), ("alpha_borja", C.c_double), ("a_borja", C.c_double * 3)]
+                ("cohesion", C.c_double), ("alpha_borja", C.c_double), ("a_borja", C.c_double * 3),
+                ("ft", C.c_double), ("heps", C.c_double), ("wcrit", C.c_double)]
 
 
 class Params(C.Structure):
@@ -216,7 +217,8 @@ def make_materials(mats):
                           float(m.get("Kinf_voce", 0.0)), float(m.get("delta_voce", 0.0)),
                           float(m.get("Ceps", 0.0)), float(m.get("Gf", 0.0)), float(m.get("cohesion", 0.0)),
                                float(m.get("alpha_borja", 0.0)),
-                               (C.c_double * 3)(*[float(v) for v in m.get("a_borja", (0.0, 0.0, 0.0))]))
+                               (C.c_double * 3)(*[float(v) for v in m.get("a_borja", (0.0, 0.0, 0.0))]),
+                          float(m.get("ft", 0.0)), float(m.get("heps", 0.0)), float(m.get("wcrit", 1.0)))
     return arr
 
 
@@ -240,6 +242,12 @@ def eigenerosion_hook(damage_n1, damage_n, P, mats, beps, DeltaX):
     f = lib().orc_eigenerosion_hook
     f.argtypes = [_dp, _dp, C.POINTER(CParticles), C.POINTER(Material), _ip, _ip, C.c_int, C.c_double]
     return f(_d(damage_n1), _d(damage_n), C.byref(P.c), mats, _i(beps[0]), _i(beps[1]), BEPS_STRIDE, float(DeltaX))
+
+
+def eigensoftening_hook(damage_n1, damage_n, strain_f_n1, P, mats, beps):
+    f = lib().orc_eigensoftening_hook
+    f.restype = C.c_int
+    return f(_d(damage_n1), _d(damage_n), _d(strain_f_n1), C.byref(P.c), mats, _i(beps[0]), _i(beps[1]), BEPS_STRIDE)
 
 
 def set_tangent_damage(damage_n1):

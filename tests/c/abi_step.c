@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
   grid.ndim = d;
   for (int a = 0; a < 3; a++) grid.n[a] = hd[2 + a];
   grid.h = sc[0];
-  nlps_params prm = {3.0, 1e-6, 1e-10, 10, 1e-14, 10, 0}; /* Read_GramsShapeFun.c:100-104; no damage driver */
+  nlps_params prm = {3.0, 1e-6, 1e-10, 10, 1e-14, 10, 0, 0}; /* Read_GramsShapeFun.c:100-104; no damage driver */
   nlps_material mat;
   memset(&mat, 0, sizeof mat);
   mat.type = NLPS_MAT_NEO_HOOKEAN;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned seq) {
   const unsigned long long t0 = wall_clock64();
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
@@ -22,9 +23,34 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned seq, int mode) 
     if (mode != 3) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__global__ __launch_bounds__(256) void k(unsigned* q, unsigned* d2, unsigned* d3, unsigned seq, int n, int nstages, double* data,
-                                         int* status, int mode) {
+struct Big {
+  unsigned* q;
+  unsigned* d2;
+  unsigned* d3;
+  unsigned seq;
+  int n, nstages;
+  double pad[40];
+  int mode;
+};
+__device__ __noinline__ int use_big(const Big* b) { return b->n + (int)b->pad[7]; }
+#ifndef VAR
+#define VAR 0
+#endif
+__global__ __launch_bounds__(256, 3) void k(unsigned* q, unsigned* d2, unsigned* d3, unsigned seq, int n, int nstages, double* data,
+                                         int* status, int mode, Big big) {
   __shared__ int s_item;
+#if VAR >= 1
+  __shared__ double sh[4044];
+  for (int i = threadIdx.x; i < 4044; i += 256) sh[i] = (double)i;
+  __syncthreads();
+  if (sh[threadIdx.x] < -1.0) atomicOr(status, 2);
+#endif
+#if VAR >= 2
+  n = use_big(&big);
+  q = big.q;
+  d2 = big.d2;
+  d3 = big.d3;
+#endif
   while (true) {
     if (threadIdx.x == 0) s_item = (int)atomicAdd(q, 1u);
     __syncthreads();
@@ -61,6 +87,9 @@ int main(int argc, char** argv) {
   hipMemset(d, 0, 2 * n * sizeof(unsigned));
   hipMemset(data, 0, n * 64 * sizeof(double));
   hipMemset(st, 0, 4);
+  Big big;
+  memset(&big, 0, sizeof big);
+  big.q = q; big.d2 = d; big.d3 = d + n; big.n = n;
   for (int ns = 1; ns <= (mode ? 1 : 3); ns++)
     for (unsigned seq = 1; seq <= 3; seq++) {
       hipMemset(q, 0, 4);
@@ -68,7 +97,7 @@ int main(int argc, char** argv) {
       hipEventCreate(&a);
       hipEventCreate(&b);
       hipEventRecord(a);
-      hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, q, d, d + n, seq + 10 * ns, n, ns, data, st, mode);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, q, d, d + n, seq + 10 * ns, n, ns, data, st, mode, big);
       hipEventRecord(b);
       hipError_t e = hipDeviceSynchronize();
       float ms = 0;
