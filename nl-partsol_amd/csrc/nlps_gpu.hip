@@ -58,7 +58,11 @@ enum {
   F_DTFN = 99, F_DTFN1 = 108, F_DTDF = 117,  // rate tensors (level-B compatibility with dU_dt)
   F_DMG = 126, F_DMG1 = 127,                 // Damage_n, Damage_n1 (eigenerosion / eigensoftening, level B only)
   F_STRF = 128, F_STRF1 = 129,               // Strain_f_n, Strain_f_n1 (eigensoftening)
-  NFD = 130
+  // eigenerosion: position and closest node of every particle when the epsilon-neighbourhoods were initialised
+  // (compute_Beps__Constitutive__(.., true), U-Newmark-beta.c:182-183): what the FROZEN list of a particle that has
+  // not moved since is made of (Beps.c:30-36).  The closest node travels as a double like any other field.
+  F_X0 = 130, F_I00 = 133,
+  NFD = 134
 };
 
 struct PView {
@@ -543,8 +547,10 @@ __device__ __forceinline__ bool force_operator(double* B, const double* tau, con
 // The epsilon-neighbourhood Beps[p] (Beps.c:16-80: particles q whose closest node lies in the 1-ring of I0_p, within
 // Ceps * DeltaX of p) is not stored: the particles are sorted by closest node once per call (first/last = the run of
 // every node in `sorted`) and every particle walks the <= 3^d runs around its own closest node.  x_GC does not change
-// between the search and the force stage, so this is the list the reference built after its search -- except for
-// particles that have not moved by more than 1e-6 since the start, whose list the reference freezes (Beps.c:30-36).
+// between the search and the force stage, so this is the list the reference built after its search.  A particle that
+// has not moved by more than 1e-6 since the start keeps the list of the initialisation (Beps.c:30-36): it walks the
+// same runs of the SNAPSHOT taken before the first search (positions and closest nodes of Initialize_Beps = true,
+// fields F_X0 / F_I00, tables first0 / last0 / sorted0) -- the same members, wherever they have moved since.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_node_ranges(int np, const unsigned long long* __restrict__ keys, int* __restrict__ first,
                               int* __restrict__ last) {
@@ -555,10 +561,25 @@ __global__ void k_node_ranges(int np, const unsigned long long* __restrict__ key
   if (i == np - 1 || keys[i + 1] != k) last[k] = i + 1;
 }
 
+__global__ void k_beps_snapshot(PView P, int ND) {  // Initialize_Beps = true: the configuration the frozen lists belong to
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.np) return;
+  for (int a = 0; a < ND; a++) PF(P, F_X0 + a, p) = PF(P, F_X + a, p);
+  PF(P, F_I00, p) = (double)P.I0[p];
+}
+__global__ void k_beps_keys0(PView P, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P.np) return;
+  keys[p] = (unsigned long long)(long long)PF(P, F_I00, p);
+  vals[p] = p;
+}
+
+// first0 / last0 / sorted0: the same tables for the closest nodes of the snapshot (nullptr: no frozen lists)
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_damage(PView P, GridD g, const MatD* __restrict__ mats, const int* __restrict__ first,
                                                 const int* __restrict__ last, const int* __restrict__ sorted,
-                                                double DeltaX) {
+                                                const int* __restrict__ first0, const int* __restrict__ last0,
+                                                const int* __restrict__ sorted0, double DeltaX) {
   const int p = blockIdx.x * BLK + threadIdx.x;
   if (p >= P.np) return;
   constexpr int T = (ND == 2) ? 5 : 9;
@@ -570,12 +591,23 @@ __global__ __launch_bounds__(BLK) void k_damage(PView P, GridD g, const MatD* __
   if (Dn < 1.0 && w[0] > 0.0) {
     const MatD m = mats[P.mat[p]];
     const double eps = m.Ceps * DeltaX;
-    double xp[ND];
+    // a particle whose total displacement is <= 1e-6 keeps the list it had (Beps.c:30-36): the one of the snapshot,
+    // i.e. the particles around its closest node THEN that were within eps of it THEN -- wherever they are now
+    double xp[ND], d2p = 0.0;
 #pragma unroll
-    for (int a = 0; a < ND; a++) xp[a] = PF(P, F_X + a, p);
+    for (int a = 0; a < ND; a++) d2p += dsqr(PF(P, F_DIS + a, p));
+    const bool frozen = first0 && !(sqrt(d2p) > 0.000001);
+    const int fx = frozen ? F_X0 : F_X;
+    if (frozen) {
+      first = first0;
+      last = last0;
+      sorted = sorted0;
+    }
+#pragma unroll
+    for (int a = 0; a < ND; a++) xp[a] = PF(P, fx + a, p);
     const double V_p = PF(P, F_VOL0, p) * PF(P, F_JN1, p);
     double sum_V = V_p, sum_VW = V_p * PF(P, F_W, p);
-    const int I0 = P.I0[p];
+    const int I0 = frozen ? (int)PF(P, F_I00, p) : P.I0[p];
     const int i0 = I0 % g.n[0], j0 = (I0 / g.n[0]) % g.n[1], k0 = I0 / (g.n[0] * g.n[1]);
     for (int dk = (ND == 3 ? -1 : 0); dk <= (ND == 3 ? 1 : 0); dk++)
       for (int dj = -1; dj <= 1; dj++)
@@ -588,7 +620,7 @@ __global__ __launch_bounds__(BLK) void k_damage(PView P, GridD g, const MatD* __
             double d2 = 0.0;
 #pragma unroll
             for (int a = 0; a < ND; a++) {
-              const double d = xp[a] - PF(P, F_X + a, q);
+              const double d = xp[a] - PF(P, fx + a, q);
               d2 += d * d;
             }
             if (sqrt(d2) <= eps) {  // q = p included, like the reference's list
@@ -1419,6 +1451,8 @@ struct nlps_gpu {
   int adaptive_min_steps = 4;
   int* nwork_d = nullptr;   // ranges[3 classes][2 splits][begin,end] of the work lists (tile_scan_block)
   int *dmg_first_d = nullptr, *dmg_last_d = nullptr;  // eigenerosion: run of every node in the I0-sorted particle list
+  int *dmg_first0_d = nullptr, *dmg_last0_d = nullptr, *dmg_sorted0_d = nullptr;  // the same for the snapshot's closest nodes
+  bool beps_snapshot = false;  // F_X0 / F_I00 hold the configuration of Initialize_Beps = true
   double* slab_d = nullptr; // P2G window slabs [ntiles][K2_SPLIT][1+ND][NW] (TileD::slab), deterministic mode only
   bool deterministic = false;
   // canonical (layer, closest node) order of every tile list each step (k_tile_order) for the LDS-atomic-bound K2 and
@@ -2263,7 +2297,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->fused_q_d, h->fused_done_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->fused_q_d, h->fused_done_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->dmg_first0_d, h->dmg_last0_d, h->dmg_sorted0_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -3145,7 +3179,18 @@ extern "C" int nlps_gpu_initialize_lme(nlps_gpu* h) {
   return check_status(h, ST_NEWTON | ST_CONNECT | ST_HALO, "initialize__LME__()");
 }
 
+// Driver_EigenErosion: compute_Beps__Constitutive__(.., true) runs once before the first step (U-Newmark-beta.c:182-183);
+// what it sees -- positions and closest nodes -- is kept for the lists that stay frozen afterwards
+static int beps_snapshot(nlps_gpu* h) {
+  if (h->beps_snapshot || !h->P.erosion || h->P.softening || h->P.np == 0) return 0;
+  hipLaunchKernelGGL(k_beps_snapshot, dim3(nblk(h->P.np)), dim3(BLK), 0, h->stream, h->P, h->nd);
+  HIPCHK(hipGetLastError());
+  h->beps_snapshot = true;
+  return 0;
+}
+
 extern "C" int nlps_gpu_local_search(nlps_gpu* h) {
+  if (beps_snapshot(h)) return 1;  // (before this search moves any closest node)
   if (search_and_lists(h, false, false, 0.0, 0.0)) return 1;
   if (compute_node_mask(h)) return 1;
   return check_status(h, ST_NEWTON | ST_CONNECT | ST_HALO, "local_search__LME__()");
@@ -3365,7 +3410,25 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
       LAUNCH_ND((k_soften_pass2<2>), (k_soften_pass2<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->sval2_d,
                 (const uint8_t*)h->rank1_d, (const int*)h->perm_d, (const double*)T0, h->g.h);
     } else {
-      LAUNCH_ND((k_damage<2>), (k_damage<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->sval2_d, h->g.h);
+      // frozen lists (Beps.c:30-36): the node tables of the snapshot's closest nodes, rebuilt per call like the others
+      if (beps_snapshot(h)) return 1;
+      if (!h->dmg_first0_d) {
+        HIPCHK(hipMalloc((void**)&h->dmg_first0_d, nn * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->dmg_last0_d, nn * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&h->dmg_sorted0_d, h->P.npad * sizeof(int)));
+      }
+      std::swap(h->dmg_sorted0_d, h->sval2_d);  // dmg_sorted0_d: the CURRENT order just sorted; sval2_d: free for the next sort
+      HIPCHK(hipMemsetAsync(h->dmg_first0_d, 0, nn * sizeof(int), h->stream));
+      HIPCHK(hipMemsetAsync(h->dmg_last0_d, 0, nn * sizeof(int), h->stream));
+      hipLaunchKernelGGL(k_beps_keys0, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->skey_d, h->sval_d);
+      bytes = h->cub_tmp_bytes;
+      HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 32,
+                                                h->stream));
+      hipLaunchKernelGGL(k_node_ranges, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->skey2_d, h->dmg_first0_d, h->dmg_last0_d);
+      // (current order in dmg_sorted0_d, snapshot order in sval2_d)
+      LAUNCH_ND((k_damage<2>), (k_damage<3>), nblk(np), h->P, h->g, h->mats_d, h->dmg_first_d, h->dmg_last_d, h->dmg_sorted0_d,
+                h->dmg_first0_d, h->dmg_last0_d, h->sval2_d, h->g.h);
+      std::swap(h->dmg_sorted0_d, h->sval2_d);  // the sort buffers go back to where the re-sort expects them
     }
     HIPCHK(hipGetLastError());
   }
