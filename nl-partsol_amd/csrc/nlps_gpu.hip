@@ -14,6 +14,8 @@
 // closest nodes with the tile's node window in LDS (nlps_tile_kernels.hpp); this file holds the search, the
 // nodal kernels, the per-particle level-B kernels and the C-ABI host code.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
+#include <thread>
 #include <hipcub/hipcub.hpp>
 
 #include <dlfcn.h>
@@ -1390,6 +1392,7 @@ struct nlps_gpu {
   // in 0.1 ms): unfinished, kept behind the developer switch NLPS_FUSED_STEP=1 ("k_step_fused")
   int fused_step = 0;
   unsigned* fused_q_d = nullptr;
+  struct FusedArgs* fused_args_d = nullptr;
   unsigned* fused_done_d = nullptr;  // [2][ntiles]
   unsigned fused_seq = 0;
   int ncu = 256;
@@ -2297,7 +2300,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->fused_q_d, h->fused_done_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->dmg_first0_d, h->dmg_last0_d, h->dmg_sorted0_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->fused_q_d, h->fused_args_d, h->fused_done_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->dmg_first0_d, h->dmg_last0_d, h->dmg_sorted0_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -3826,8 +3829,6 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     fs.seq = h->fused_seq;
     fs.nstages = 3;
     if (const char* e = getenv("NLPS_FUSED_STAGES")) fs.nstages = atoi(e);
-    fs.debug = 0;
-    if (const char* e = getenv("NLPS_FUSED_DEBUG")) fs.debug = atoi(e);
     fs.bc.n = nbcc;
     for (int i = 0; i < nbcc; i++) {
       fs.bc.dim[i] = bcc[i].dim;
@@ -3841,9 +3842,45 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     ksf.bin = 1;
     ksf.tc = tile_cnt(h, true);
     ksf.tc.count = h->tile_count2_d;
-    const TileD tdf = tile_view(h, 0);
-    hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(3 * h->ncu), dim3(BLK), 0, h->stream, h->P, h->g, h->N, tdf,
-                       h->mats_d, h->prm, dt, gamma_nm, h->gstatus_d, ksf, fs);
+    int fgrid = 3 * h->ncu;
+    if (const char* e = getenv("NLPS_FUSED_GRID")) fgrid = atoi(e);
+    fs.trace = nullptr;
+    static int* trace_h = nullptr;
+    if (getenv("NLPS_FUSED_TRACE")) {
+      if (!trace_h) HIPCHK(hipHostMalloc((void**)&trace_h, 8 * sizeof(int) * 1024, hipHostMallocCoherent));
+      memset(trace_h, 0xff, 8 * sizeof(int) * 1024);
+      fs.trace = trace_h;
+    }
+    FusedArgs fa;
+    fa.P = h->P;
+    fa.g = h->g;
+    fa.N = h->N;
+    fa.td = tile_view(h, 0);
+    fa.mats = h->mats_d;
+    fa.prm = h->prm;
+    fa.dt = dt;
+    fa.gamma_nm = gamma_nm;
+    fa.gstatus = h->gstatus_d;
+    fa.ks = ksf;
+    fa.fs = fs;
+    if (!h->fused_args_d) HIPCHK(hipMalloc((void**)&h->fused_args_d, sizeof(FusedArgs)));
+    HIPCHK(hipMemcpyAsync(h->fused_args_d, &fa, sizeof fa, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // (fa lives on this stack frame; a pinned staging block would avoid the wait)
+    hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(fgrid), dim3(BLK), 0, h->stream,
+                       (const FusedArgs*)h->fused_args_d);
+    if (fs.trace) {
+      const int nb = std::min(fgrid, 1024);
+      int* tr = trace_h;
+      auto dump = [nb, tr]() {
+        usleep(3000000);
+        for (int b = 0; b < nb; b++)
+          if (tr[8 * b + 4] != 5 || tr[8 * b + 5] != 5 || tr[8 * b + 6] != 5 || tr[8 * b + 7] != 5)
+            fprintf(stderr, "wg %d item %d marks %d %d %d %d\n", b, tr[8 * b], tr[8 * b + 4], tr[8 * b + 5], tr[8 * b + 6], tr[8 * b + 7]);
+        fprintf(stderr, "trace dumped\n");
+      };
+      if (atoi(getenv("NLPS_FUSED_TRACE")) == 2) std::thread(dump).detach();  // 2: the caller goes on (the first step only makes sense)
+      else dump();
+    }
     HIPCHK(hipGetLastError());
     if (h->timing) {
       HIPCHK(hipEventRecord(h->ev[4], h->stream));

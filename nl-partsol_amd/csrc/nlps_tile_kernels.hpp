@@ -567,7 +567,7 @@ struct FusedStep {
   unsigned* done3;       // the same for the force flush of K3
   unsigned seq;          // this step's number (never 0)
   int nstages;           // 3; developer switch NLPS_FUSED_STAGES runs the first stages only
-  int debug;
+  int* trace;            // developer switch NLPS_FUSED_TRACE: host-visible progress marks, 8 ints per workgroup
   const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
   BcStep bc;             // their components and values at this step
   double gv[3];          // gravity
@@ -1727,10 +1727,58 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
 // ------------------------------------------------------------------------------------------------
 // k_step_fused: K2, K3 and K5 of the explicit step as ONE launch of persistent workgroups (see FusedStep)
 // ------------------------------------------------------------------------------------------------
+// (the three stages are real function calls: inlined into one body the persistent loop became a lane-masked loop nest of
+// ten thousand instructions)
+#ifndef NLPS_FUSED_CALLS
+#define NLPS_FUSED_CALLS 1
+#endif
+#if NLPS_FUSED_CALLS
+#define FUSED_STAGE __device__ __noinline__
+#else
+#define FUSED_STAGE __device__ __forceinline__
+#endif
+struct FusedArgs {
+  PView P;
+  GridD g;
+  NView N;
+  TileD td;
+  const MatD* mats;
+  ParamsD prm;
+  double dt, gamma_nm;
+  int* gstatus;
+  K5Search ks;
+  FusedStep fs;
+};
+template <int ND>
+FUSED_STAGE void fused_stage_k2(const FusedArgs* a, int wb, int tile, double* sh) {
+  constexpr int NWA = TileCfg<ND>::NWA;
+  TileWork tw{tile, 0, 1, wb};
+  k2_body<ND, true, BLK>(a->P, a->g, a->N, a->td, a->prm, a->dt, a->gamma_nm, a->gstatus, tw, 0, sh,
+                         reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA), &a->fs);
+}
 template <int ND, int LAW>
-__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
-                                                                                 ParamsD prm, double dt, double gamma_nm,
-                                                                                 int* __restrict__ gstatus, K5Search ks, FusedStep fs) {
+FUSED_STAGE void fused_stage_k3(const FusedArgs* a, int wb, int tile, double* sh) {
+  using L3 = K3Lds<ND, 1, false>;
+  constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA;
+  TileWork tw{tile, 0, 1, wb};
+  double* duxy = sh;  // 16-byte aligned (NW is even)
+  double* duz = duxy + 2 * NW;
+  double* fac = duz + L3::N_DUZ;
+  double* dvxy = fac + ND * NWA;  // MODE 1 has no rate windows: two placeholders each
+  double* dvz = dvxy + 2;
+  int* ints = reinterpret_cast<int*>(dvz + 2);
+  const L3 lds{dvxy, dvz, duxy, duz, fac, ints, ints + 2, ints + 4};
+  k3_body<ND, LAW, 1, false, BLK>(a->P, a->g, a->N, a->td, a->mats, a->prm, a->gstatus, nullptr, tw, 0, lds, &a->fs);
+}
+template <int ND, int LAW>
+FUSED_STAGE void fused_stage_k5(const FusedArgs* a, int wb, int tile, double* sh) {
+  constexpr int NW = TileCfg<ND>::NW;
+  TileWork tw{tile, 0, 1, wb};
+  k5_body<ND, (LAW == NLPS_MAT_NEO_HOOKEAN || LAW == NLPS_MAT_HENCKY) ? 0 : 2, true>(a->P, a->g, a->N, a->td, a->dt, a->gamma_nm,
+                                                                                     a->ks, tw, sh, sh + 2 * NW, &a->fs, a->gstatus);
+}
+template <int ND, int LAW>
+__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(const FusedArgs* __restrict__ args) {
   static_assert(K3_BLK == BLK && K5_BLK == BLK && K2_SPLIT == 1 && K3_SPLIT == 1 && K5_SPLIT == 1, "one work list, one block size");
   using L3 = K3Lds<ND, 1, false>;
   constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA, NROWS = WinRows<ND>::NROWS;
@@ -1741,48 +1789,35 @@ __global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fuse
   constexpr int NSH = (N2 > N3 ? (N2 > N5 ? N2 : N5) : (N3 > N5 ? N3 : N5));
   __shared__ __attribute__((aligned(16))) double sh[NSH];
   __shared__ int s_item;
+  const TileD& td = args->td;
+  const FusedStep& fs = args->fs;
   const int w_lo = td.range[0], nwork = td.range[1] - td.range[0];
+  const int total = fs.nstages * nwork;
   while (true) {
+#define FTRACE(k, v)                                                                                         \
+  if (fs.trace && (threadIdx.x & 63) == 0)                                                                   \
+    __hip_atomic_store(fs.trace + 8 * (size_t)blockIdx.x + (k) + (k >= 4 ? (threadIdx.x >> 6) : 0), (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (threadIdx.x == 0) s_item = (int)atomicAdd(fs.q_head, 1u);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(s_item);  // wave-uniform by construction: scalar branches below
     __syncthreads();  // (s_item is rewritten at the top of the next trip; the stage bodies re-initialise their LDS)
-    if (item >= fs.nstages * nwork) break;
+    FTRACE(0, item) FTRACE(4, 1)
+    if (item >= total) break;
     const int stage = item / nwork;
-    TileWork tw;
-    tw.wb = w_lo + (item - stage * nwork);
-    const int2 wk = td.work[0][tw.wb];
-    tw.tile = wk.x;
-    tw.part = 0;
-    tw.nparts = 1;
-    if (fs.debug == 1) continue;
+    const int wb = w_lo + (item - stage * nwork);
+    const int tile = td.work[0][wb].x;
     // a tile of a later stage reads nodal sums of its window: the flushes of the tiles around it must have landed
-    if (stage == 1 && fs.debug != 7 && fs.debug < 10) fused_wait_neighbours<ND>(td, tw.tile, fs.done2, fs.seq, gstatus);
-    if (stage == 2 && fs.debug != 7) fused_wait_neighbours<ND>(td, tw.tile, fs.done3, fs.seq, gstatus);
-    if (stage == 0) {
-      double* acc = sh;
-      unsigned* actrow = reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA);
-      k2_body<ND, true, BLK>(P, g, N, td, prm, dt, gamma_nm, gstatus, tw, 0, acc, actrow, &fs);
-    } else if (stage == 1 && fs.debug >= 9) {
-      // (developer: the stage without its body)
-    } else if (stage == 1) {
-      double* duxy = sh;                       // 16-byte aligned (NW is even)
-      double* duz = duxy + 2 * NW;
-      double* fac = duz + L3::N_DUZ;
-      double* dvxy = fac + ND * NWA;           // MODE 1 has no rate windows: two placeholders each
-      double* dvz = dvxy + 2;
-      int* ints = reinterpret_cast<int*>(dvz + 2);
-      const L3 lds{dvxy, dvz, duxy, duz, fac, ints, ints + 2, ints + 4};
-      k3_body<ND, LAW, 1, false, BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, 0, lds, &fs);
-    } else {
-      double* axy = sh;
-      double* az = axy + 2 * NW;
-      k5_body<ND, (LAW == NLPS_MAT_NEO_HOOKEAN || LAW == NLPS_MAT_HENCKY) ? 0 : 2, true>(P, g, N, td, dt, gamma_nm, ks, tw, axy, az, &fs, gstatus);
-    }
-    if (fs.debug == 11 && stage == 1) {
-      __syncthreads();
-    } else if (stage < 2 && fs.debug != 8) fused_publish((stage == 0 || fs.debug == 10 ? fs.done2 : fs.done3) + tw.tile, fs.seq);
+    if (stage == 1) fused_wait_neighbours<ND>(td, tile, fs.done2, fs.seq, args->gstatus);
+    if (stage == 2) fused_wait_neighbours<ND>(td, tile, fs.done3, fs.seq, args->gstatus);
+    FTRACE(4, 2)
+    if (stage == 0) fused_stage_k2<ND>(args, wb, tile, sh);
+    else if (stage == 1) fused_stage_k3<ND, LAW>(args, wb, tile, sh);
+    else fused_stage_k5<ND, LAW>(args, wb, tile, sh);
+    FTRACE(4, 3)
+    if (stage < 2) fused_publish((stage == 0 ? fs.done2 : fs.done3) + tile, fs.seq);
+    FTRACE(4, 4)
   }
+  FTRACE(4, 5)
 }
 
 // ------------------------------------------------------------------------------------------------
