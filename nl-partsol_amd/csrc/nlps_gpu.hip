@@ -3845,11 +3845,24 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     int fgrid = 3 * h->ncu;
     if (const char* e = getenv("NLPS_FUSED_GRID")) fgrid = atoi(e);
     fs.trace = nullptr;
+    fs.nofence = 0;
+    if (const char* e = getenv("NLPS_FUSED_NOFENCE")) fs.nofence = atoi(e);
     static int* trace_h = nullptr;
     if (getenv("NLPS_FUSED_TRACE")) {
-      if (!trace_h) HIPCHK(hipHostMalloc((void**)&trace_h, 8 * sizeof(int) * 1024, hipHostMallocCoherent));
+      if (!trace_h) {
+        HIPCHK(hipHostMalloc((void**)&trace_h, 8 * sizeof(int) * 1024 + 128, hipHostMallocCoherent));
+        memset(trace_h + 8 * 1024, 0, 128);
+      }
       memset(trace_h, 0xff, 8 * sizeof(int) * 1024);
       fs.trace = trace_h;
+      static int* trace_d = nullptr;  // 3: per-stage times only, in device memory (host-memory atomics distort them)
+      if (atoi(getenv("NLPS_FUSED_TRACE")) == 3) {
+        if (!trace_d) {
+          HIPCHK(hipMalloc((void**)&trace_d, 8 * sizeof(int) * 1024 + 128));
+          HIPCHK(hipMemsetAsync(trace_d, 0, 8 * sizeof(int) * 1024 + 128, h->stream));
+        }
+        fs.trace = trace_d;
+      }
     }
     FusedArgs fa;
     fa.P = h->P;
@@ -3863,11 +3876,15 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     fa.gstatus = h->gstatus_d;
     fa.ks = ksf;
     fa.fs = fs;
+#if NLPS_FUSED_BYVAL
+    hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(fgrid), dim3(BLK), 0, h->stream, fa);
+#else
     if (!h->fused_args_d) HIPCHK(hipMalloc((void**)&h->fused_args_d, sizeof(FusedArgs)));
     HIPCHK(hipMemcpyAsync(h->fused_args_d, &fa, sizeof fa, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // (fa lives on this stack frame; a pinned staging block would avoid the wait)
     hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(fgrid), dim3(BLK), 0, h->stream,
                        (const FusedArgs*)h->fused_args_d);
+#endif
     if (fs.trace) {
       const int nb = std::min(fgrid, 1024);
       int* tr = trace_h;
@@ -3878,8 +3895,15 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
             fprintf(stderr, "wg %d item %d marks %d %d %d %d\n", b, tr[8 * b], tr[8 * b + 4], tr[8 * b + 5], tr[8 * b + 6], tr[8 * b + 7]);
         fprintf(stderr, "trace dumped\n");
       };
-      if (atoi(getenv("NLPS_FUSED_TRACE")) == 2) std::thread(dump).detach();  // 2: the caller goes on (the first step only makes sense)
-      else dump();
+      const int tmode = atoi(getenv("NLPS_FUSED_TRACE"));
+      if (tmode == 2) std::thread(dump).detach();  // 2: the caller goes on (the first step only makes sense)
+      else if (tmode == 1) dump();
+      else {  // 3: workgroup time per stage, summed over the steps so far
+        HIPCHK(hipMemcpyAsync(trace_h + 8 * 1024, fs.trace + 8 * 1024, 128, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const unsigned long long* a = reinterpret_cast<const unsigned long long*>(trace_h + 8 * 1024);
+        fprintf(stderr, "fused ticks wait %llu %llu %llu body %llu %llu %llu publish %llu %llu %llu\n", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]);
+      }
     }
     HIPCHK(hipGetLastError());
     if (h->timing) {

@@ -568,6 +568,7 @@ struct FusedStep {
   unsigned seq;          // this step's number (never 0)
   int nstages;           // 3; developer switch NLPS_FUSED_STAGES runs the first stages only
   int* trace;            // developer switch NLPS_FUSED_TRACE: host-visible progress marks, 8 ints per workgroup
+  int nofence;           // developer switch NLPS_FUSED_NOFENCE (timing experiments): 1 no release, 2 no acquire
   const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
   BcStep bc;             // their components and values at this step
   double gv[3];          // gravity
@@ -587,7 +588,7 @@ __device__ __forceinline__ bool fused_wait(const unsigned* flag, unsigned seq) {
 // the workgroup barrier; the window loads that follow bypass L1 anyway, coherent_load)
 template <int ND>
 __device__ __forceinline__ void fused_wait_neighbours(const TileD& td, int tile, const unsigned* done, unsigned seq,
-                                                      int* __restrict__ gstatus) {
+                                                      int* __restrict__ gstatus, int nofence) {
   const int t = threadIdx.x;
   if (t < 64) {
     if (t < (ND == 3 ? 27 : 9)) {
@@ -599,17 +600,17 @@ __device__ __forceinline__ void fused_wait_neighbours(const TileD& td, int tile,
           if (!fused_wait(done + nb, seq)) atomicOr(gstatus, 32);  // ST_SYNC: reported, never a hang
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!(nofence & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
 }
 // after a window flush: every wave drains its atomics, the workgroup meets, one lane releases at agent scope
-__device__ __forceinline__ void fused_publish(unsigned* flag, unsigned seq) {
+__device__ __forceinline__ void fused_publish(unsigned* flag, unsigned seq, int nofence) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!(nofence & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1730,7 +1731,10 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
 // (the three stages are real function calls: inlined into one body the persistent loop became a lane-masked loop nest of
 // ten thousand instructions)
 #ifndef NLPS_FUSED_CALLS
-#define NLPS_FUSED_CALLS 1
+#define NLPS_FUSED_CALLS 0
+#endif
+#ifndef NLPS_FUSED_BYVAL
+#define NLPS_FUSED_BYVAL 1
 #endif
 #if NLPS_FUSED_CALLS
 #define FUSED_STAGE __device__ __noinline__
@@ -1749,12 +1753,72 @@ struct FusedArgs {
   K5Search ks;
   FusedStep fs;
 };
+// NLPS_FUSED_BYVAL 0: the argument block sits in device memory and every trip of the persistent loop reads what its
+// stage needs through constant-address-space loads (scalar, invariant) behind a pointer the optimiser cannot see through:
+// nothing of one stage stays in registers while another runs.  (As a kernel argument -- BYVAL 1 -- the whole block and
+// what the three stages derive from it is hoisted to the kernel entry and spilled: 338 v_writelane, 1083 v_readlane.)
+template <class T>
+__device__ __forceinline__ T load_const(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dwords");
+  constexpr int n = sizeof(T) / 4;
+  typedef const __attribute__((address_space(4))) unsigned* cptr;
+  cptr c = (cptr)(reinterpret_cast<const unsigned*>(p));
+  unsigned w[n];
+#pragma unroll
+  for (int i = 0; i < n; i++) w[i] = c[i];
+  T t;
+  __builtin_memcpy(&t, w, sizeof(T));
+  return t;
+}
+// (a pointer that comes out of memory in pieces is a flat pointer: flat_load, flat_atomic.  One that is read AS a pointer
+// from the constant address space is taken for a global pointer by the back end, as kernel arguments are)
+template <class T>
+__device__ __forceinline__ T* load_ptr(T* const* p) {
+  typedef T* const __attribute__((address_space(4)))* cpp;
+  return *(cpp)p;
+}
+#define NLPS_G(x) v.x = load_ptr(&s->x);
+__device__ __forceinline__ void globalise(PView& v, const PView* s) {
+  NLPS_G(d) NLPS_G(I0) NLPS_G(I0n) NLPS_G(mat) NLPS_G(nn) NLPS_G(status) NLPS_G(mlo) NLPS_G(mhi) NLPS_G(tile) NLPS_G(rank)
+}
+__device__ __forceinline__ void globalise(NView& v, const NView* s) {
+  NLPS_G(active) NLPS_G(seed) NLPS_G(h_avg) NLPS_G(beta_t2) NLPS_G(nm) NLPS_G(dU) NLPS_G(force) NLPS_G(accel) NLPS_G(reaction) NLPS_G(fixed)
+}
+__device__ __forceinline__ void globalise(TileD& v, const TileD* s) {
+  NLPS_G(slab) NLPS_G(start) NLPS_G(count) NLPS_G(order) NLPS_G(order_m) NLPS_G(work[0]) NLPS_G(work[1]) NLPS_G(range) NLPS_G(phase)
+  NLPS_G(sig_cnt) NLPS_G(sig_flag)
+}
+__device__ __forceinline__ void globalise(TileCnt& v, const TileCnt* s) {
+  NLPS_G(count) NLPS_G(gstatus) NLPS_G(home) NLPS_G(foreign) NLPS_G(node_cnt) NLPS_G(nrank)
+}
+__device__ __forceinline__ void globalise(K5Search& v, const K5Search* s) {
+  NLPS_G(rank1)
+  globalise(v.tc, &s->tc);
+}
+__device__ __forceinline__ void globalise(FusedStep& v, const FusedStep* s) { NLPS_G(q_head) NLPS_G(done2) NLPS_G(done3) NLPS_G(trace) NLPS_G(bcmask) }
+template <class T>
+__device__ __forceinline__ void globalise(T*& v, T* const* s) { v = load_ptr(s); }
+__device__ __forceinline__ void globalise(GridD&, const GridD*) {}
+__device__ __forceinline__ void globalise(ParamsD&, const ParamsD*) {}
+__device__ __forceinline__ void globalise(double&, const double*) {}
+#undef NLPS_G
+typedef int* IntPtr;
+typedef const MatD* MatCPtr;
+#if NLPS_FUSED_BYVAL
+#define FUSED_GET(T, name, field) const T& name = a->field;
+#else
+#define FUSED_GET(T, name, field)  \
+  T name = load_const(&a->field); \
+  globalise(name, &a->field);
+#endif
 template <int ND>
 FUSED_STAGE void fused_stage_k2(const FusedArgs* a, int wb, int tile, double* sh) {
   constexpr int NWA = TileCfg<ND>::NWA;
   TileWork tw{tile, 0, 1, wb};
-  k2_body<ND, true, BLK>(a->P, a->g, a->N, a->td, a->prm, a->dt, a->gamma_nm, a->gstatus, tw, 0, sh,
-                         reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA), &a->fs);
+  FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(ParamsD, prm, prm)
+  FUSED_GET(double, dt, dt) FUSED_GET(double, gamma_nm, gamma_nm) FUSED_GET(IntPtr, gstatus, gstatus)
+  FusedStep fs;  // (K2 only asks whether it is there)
+  k2_body<ND, true, BLK>(P, g, N, td, prm, dt, gamma_nm, gstatus, tw, 0, sh, reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA), &fs);
 }
 template <int ND, int LAW>
 FUSED_STAGE void fused_stage_k3(const FusedArgs* a, int wb, int tile, double* sh) {
@@ -1768,17 +1832,26 @@ FUSED_STAGE void fused_stage_k3(const FusedArgs* a, int wb, int tile, double* sh
   double* dvz = dvxy + 2;
   int* ints = reinterpret_cast<int*>(dvz + 2);
   const L3 lds{dvxy, dvz, duxy, duz, fac, ints, ints + 2, ints + 4};
-  k3_body<ND, LAW, 1, false, BLK>(a->P, a->g, a->N, a->td, a->mats, a->prm, a->gstatus, nullptr, tw, 0, lds, &a->fs);
+  FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(ParamsD, prm, prm)
+  FUSED_GET(MatCPtr, mats, mats) FUSED_GET(IntPtr, gstatus, gstatus) FUSED_GET(FusedStep, fs, fs)
+  k3_body<ND, LAW, 1, false, BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, 0, lds, &fs);
 }
 template <int ND, int LAW>
 FUSED_STAGE void fused_stage_k5(const FusedArgs* a, int wb, int tile, double* sh) {
   constexpr int NW = TileCfg<ND>::NW;
   TileWork tw{tile, 0, 1, wb};
-  k5_body<ND, (LAW == NLPS_MAT_NEO_HOOKEAN || LAW == NLPS_MAT_HENCKY) ? 0 : 2, true>(a->P, a->g, a->N, a->td, a->dt, a->gamma_nm,
-                                                                                     a->ks, tw, sh, sh + 2 * NW, &a->fs, a->gstatus);
+  FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(K5Search, ks, ks)
+  FUSED_GET(double, dt, dt) FUSED_GET(double, gamma_nm, gamma_nm) FUSED_GET(IntPtr, gstatus, gstatus) FUSED_GET(FusedStep, fs, fs)
+  k5_body<ND, (LAW == NLPS_MAT_NEO_HOOKEAN || LAW == NLPS_MAT_HENCKY) ? 0 : 2, true>(P, g, N, td, dt, gamma_nm, ks, tw, sh, sh + 2 * NW,
+                                                                                     &fs, gstatus);
 }
 template <int ND, int LAW>
-__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(const FusedArgs* __restrict__ args) {
+#if NLPS_FUSED_BYVAL
+__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(const FusedArgs args_v) {
+  const FusedArgs* args = &args_v;
+#else
+__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(const FusedArgs* __restrict__ args_g) {
+#endif
   static_assert(K3_BLK == BLK && K5_BLK == BLK && K2_SPLIT == 1 && K3_SPLIT == 1 && K5_SPLIT == 1, "one work list, one block size");
   using L3 = K3Lds<ND, 1, false>;
   constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA, NROWS = WinRows<ND>::NROWS;
@@ -1789,35 +1862,53 @@ __global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fuse
   constexpr int NSH = (N2 > N3 ? (N2 > N5 ? N2 : N5) : (N3 > N5 ? N3 : N5));
   __shared__ __attribute__((aligned(16))) double sh[NSH];
   __shared__ int s_item;
-  const TileD& td = args->td;
-  const FusedStep& fs = args->fs;
-  const int w_lo = td.range[0], nwork = td.range[1] - td.range[0];
-  const int total = fs.nstages * nwork;
   while (true) {
+#if !NLPS_FUSED_BYVAL
+    const FusedArgs* args = args_g;
+    asm volatile("" : "+s"(args));  // a new pointer every trip: nothing read through it is hoisted out of the loop
+    const FusedArgs* a = args;
+#else
+    const FusedArgs* a = args;
+#endif
+    FUSED_GET(TileD, td, td) FUSED_GET(FusedStep, fs, fs) FUSED_GET(IntPtr, gstatus, gstatus)
+    const int w_lo = td.range[0], nwork = td.range[1] - td.range[0];
+    const int total = fs.nstages * nwork;
 #define FTRACE(k, v)                                                                                         \
-  if (fs.trace && (threadIdx.x & 63) == 0)                                                                   \
+  if (fs.trace && (threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                              \
     __hip_atomic_store(fs.trace + 8 * (size_t)blockIdx.x + (k) + (k >= 4 ? (threadIdx.x >> 6) : 0), (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (threadIdx.x == 0) s_item = (int)atomicAdd(fs.q_head, 1u);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(s_item);  // wave-uniform by construction: scalar branches below
     __syncthreads();  // (s_item is rewritten at the top of the next trip; the stage bodies re-initialise their LDS)
     FTRACE(0, item) FTRACE(4, 1)
-    if (item >= total) break;
+    if (item >= total) {
+      FTRACE(4, 5)
+      break;
+    }
+    long long t0 = fs.trace ? wall_clock64() : 0;
     const int stage = item / nwork;
     const int wb = w_lo + (item - stage * nwork);
     const int tile = td.work[0][wb].x;
     // a tile of a later stage reads nodal sums of its window: the flushes of the tiles around it must have landed
-    if (stage == 1) fused_wait_neighbours<ND>(td, tile, fs.done2, fs.seq, args->gstatus);
-    if (stage == 2) fused_wait_neighbours<ND>(td, tile, fs.done3, fs.seq, args->gstatus);
+    if (stage == 1) fused_wait_neighbours<ND>(td, tile, fs.done2, fs.seq, gstatus, fs.nofence);
+    if (stage == 2) fused_wait_neighbours<ND>(td, tile, fs.done3, fs.seq, gstatus, fs.nofence);
     FTRACE(4, 2)
+    long long t1 = fs.trace ? wall_clock64() : 0;
     if (stage == 0) fused_stage_k2<ND>(args, wb, tile, sh);
     else if (stage == 1) fused_stage_k3<ND, LAW>(args, wb, tile, sh);
     else fused_stage_k5<ND, LAW>(args, wb, tile, sh);
     FTRACE(4, 3)
-    if (stage < 2) fused_publish((stage == 0 ? fs.done2 : fs.done3) + tile, fs.seq);
+    long long t2 = fs.trace ? wall_clock64() : 0;
+    if (stage < 2) fused_publish((stage == 0 ? fs.done2 : fs.done3) + tile, fs.seq, fs.nofence);
     FTRACE(4, 4)
+    if (fs.trace && threadIdx.x == 0) {  // 100 MHz ticks: [stage] waiting, [3 + stage] body, [6 + stage] publish
+      long long t3 = wall_clock64();
+      unsigned long long* acc = reinterpret_cast<unsigned long long*>(fs.trace + 8 * 1024);
+      atomicAdd(acc + stage, (unsigned long long)(t1 - t0));
+      atomicAdd(acc + 3 + stage, (unsigned long long)(t2 - t1));
+      atomicAdd(acc + 6 + stage, (unsigned long long)(t3 - t2));
+    }
   }
-  FTRACE(4, 5)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,6 +2,8 @@
 seeded inputs.  Bit-exact for index maps (I0, neighbour lists, ActiveNode, Nodes2Mask, dof masks);
 FP64 fields to the tolerances of BASELINE.md §4: 1e-10 relative to the field's magnitude for particle
 fields, 1e-10 for nodal sums (atomics reorder them)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1460,3 +1462,31 @@ def test_adaptive_resort_only_moves_memory():
     assert np.array_equal(a["I0"], b["I0"])
     for k in ("x", "vel", "F_n", "Stress", "rho", "lambda"):
         assert_close(a[k], b[k], 1e-10, f"adaptive re-sort on / off: {k}")
+
+
+@pytest.mark.skipif(not os.environ.get("NLPS_TEST_FUSED_STEP"), reason="k_step_fused is a developer switch (NLPS_TEST_FUSED_STEP=1 runs it)")
+def test_one_launch_step_matches_the_separate_kernels(monkeypatch):
+    """k_step_fused (K2, K3 and K5 of one explicit step as the stages of one persistent launch, tile flags in place of the
+    kernel boundaries): the same particle state as the three launches, and the nodal arrays it never stored come out of
+    nlps_gpu_explicit_nodal all the same."""
+    nsteps, dt = 6, 1e-4
+    case = small_case(3, velocity=[0.0, 0.0, -10.0])
+    n = nlps()
+    gb = n.BccSet([dirichlet_plane(case, 2, 2, nsteps)])
+    S = gpu_setup(case, nsteps=nsteps)
+    monkeypatch.setenv("NLPS_FUSED_STEP", "1")
+    Sf = gpu_setup(case, nsteps=nsteps)
+    monkeypatch.delenv("NLPS_FUSED_STEP")
+    Sf.set_timing(True)
+    for t in range(nsteps):
+        S.explicit_step(gb, t, dt)
+        Sf.explicit_step(gb, t, dt)
+    assert S.status_flags() == 0 and Sf.status_flags() == 0
+    assert Sf.get_timing()[7] == 1.0, "the one-launch form did not run"
+    a, b = S.download_state(), Sf.download_state()
+    assert np.array_equal(a["I0"], b["I0"])
+    for k in ("x", "vel", "acc", "Stress", "F_n", "J_n", "rho", "lambda"):
+        assert_close(b[k], a[k], 1e-11, f"{k}: one launch vs three")
+    na, nb = S.explicit_nodal(), Sf.explicit_nodal()
+    for k in ("mass", "dU", "force", "accel", "reaction"):
+        assert_close(nb[k], na[k], 1e-10, f"nodal {k}: one launch vs three", scale=1e-12)
