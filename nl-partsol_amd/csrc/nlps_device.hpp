@@ -123,6 +123,12 @@ struct ParamsD {
 #ifndef NLPS_K3_WAVES_NH
 #define NLPS_K3_WAVES_NH 3  // fused 3-D Neo-Hookean K3 (two-pass gather): 0.294 -> 0.267 ms at 1 M particles
 #endif
+#ifndef NLPS_K3_WAVES_HENCKY
+#define NLPS_K3_WAVES_HENCKY 3
+#endif
+#ifndef NLPS_K3_WAVES_DP
+#define NLPS_K3_WAVES_DP 2
+#endif
 #ifndef NLPS_K3_WAVES
 #define NLPS_K3_WAVES 2  // Hencky / Drucker-Prager need > 256 VGPRs otherwise (1 wave/SIMD: 0.54 -> 0.37 ms at 2)
 #endif

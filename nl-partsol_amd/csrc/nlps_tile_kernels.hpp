@@ -464,6 +464,9 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
 #ifndef NLPS_K3_TWOPASS_ALL
 #define NLPS_K3_TWOPASS_ALL 0
 #endif
+#ifndef NLPS_K3_RELOAD
+#define NLPS_K3_RELOAD 1
+#endif
 #ifndef NLPS_ABL_ATOM
 #define NLPS_ABL_ATOM 0
 #endif
@@ -950,10 +953,14 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
 // compacted into an LDS list first, so every lane works and the kernel is the single-law specialisation (one launch per
 // law present; the run-time dispatch over all laws in one kernel needed 436 B of scratch per lane and 0.51 ms).
 // waves per SIMD the register budget is set for: the fused 3-D Neo-Hookean stage fits three (two-pass gather), the
-// spectral and plastic laws need the registers of two (Hencky at three: 192 B of scratch and 4 % slower)
+// same goes for Hencky once its LME factors are rebuilt after the stress update (RELOAD below), the plastic laws keep two
 template <int ND, int LAW, int MODE>
 struct K3Waves {
-  static constexpr int value = ND == 2 ? NLPS_K3_WAVES_2D : ((MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN) ? NLPS_K3_WAVES_NH : NLPS_K3_WAVES);
+  static constexpr int value = ND == 2 ? NLPS_K3_WAVES_2D
+                               : (MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN) ? NLPS_K3_WAVES_NH
+                               : (MODE == 1 && LAW == NLPS_MAT_HENCKY)      ? NLPS_K3_WAVES_HENCKY
+                               : (MODE == 1 && LAW == NLPS_MAT_DRUCKER_PRAGER) ? NLPS_K3_WAVES_DP
+                                                                               : NLPS_K3_WAVES;
 };
 // the LDS of k3_tile, owned by the caller of k3_body (the kernel below, or k_step_fused, which shares one block of LDS
 // between its three stages)
@@ -1104,7 +1111,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     // which is what lets the elastic laws run at three waves per SIMD; it costs ~350 more VALU instructions a particle.
     // (the level-B modes keep the single pass: with and without rate tensors they must give the same F bit for bit)
     // and the laws that stay at two waves per SIMD keep it too: there the second set of masked weights only costs)
-    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && (LAW == NLPS_MAT_NEO_HOOKEAN || NLPS_K3_TWOPASS_ALL);
+    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && (K3Waves<ND, LAW, MODE>::value >= 3 || NLPS_K3_TWOPASS_ALL);
     if (TWOPASS) {
 #pragma unroll 1
       for (int k = 0; k < KN; k++) {
@@ -1433,6 +1440,28 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), -1.0);
     PH(11)
     if (fo_ok) {
+      // RELOAD (the laws whose stress update sets the register budget): the LME factors are rebuilt from the particle's
+      // stored x, lambda, beta and masks after the stress update instead of living through it (15 exponentials again, for
+      // 40 registers less across the most register-hungry part of the kernel)
+      // Measured at 1 M particles: Hencky at three waves per SIMD without scratch 0.290 ms (0.295 at two); Drucker-Prager
+      // gains nothing from it (two waves with the reload 0.363 ms, three 0.358 ms with 212 B of scratch, 0.348 ms as it
+      // was): those kernels are bound by their instruction count (4100 / 5900 static), not by latency.
+      constexpr bool RELOAD = (NLPS_K3_RELOAD != 0) && ND == 3 && MODE == 1 && LAW != NLPS_MAT_NEO_HOOKEAN && K3Waves<ND, LAW, MODE>::value >= 3;
+      Lme<ND> cs;
+      if (RELOAD) {
+        int p2 = pl;
+        asm volatile("" : "+v"(p2));
+        double lam2[ND], beta2;
+        load_lme<ND>(P, g, p2, cs, lam2, beta2);
+      } else {
+        cs = c;
+      }
+      const Lme<ND>& c = cs;
+      NLPS_YZ_LOCALS(c);
+      (void)ly5;
+      (void)lz5;
+      const double hx = c.lx[2] - c.lx[3];
+      const double al[3] = {c.lx[2], c.ly[2], (ND == 3) ? c.lz[2 % KN] : 0.0};
       // pass 2: -f_A = p_A * (B l_A) with l = a - h u:  B l = B a - h (B[.][x] u_i + B[.][y] v_j + B[.][z] w_k)
       double Ba[ND], hB[ND * ND];
 #pragma unroll
