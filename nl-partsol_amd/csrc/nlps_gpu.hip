@@ -1096,7 +1096,8 @@ struct TileTabCfg {
 
 template <int ND>
 __global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD g, NView N, TileScanArgs ts,
-                                                      int* __restrict__ foreign, int* __restrict__ foreign_host, TileTab tab) {
+                                                      int* __restrict__ foreign, int* __restrict__ foreign_host, TileTab tab,
+                                                      int clear_nodal) {
   if (blockIdx.x == 0) {
     if (foreign && threadIdx.x < 64) {  // this step's count of displaced particles (bin_particle) -> pinned host word
       int v = foreign[32 * threadIdx.x];
@@ -1111,7 +1112,19 @@ __global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD 
   const int nbd = (nnodes + 1023) >> 10;  // workgroups of the activation
   if ((int)blockIdx.x <= nbd) {
     const int A = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
-    if (A < nnodes) dilate_node<ND>(n0 + A, g, N);
+    if (A < nnodes) {
+      dilate_node<ND>(n0 + A, g, N);
+      if (clear_nodal) {  // (k_step_clear's nodal part, when that kernel has nothing else to do: the search ran ahead)
+        const size_t B = (size_t)n0 + A;
+#pragma unroll
+        for (int a = 0; a < 1 + ND; a++) N.nm[B * (1 + ND) + a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < ND; a++) {
+          N.force[B * ND + a] = 0.0;
+          N.fixed[B * ND + a] = 0;
+        }
+      }
+    }
     return;
   }
   // layer tables of the canonical tile lists (TileTab), one wave per tile
@@ -1390,6 +1403,7 @@ struct nlps_gpu {
   // OFF: on the GPU boxes of round 3 the launch never completed once a second stage had items, even with the stage bodies
   // and every wait and publish taken out (while tools/fused_sync_test.hip, the same skeleton without the physics, ran
   // in 0.1 ms): unfinished, kept behind the developer switch NLPS_FUSED_STEP=1 ("k_step_fused")
+  int lazy_nodal = 1;  // the folded explicit step (k3_tile_lazy / k5_tile_lazy): 1 below 2 M particles, 2 always, 0 never (NLPS_LAZY_NODAL)
   int fused_step = 0;
   unsigned* fused_q_d = nullptr;
   struct FusedArgs* fused_args_d = nullptr;
@@ -1817,6 +1831,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
   if (const char* e = getenv("NLPS_FUSE_SEARCH")) h->fuse_search = atoi(e);
   if (const char* e = getenv("NLPS_FUSED_STEP")) h->fused_step = atoi(e);
+  if (const char* e = getenv("NLPS_LAZY_NODAL")) h->lazy_nodal = atoi(e);
   {
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
@@ -3038,6 +3053,19 @@ static NodeRanges node_ranges(nlps_gpu* h, int part) {
   return {lo * plane, (il - lo) * plane, ih * plane, (hi + 1 - ih) * plane};
 }
 
+// The folded explicit step (and k_step_fused) never stored dU, the accelerations and the reactions of its step: made here,
+// from the nodal sums of that step, before somebody reads them or overwrites the sums they come from.
+static int materialise_nodal(nlps_gpu* h) {
+  if (!h->nodal_stale) return 0;
+  const NodeRanges r = node_ranges(h, 0);
+  LAUNCH_ND((k_nodal_dU<2>), (k_nodal_dU<3>), nblk(r.an + r.bn), r.a0, r.an, r.b0, r.bn, h->N, h->last_bm, h->last_bc);
+  LAUNCH_ND((k_nodal_accel<2>), (k_nodal_accel<3>), nblk(r.an + r.bn), r.a0, r.an, r.b0, r.bn, h->N, h->last_gv[0],
+            h->last_gv[1], h->last_gv[2], 0, (int*)nullptr, (int*)nullptr, 0);
+  HIPCHK(hipGetLastError());
+  h->nodal_stale = false;
+  return 0;
+}
+
 // arms the boundary-done signal of a single-launch stage (overlap mode 2): stage 0 = K2, 1 = K3
 static void arm_signal(nlps_gpu* h, TileD& td, int stage) {
   RcclHalo* R = h->rccl;
@@ -3081,8 +3109,10 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   // nodal accumulators are reset here
   const bool ahead = h->ahead && !init;
   if (ahead) std::swap(h->tile_count_d, h->tile_count2_d);  // the counters that search filled size the lists from here on
-  LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
-            h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0, node_lists(h) ? h->node_cnt_d : nullptr, ahead ? 0 : 1);
+  const bool clear_in_dilate = ahead && p2g;  // nothing but the nodal accumulators to reset: k_dilate_scan does it
+  if (!clear_in_dilate)
+    LAUNCH_ND((k_step_clear<2>), (k_step_clear<3>), nblk(std::max(h->nwn, h->ntw)), h->n0, h->nwn, h->N,
+              h->tile_count_d + h->tile0, h->ntw, p2g ? 1 : 0, node_lists(h) ? h->node_cnt_d : nullptr, ahead ? 0 : 1);
   if (!ahead) {
     TileCnt tc = tile_cnt(h, true);
     if (init) LAUNCH_ND((k_init_I0<2>), (k_init_I0<3>), nblk(np), h->P, h->g, h->N, tc);
@@ -3100,8 +3130,8 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
     tab.base = h->tabo_d;
     const int nb = 1 + (h->nwn + 1023) / 1024 + (node_lists(h) ? (h->ntw + 15) / 16 : 0);
     int* fo = (h->adaptive_resort > 0.0 && !h->deterministic) ? h->foreign_d : nullptr;
-    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h, tab);
-    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h, tab);
+    if (h->nd == 2) hipLaunchKernelGGL(k_dilate_scan<2>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h, tab, clear_in_dilate ? 1 : 0);
+    else hipLaunchKernelGGL(k_dilate_scan<3>, dim3(nb), dim3(1024), 0, h->stream, h->n0, h->nwn, h->g, h->N, ts, fo, h->foreign_h, tab, clear_in_dilate ? 1 : 0);
   }
   HIPCHK(hipGetLastError());
   if (halo(h, h->N.active, 1, 1, 1, overlap ? 1 : 0)) return 1;
@@ -3435,6 +3465,7 @@ extern "C" int nlps_gpu_internal_forces(nlps_gpu* h, double* R) {
     }
     HIPCHK(hipGetLastError());
   }
+  if (materialise_nodal(h)) return 1;  // (the forces of the last explicit step are about to go)
   HIPCHK(hipMemsetAsync(h->N.force, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
   {
     TileD td = tile_view(h);
@@ -3800,6 +3831,68 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     }
 #undef NLPS_K5
   };
+  // Folded form (k3_tile_lazy / k5_tile_lazy): one GPU without a ghost exchange, one law, the Dirichlet sets small enough
+  // to travel as kernel arguments: no nodal kernels between the stages (made later if somebody asks for the nodal arrays)
+  // (measured: 1 % faster per step at 1 M particles -- three launches less -- and 1.2 % slower at 8 M, where the window
+  // loads of 17 k tiles redo the two divisions per node 16 times over: on below 2 M particles, NLPS_LAZY_NODAL=2 always)
+  const bool lazy = (h->lazy_nodal == 2 || (h->lazy_nodal == 1 && h->P.np <= 2000000)) && fuse && h->fuse_search == 1 && !det && !h->rccl && !h->halo && h->uniform_law >= 0 &&
+                    h->uniform_law <= NLPS_KLAW_FRICTIONAL && nbcc <= NLPS_MAX_BC_INLINE;
+  LazyNodal ln;
+  if (lazy) {
+    memset(&ln, 0, sizeof ln);
+    ln.fs.bc.n = nbcc;
+    for (int i = 0; i < nbcc; i++) {
+      ln.fs.bc.dim[i] = bcc[i].dim;
+      ln.fs.bc.bits[i] = h->bcs[i].n > 0 ? dirbits_of(bcc[i], step, h->nsteps) : 0;
+      for (int k = 0; k < 3; k++) ln.fs.bc.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
+    }
+    ln.fs.bcmask = nbcc > 0 ? h->bcmask_d : nullptr;
+    ln.fs.plain_loads = 1;
+    for (int a = 0; a < 3; a++) ln.fs.gv[a] = gv[a];
+    ln.n0 = h->n0;
+    ln.nwn = h->nwn;
+    ln.node_cnt = node_lists(h) ? h->node_cnt_d : nullptr;
+    ln.ntw = h->ntw;  // (ln.tile_count: after search_and_lists, which swaps the two counter arrays)
+  }
+  auto launch_k3_lazy = [&]() {
+    const TileD td = tile_view(h, 0);
+#define NLPS_K3L(NDv, LAWv)                                                                                              \
+  hipLaunchKernelGGL((k3_tile_lazy<NDv, LAWv>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
+                     h->mats_d, h->prm, h->gstatus_d, ln)
+    const int law = h->uniform_law;
+    if (ND == 2) {
+      if (law == 0) NLPS_K3L(2, 0);
+      else if (law == 1) NLPS_K3L(2, 1);
+      else if (law == 2) NLPS_K3L(2, 2);
+      else if (law == 3) NLPS_K3L(2, 3);
+      else NLPS_K3L(2, 4);
+    } else {
+      if (law == 0) NLPS_K3L(3, 0);
+      else if (law == 1) NLPS_K3L(3, 1);
+      else if (law == 2) NLPS_K3L(3, 2);
+      else if (law == 3) NLPS_K3L(3, 3);
+      else NLPS_K3L(3, 4);
+    }
+#undef NLPS_K3L
+  };
+  auto launch_k5_lazy = [&]() {
+    const TileD td = tile_view(h, 0);
+    ks.tc = tile_cnt(h, true);
+    ks.tc.count = h->tile_count2_d;
+    ks_made = true;
+#define NLPS_K5L(NDv, LAWv)                                                                                             \
+  hipLaunchKernelGGL((k5_tile_lazy<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g, h->N, td, \
+                     dt, gamma_nm, ks, ln, h->gstatus_d)
+    const int law = h->uniform_law;
+    if (ND == 2) {
+      if (law == 0 || law == 1) NLPS_K5L(2, 0);
+      else NLPS_K5L(2, 2);
+    } else {
+      if (law == 0 || law == 1) NLPS_K5L(3, 0);
+      else NLPS_K5L(3, 2);
+    }
+#undef NLPS_K5L
+  };
   // One launch for K2, K3 and K5 (k_step_fused): one GPU without a ghost exchange, 3-D, one law, the Dirichlet sets
   // small enough to travel as kernel arguments.  The nodal kernels between the stages run lazily, only when somebody
   // asks for the nodal arrays (nlps_gpu_explicit_nodal).
@@ -3846,6 +3939,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (const char* e = getenv("NLPS_FUSED_GRID")) fgrid = atoi(e);
     fs.trace = nullptr;
     fs.nofence = 0;
+    fs.plain_loads = 0;
     if (const char* e = getenv("NLPS_FUSED_NOFENCE")) fs.nofence = atoi(e);
     static int* trace_h = nullptr;
     if (getenv("NLPS_FUSED_TRACE")) {
@@ -3920,7 +4014,22 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // the node window are reset by k_step_clear inside search_and_lists)
   if (search_and_lists(h, false, true, dt, gamma_nm, ov2 ? 2 : (ov ? 1 : 0))) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-  if (ov2) {
+  if (lazy) {
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
+    ln.tile_count = h->tile_count2_d + h->tile0;
+    launch_k3_lazy();
+    HIPCHK(hipGetLastError());
+    if (h->timing) {
+      HIPCHK(hipEventRecord(h->ev[4], h->stream));
+      HIPCHK(hipEventRecord(h->ev[5], h->stream));
+    }
+    launch_k5_lazy();
+    HIPCHK(hipGetLastError());
+    h->nodal_stale = true;
+    h->last_bc = ln.fs.bc;
+    h->last_bm = ln.fs.bcmask;
+    for (int a = 0; a < 3; a++) h->last_gv[a] = gv[a];
+  } else if (ov2) {
     // mode 2: K2 is in flight as ONE launch; its boundary tiles release the exchange of the shared layers of nm, which
     // runs beside its interior tiles; the handle's stream picks the result up before the nodal kernel
     if (halo(h, h->N.nm, 1 + ND, 8, 0, 3)) return 1;
@@ -4025,14 +4134,7 @@ extern "C" int nlps_gpu_num_active(nlps_gpu* h, int* nactive) {
 extern "C" int nlps_gpu_explicit_nodal(nlps_gpu* h, double* mass, double* dU, double* force, double* accel,
                                        double* reaction) {
   int ND = h->nd;
-  if (h->nodal_stale) {  // the last step ran as k_step_fused: dU, accelerations and reactions were never stored
-    const NodeRanges r = node_ranges(h, 0);
-    LAUNCH_ND((k_nodal_dU<2>), (k_nodal_dU<3>), nblk(r.an + r.bn), r.a0, r.an, r.b0, r.bn, h->N, h->last_bm, h->last_bc);
-    LAUNCH_ND((k_nodal_accel<2>), (k_nodal_accel<3>), nblk(r.an + r.bn), r.a0, r.an, r.b0, r.bn, h->N, h->last_gv[0],
-              h->last_gv[1], h->last_gv[2], 0, (int*)nullptr, (int*)nullptr, 0);
-    HIPCHK(hipGetLastError());
-    h->nodal_stale = false;
-  }
+  if (materialise_nodal(h)) return 1;
   if (compute_node_mask(h)) return 1;
   HIPCHK(hipMemcpyAsync(&h->nactive, h->total_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

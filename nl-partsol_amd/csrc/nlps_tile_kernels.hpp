@@ -572,6 +572,7 @@ struct FusedStep {
   int nstages;           // 3; developer switch NLPS_FUSED_STAGES runs the first stages only
   int* trace;            // developer switch NLPS_FUSED_TRACE: host-visible progress marks, 8 ints per workgroup
   int nofence;           // developer switch NLPS_FUSED_NOFENCE (timing experiments): 1 no release, 2 no acquire
+  int plain_loads;       // the nodal sums were flushed by an EARLIER launch (k3_tile_lazy, k5_tile_lazy): ordinary loads do
   const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
   BcStep bc;             // their components and values at this step
   double gv[3];          // gravity
@@ -622,14 +623,15 @@ __device__ __forceinline__ double coherent_load(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // what k_nodal_dU makes of a node (U-Verlet.c:357-362 + :455-527), from the nodal sums as they stand in L2
+__device__ __forceinline__ double nodal_load(const FusedStep& fs, const double* p) { return fs.plain_loads ? *p : coherent_load(p); }
 template <int ND>
 __device__ __forceinline__ void fused_nodal_dU(const NView& N, const FusedStep& fs, int A, double* val, bool* fix) {
-  const double M = coherent_load(N.nm + (size_t)A * (1 + ND));
+  const double M = nodal_load(fs, N.nm + (size_t)A * (1 + ND));
   const bool active = N.active[A];
   const bool act = active && M != 0.0;
 #pragma unroll
   for (int a = 0; a < ND; a++) {
-    val[a] = act ? coherent_load(N.nm + (size_t)A * (1 + ND) + 1 + a) / M : 0.0;
+    val[a] = act ? nodal_load(fs, N.nm + (size_t)A * (1 + ND) + 1 + a) / M : 0.0;
     fix[a] = false;
   }
   const unsigned bm = (fs.bcmask && active) ? fs.bcmask[A] : 0u;
@@ -650,7 +652,7 @@ template <int ND>
 __device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedStep& fs, int A, double* acc) {
   double dU[ND];
   bool fix[ND];
-  const double M = coherent_load(N.nm + (size_t)A * (1 + ND));
+  const double M = nodal_load(fs, N.nm + (size_t)A * (1 + ND));
   const bool act = N.active[A] && M != 0.0;
   (void)dU;
 #pragma unroll
@@ -666,7 +668,7 @@ __device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedSte
   }
 #pragma unroll
   for (int a = 0; a < ND; a++)
-    acc[a] = (act && !fix[a]) ? fs.gv[a] + coherent_load(N.force + (size_t)A * ND + a) / M : 0.0;
+    acc[a] = (act && !fix[a]) ? fs.gv[a] + nodal_load(fs, N.force + (size_t)A * ND + a) / M : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1565,6 +1567,44 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
   k3_body<ND, LAW, MODE, FILT, NT>(P, g, N, td, mats, prm, gstatus, dVgrid, tw, nbnd, lds, nullptr);
 }
 
+// The explicit step of one GPU without a ghost exchange, "folded" form: the nodal kernels between the stages are gone.
+// K3 makes dU = sum m N dD / M (+ Dirichlet values) of its window nodes from the sums K2 flushed, K5 makes a = g + f / M
+// from the forces K3 flushed (fused_nodal_dU / fused_nodal_accel: what k_nodal_dU / k_nodal_accel do per node, here per
+// window slot -- 16 x the divisions, two per thread and tile), and K3's workgroups reset on the side what the search
+// inside K5 accumulates into.  Three launches and ~35 us per step less at 1 M particles; the nodal arrays nobody reads
+// during the step are made when somebody asks (nlps_gpu_explicit_nodal, nodal_stale).
+struct LazyNodal {
+  FusedStep fs;  // bc, bcmask, gv (the queue fields are unused)
+  int n0, nwn;   // node window
+  int* node_cnt;
+  int* tile_count;
+  int ntw;
+};
+template <int ND, int LAW>
+__global__ __launch_bounds__(K3_BLK, (K3Waves<ND, LAW, 1>::value)) void k3_tile_lazy(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
+                                                                                  ParamsD prm, int* __restrict__ gstatus, LazyNodal ln) {
+  using L = K3Lds<ND, 1, false>;
+  __shared__ __attribute__((aligned(16))) double dvxy[L::N_DVXY];
+  __shared__ double dvz[L::N_DVZ];
+  __shared__ __attribute__((aligned(16))) double duxy[2 * L::NW];
+  __shared__ double duz[L::N_DUZ];
+  __shared__ double fac[ND * L::NWA];
+  __shared__ int sel[L::SELCAP];
+  __shared__ int nsel;
+  __shared__ int wcnt[K3_BLK / 64];
+  for (int i = blockIdx.x * K3_BLK + threadIdx.x; i < max(ln.nwn, ln.ntw); i += gridDim.x * K3_BLK) {
+    if (i < ln.ntw) ln.tile_count[i] = 0;
+    if (i < ln.nwn) {
+      N.seed[ln.n0 + i] = 0;
+      if (ln.node_cnt) ln.node_cnt[ln.n0 + i] = 0;
+    }
+  }
+  TileWork tw;
+  if (!tile_work_item<K3_SPLIT>(td, tw)) return;
+  const L lds{dvxy, dvz, duxy, duz, fac, sel, &nsel, wcnt};
+  k3_body<ND, LAW, 1, false, K3_BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, 0, lds, &ln.fs);
+}
+
 // Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)
 // in a fixed order and writes out[node][NF]: the second half of the P2G flush (see TileD::slab).  A tile's slab is
 // valid iff the tile was launched this step (inside [tile0, tile0 + ntw) and count > 0); it then holds td.slab_n slabs.
@@ -1752,6 +1792,16 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile(PView P, GridD g, NView N, Til
   TileWork tw;
   if (!tile_work_item<K5_SPLIT>(td, tw)) return;
   k5_body<ND, LAW, SEARCH>(P, g, N, td, dt, gamma_nm, ks, tw, axy, az, nullptr, nullptr);
+}
+
+template <int ND, int LAW>
+__global__ __launch_bounds__(K5_BLK) void k5_tile_lazy(PView P, GridD g, NView N, TileD td, double dt, double gamma_nm, K5Search ks,
+                                                       LazyNodal ln, int* __restrict__ gstatus) {
+  __shared__ __attribute__((aligned(16))) double axy[2 * TileCfg<ND>::NW];
+  __shared__ double az[(ND == 3) ? TileCfg<ND>::NW : 1];
+  TileWork tw;
+  if (!tile_work_item<K5_SPLIT>(td, tw)) return;
+  k5_body<ND, LAW, true>(P, g, N, td, dt, gamma_nm, ks, tw, axy, az, &ln.fs, gstatus);
 }
 
 // ------------------------------------------------------------------------------------------------

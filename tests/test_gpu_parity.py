@@ -1490,3 +1490,34 @@ def test_one_launch_step_matches_the_separate_kernels(monkeypatch):
     na, nb = S.explicit_nodal(), Sf.explicit_nodal()
     for k in ("mass", "dU", "force", "accel", "reaction"):
         assert_close(nb[k], na[k], 1e-10, f"nodal {k}: one launch vs three", scale=1e-12)
+
+
+@pytest.mark.parametrize("ndim,material", [(2, DP), (3, NH)])
+def test_folded_step_matches_the_nodal_kernels(monkeypatch, ndim, material):
+    """Default on one GPU: K3 and K5 make dU and the accelerations of their window nodes themselves (k3_tile_lazy,
+    k5_tile_lazy) and the nodal arrays are only made on request.  Same state, same nodal arrays as the form with the
+    nodal kernels between the stages (NLPS_LAZY_NODAL=0: what the multi-rank and deterministic paths run), also when
+    the request comes late, after a download."""
+    nsteps, dt = 5, 1e-4
+    v = [0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0]
+    case = small_case(ndim, material=material, velocity=v)
+    n = nlps()
+    gb = n.BccSet([dirichlet_plane(case, ndim - 1, 2, nsteps)])
+    S = gpu_setup(case, nsteps=nsteps)
+    monkeypatch.setenv("NLPS_LAZY_NODAL", "0")
+    Sn = gpu_setup(case, nsteps=nsteps)
+    monkeypatch.delenv("NLPS_LAZY_NODAL")
+    grav = [0.0] * (ndim - 1) + [-9.81]
+    for t in range(nsteps):
+        S.explicit_step(gb, t, dt, gravity=grav)
+        Sn.explicit_step(gb, t, dt, gravity=grav)
+    assert S.status_flags() == 0 and Sn.status_flags() == 0
+    a, b = S.download_state(), Sn.download_state()
+    assert np.array_equal(a["I0"], b["I0"])
+    for k in ("x", "vel", "acc", "Stress", "F_n", "J_n", "rho"):
+        assert_close(a[k], b[k], 1e-11, f"{k}: folded step vs nodal kernels")
+    na, nb = S.explicit_nodal(), Sn.explicit_nodal()
+    assert S.nactive == Sn.nactive
+    for k in ("mass", "dU", "force", "accel", "reaction"):
+        assert_close(na[k], nb[k], 1e-10, f"nodal {k}: folded step vs nodal kernels", scale=1e-12)
+    assert np.abs(nb["reaction"]).max() > 0.0 and np.abs(nb["dU"]).max() > 0.0
