@@ -98,14 +98,16 @@ struct TileD {
 // called by all threads of a workgroup after its global flush
 __device__ __forceinline__ void tile_signal(const TileD& td, int wb, int nb) {
   if (!td.sig_flag || wb >= nb) return;
-  // producer side of the hand-off (MI355X_MICROARCH.md, "Valid forms"): every wave drains its own flush atomics,
-  // the workgroup meets, ONE lane releases at agent scope and counts (256 threads fencing cost 2-4x one lane's, per
-  // workgroup, and 900 boundary workgroups do this)
+  // producer side of the hand-off (MI355X_MICROARCH.md, "Valid forms"): every wave drains its own flush atomics, the
+  // workgroup meets, ONE lane counts.  What is handed over -- the nodal sums of the shared layers -- was written by
+  // agent-scope atomics only, which leave no line behind in the XCD's L2 (same table: "atomic DROP it"), so a workgroup
+  // has nothing to write back: the agent-scope release every boundary workgroup used to make here (buffer_wbl2, ~900
+  // workgroups per stage) cost 30 us per step (0.664 -> 0.634 ms in the one-GPU rehearsal of overlap mode 2).  The last
+  // workgroup still publishes with a release, and the consumers are kernels launched after k_wait_flag has seen the
+  // flag: a launch starts with an agent acquire.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned old = atomicAdd(td.sig_cnt, 1u);
     if (old == (unsigned)nb - 1u) {
       atomicExch(td.sig_cnt, 0u);  // ready for the next launch
