@@ -220,7 +220,9 @@ int nlps_gpu_explicit_step(nlps_gpu *h, const nlps_bcc *bcc, int nbcc, int step,
                            double gamma, const double *gravity);
 /* Number of active nodes after the last search (computes Nodes2Mask on the device). */
 int nlps_gpu_num_active(nlps_gpu *h, int *nactive);
-/* Nodal results of the last explicit step in masked numbering (any pointer may be NULL). */
+/* Nodal results of the last explicit step in masked numbering (any pointer may be NULL).  On one GPU without a ghost
+ * exchange the step itself keeps only the nodal sums (mass, momentum, force): dU, accelerations and reactions are made
+ * from them by this call (or before a level-B stage overwrites the sums), two small kernels. */
 int nlps_gpu_explicit_nodal(nlps_gpu *h, double *mass, double *dU, double *force, double *accel,
                             double *reaction);
 
