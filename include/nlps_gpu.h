@@ -153,6 +153,12 @@ int nlps_gpu_download_state(nlps_gpu *h, nlps_particles *host);
 /* MPM_Mesh.NumberNodes[p] and ListNodes[p] as arrays (chain order = nodal_set__Particles__ order,
  * Particles/Particles-Tools.c:71-82): nn[np], list[np][NLPS_MAXNB]. */
 int nlps_gpu_download_lists(nlps_gpu *h, int *nn, int *list);
+/* The shape functions and their gradients of particles first .. first + count - 1 (caller's order) in the order of
+ * ListNodes[p]: what compute_N__ShapeFun__ / compute_dN__ShapeFun__ return for the LME family (Shape-Functions.c:145-262;
+ * p__LME__ LME.c:716-762, dp__LME__ LME.c:836-891, with the particle's current lambda and beta).  N[count][NLPS_MAXNB],
+ * dN[count][NLPS_MAXNB][ndim], entries behind NumberNodes[p] are 0; either may be NULL.  A level-A entry for callers that
+ * interpolate fields of their own (outputs, contact, diagnostics); the step kernels never store these values. */
+int nlps_gpu_shape_functions(nlps_gpu *h, int first, int count, double *N, double *dN);
 /* FEM_Mesh.ActiveNode[nnodes] as bytes */
 int nlps_gpu_download_active(nlps_gpu *h, unsigned char *active);
 /* OR of the per-particle failure flags (1 Newton, 2 connectivity, 4 J<=0, 8 constitutive, 16 halo) */

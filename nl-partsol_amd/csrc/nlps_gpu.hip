@@ -2422,6 +2422,123 @@ extern "C" int nlps_gpu_download_lists(nlps_gpu* h, int* nn_out, int* list) {
   return 0;
 }
 
+static int check_status(nlps_gpu* h, int fatal_mask, const char* where);
+// Level A: the shape functions themselves.  One thread per requested particle (device slot): p_a = e_a / Z for the 5^d
+// stencil slots (0 for non-members) and dp_a = -p_a J^-1 l_a (LME.c:836-891: r and J from the same p), written per SLOT;
+// the host puts them into the particle's list order (the walk of nlps_gpu_download_lists).
+template <int ND>
+__global__ void k_shape_slots(PView P, GridD g, const int* __restrict__ slots, int n, double* __restrict__ Ns,
+                              double* __restrict__ dNs, int* __restrict__ gstatus) {
+  constexpr int NS = (ND == 3) ? 125 : 25, KN = Lme<ND>::KN;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int p = slots[q];
+  double* Nq = Ns + (size_t)q * NS;
+  double* dq = dNs + (size_t)q * NS * ND;
+  for (int b = 0; b < NS; b++) {
+    Nq[b] = 0.0;
+    for (int a = 0; a < ND; a++) dq[b * ND + a] = 0.0;
+  }
+  Lme<ND> c;
+  double lam[ND], beta;
+  if (!load_lme<ND>(P, g, p, c, lam, beta)) return;
+  // plain sums in slot order (not the wave-cooperative row form of the step kernels: lanes hold unrelated particles here)
+  double Z = 0.0;
+  for (int b = 0; b < NS; b++)
+    if (c.on(b)) Z += c.ex[b % 5] * c.ey[(b / 5) % 5] * ((ND == 3) ? c.ez[(b / 25) % KN] : 1.0);
+  const double Zinv = 1.0 / Z;
+  double r[ND], J[ND * ND], Jm1[ND * ND];
+  for (int a = 0; a < ND; a++) r[a] = 0.0;
+  for (int a = 0; a < ND * ND; a++) J[a] = 0.0;
+  for (int b = 0; b < NS; b++) {
+    if (!c.on(b)) continue;
+    const int i = b % 5, j = (b / 5) % 5, k = b / 25;
+    const double pa = c.ex[i] * c.ey[j] * ((ND == 3) ? c.ez[k % KN] : 1.0) * Zinv;
+    const double l[3] = {c.lx[i], c.ly[j], (ND == 3) ? c.lz[k % KN] : 0.0};
+    for (int a = 0; a < ND; a++) {
+      r[a] += pa * l[a];
+      for (int m = 0; m < ND; m++) J[a * ND + m] += pa * l[a] * l[m];
+    }
+  }
+  for (int a = 0; a < ND; a++)
+    for (int m = 0; m < ND; m++) J[a * ND + m] -= r[a] * r[m];
+  if (!inverse<ND>(Jm1, J)) {
+    atomicOr(&P.status[p], ST_NEWTON);
+    atomicOr(gstatus, ST_NEWTON);
+    return;
+  }
+  for (int b = 0; b < NS; b++) {
+    if (!c.on(b)) continue;
+    const int i = b % 5, j = (b / 5) % 5, k = b / 25;
+    const double pa = c.ex[i] * c.ey[j] * ((ND == 3) ? c.ez[k % KN] : 1.0) * Zinv;
+    const double l[3] = {c.lx[i], c.ly[j], (ND == 3) ? c.lz[k % KN] : 0.0};
+    Nq[b] = pa;
+    for (int a = 0; a < ND; a++) {
+      double v = 0.0;
+      for (int m = 0; m < ND; m++) v += Jm1[a * ND + m] * l[m];
+      dq[b * ND + a] = -pa * v;
+    }
+  }
+}
+
+extern "C" int nlps_gpu_shape_functions(nlps_gpu* h, int first, int count, double* N_out, double* dN_out) {
+  const int np = h->P.np, ND = h->nd, NS = ND == 3 ? 125 : 25;
+  if (first < 0 || count < 0 || first + count > np) {
+    h->err = "nlps_gpu_shape_functions(): particle range outside the cloud";
+    return 1;
+  }
+  if (count == 0) return 0;
+  if (refresh_perm(h)) return 1;
+  // device slots of the caller's particles first .. first + count - 1
+  std::vector<int> slot_of(np), slots(count), I0(np);
+  for (int s = 0; s < np; s++) slot_of[h->perm[s]] = s;
+  for (int q = 0; q < count; q++) slots[q] = slot_of[first + q];
+  int* slots_d = nullptr;
+  double *Ns_d = nullptr, *dNs_d = nullptr;
+  HIPCHK(hipMalloc((void**)&slots_d, (size_t)count * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&Ns_d, (size_t)count * NS * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&dNs_d, (size_t)count * NS * ND * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(slots_d, slots.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (ND == 2) hipLaunchKernelGGL(k_shape_slots<2>, dim3(nblk(count)), dim3(BLK), 0, h->stream, h->P, h->g, slots_d, count, Ns_d, dNs_d, h->gstatus_d);
+  else hipLaunchKernelGGL(k_shape_slots<3>, dim3(nblk(count)), dim3(BLK), 0, h->stream, h->P, h->g, slots_d, count, Ns_d, dNs_d, h->gstatus_d);
+  HIPCHK(hipGetLastError());
+  std::vector<double> Ns((size_t)count * NS), dNs((size_t)count * NS * ND);
+  std::vector<u64> lo(np), hi(np);
+  HIPCHK(hipMemcpyAsync(Ns.data(), Ns_d, Ns.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(dNs.data(), dNs_d, dNs.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(I0.data(), h->P.I0, (size_t)np * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(lo.data(), h->P.mlo, (size_t)np * sizeof(u64), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hi.data(), h->P.mhi, (size_t)np * sizeof(u64), hipMemcpyDeviceToHost));
+  (void)hipFree(slots_d);
+  (void)hipFree(Ns_d);
+  (void)hipFree(dNs_d);
+  const GridD& g = h->g;
+  for (int q = 0; q < count; q++) {
+    const int s = slots[q];
+    int ijk[3] = {I0[s] % g.n[0], (I0[s] / g.n[0]) % g.n[1], I0[s] / (g.n[0] * g.n[1])};
+    int cls = 0, mul = 1;
+    for (int a = 0; a < 3; a++) {
+      cls += (a < ND ? nlps_host::class5(ijk[a], g.n[a]) : 2) * mul;
+      mul *= 5;
+    }
+    int tmp[NLPS_MAXNB], nt = 0;  // the members in chain order, then reversed: the order of ListNodes (nlps_gpu_download_lists)
+    for (int w = 0; w < h->tab.count2[cls]; w++) {
+      const int b = h->tab.order2[cls][w];
+      const bool on = b < 64 ? ((lo[s] >> b) & 1ull) : ((hi[s] >> (b - 64)) & 1ull);
+      if (on) tmp[nt++] = b;
+    }
+    for (int a = 0; a < NLPS_MAXNB; a++) {
+      const int b = a < nt ? tmp[nt - 1 - a] : -1;
+      if (N_out) N_out[(size_t)q * NLPS_MAXNB + a] = b >= 0 ? Ns[(size_t)q * NS + b] : 0.0;
+      if (dN_out)
+        for (int d = 0; d < ND; d++)
+          dN_out[((size_t)q * NLPS_MAXNB + a) * ND + d] = b >= 0 ? dNs[((size_t)q * NS + b) * ND + d] : 0.0;
+    }
+  }
+  return check_status(h, ST_NEWTON, "nlps_gpu_shape_functions()");
+}
+
 extern "C" int nlps_gpu_download_active(nlps_gpu* h, unsigned char* active) {
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(active, h->N.active, (size_t)h->g.nnodes, hipMemcpyDeviceToHost));

@@ -65,7 +65,7 @@ _LIB = None
 
 # every symbol include/nlps_gpu.h declares
 SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_gpu_synchronize",
-           "nlps_gpu_download_state", "nlps_gpu_download_lists", "nlps_gpu_download_active",
+           "nlps_gpu_download_state", "nlps_gpu_download_lists", "nlps_gpu_shape_functions", "nlps_gpu_download_active",
            "nlps_gpu_status_flags", "nlps_gpu_initialize_lme", "nlps_gpu_local_search", "nlps_gpu_active_masks",
            "nlps_gpu_set_node_numbering",
            "nlps_gpu_lumped_mass", "nlps_gpu_nodal_field_n", "nlps_gpu_compatibility", "nlps_gpu_constitutive",
@@ -138,6 +138,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p]
         L.nlps_gpu_download_state.argtypes = [C.c_void_p, C.POINTER(Particles)]
         L.nlps_gpu_download_lists.argtypes = [C.c_void_p, _ip, _ip]
+        L.nlps_gpu_shape_functions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.nlps_gpu_download_active.argtypes = [C.c_void_p, C.c_void_p]
         L.nlps_gpu_status_flags.argtypes = [C.c_void_p, _ip]
         L.nlps_gpu_active_masks.argtypes = [C.c_void_p, C.POINTER(Bcc), C.c_int, C.c_int, _ip, _ip, _ip, _ip]
@@ -396,6 +397,14 @@ class Solver:
         lst = np.zeros((self.np, MAXNB), dtype=np.int32)
         self._chk(self.L.nlps_gpu_download_lists(self.h, _i(nn), _i(lst)))
         return nn, lst
+
+    def shape_functions(self, first=0, count=None):
+        """N[count][MAXNB] and dN[count][MAXNB][ndim] of particles first .. first + count - 1 in the order of their lists."""
+        count = self.np - first if count is None else count
+        N = np.zeros((count, MAXNB))
+        dN = np.zeros((count, MAXNB, self.ndim))
+        self._chk(self.L.nlps_gpu_shape_functions(self.h, int(first), int(count), _vp(N), _vp(dN)))
+        return N, dN
 
     def download_active(self):
         a = np.zeros(self.nnodes, dtype=np.uint8)

@@ -1521,3 +1521,46 @@ def test_folded_step_matches_the_nodal_kernels(monkeypatch, ndim, material):
     for k in ("mass", "dU", "force", "accel", "reaction"):
         assert_close(na[k], nb[k], 1e-10, f"nodal {k}: folded step vs nodal kernels", scale=1e-12)
     assert np.abs(nb["reaction"]).max() > 0.0 and np.abs(nb["dU"]).max() > 0.0
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_shape_functions_level_a(ndim):
+    """compute_N__ShapeFun__ / compute_dN__ShapeFun__ for the LME family (p__LME__, dp__LME__): the values and gradients
+    themselves, in the order of every particle's list, after the initial search and again after the cloud has moved
+    (new lambda, new masks)."""
+    o = orc()
+    nsteps, dt = 4, 1e-4
+    v = [3.0, -10.0] if ndim == 2 else [3.0, 1.0, -10.0]
+    case = small_case(ndim, velocity=v)
+    M, P, prm, mats = oracle_setup(case)
+    S = gpu_setup(case, nsteps=nsteps)
+
+    def compare(what):
+        nn, lst = S.download_lists()
+        assert np.array_equal(nn, P["nn"]) and lists_equal(nn, lst, P["list"])
+        N, dN = S.shape_functions()
+        first = max(0, S.np - 40)
+        Nt, dNt = S.shape_functions(first, S.np - first)  # a range that does not start at 0
+        assert np.array_equal(Nt, N[first:]) and np.array_equal(dNt, dN[first:])
+        worst_n = worst_d = 0.0
+        for p in range(0, S.np, 7):
+            n_ref, d_ref = o.compute_N(P, M, p), o.compute_dN(P, M, p)
+            k = n_ref.shape[0]
+            assert k == nn[p]
+            worst_n = max(worst_n, float(np.max(np.abs(N[p, :k] - n_ref))))
+            worst_d = max(worst_d, float(np.max(np.abs(dN[p, :k] - d_ref)) / np.max(np.abs(d_ref))))
+            assert not N[p, k:].any() and not dN[p, k:].any()
+            assert abs(N[p, :k].sum() - 1.0) < 1e-12
+        assert worst_n < 1e-11, f"{what}: N differs by {worst_n:.2e}"
+        assert worst_d < 1e-9, f"{what}: dN differs by {worst_d:.2e} of its magnitude"
+
+    compare("after initialize__LME__")
+    n = nlps()
+    gb = n.BccSet([dirichlet_plane(case, ndim - 1, 2, nsteps)])
+    stepper = o.ExplicitStepper(P, M, mats, prm, o.BccSet([dirichlet_plane(case, ndim - 1, 2, nsteps)]), nsteps)
+    for t in range(nsteps):
+        assert stepper.step(t, dt) == 0
+        S.explicit_step(gb, t, dt)
+    o.local_search(P, M, prm)
+    S.local_search()
+    compare("after four explicit steps and a search")
