@@ -3950,8 +3950,9 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   };
   // Folded form (k3_tile_lazy / k5_tile_lazy): one GPU without a ghost exchange, one law, the Dirichlet sets small enough
   // to travel as kernel arguments: no nodal kernels between the stages (made later if somebody asks for the nodal arrays)
-  // (measured: 1 % faster per step at 1 M particles -- three launches less -- and 1.2 % slower at 8 M, where the window
-  // loads of 17 k tiles redo the two divisions per node 16 times over: on below 2 M particles, NLPS_LAZY_NODAL=2 always)
+  // (measured: 3 % faster per step at 1 M particles -- three launches less -- and equal within the noise at 4 M and 8 M,
+  // where the window loads of 17 k tiles redo the two divisions per node 16 times over: on below 2 M particles,
+  // NLPS_LAZY_NODAL=2 always)
   const bool lazy = (h->lazy_nodal == 2 || (h->lazy_nodal == 1 && h->P.np <= 2000000)) && fuse && h->fuse_search == 1 && !det && !h->rccl && !h->halo && h->uniform_law >= 0 &&
                     h->uniform_law <= NLPS_KLAW_FRICTIONAL && nbcc <= NLPS_MAX_BC_INLINE;
   LazyNodal ln;

@@ -628,15 +628,20 @@ __device__ __forceinline__ double coherent_load(const double* p) {
 __device__ __forceinline__ double nodal_load(const FusedStep& fs, const double* p) { return fs.plain_loads ? *p : coherent_load(p); }
 template <int ND>
 __device__ __forceinline__ void fused_nodal_dU(const NView& N, const FusedStep& fs, int A, double* val, bool* fix) {
+  // every operand is requested before the first one is looked at (one round of latency instead of three)
   const double M = nodal_load(fs, N.nm + (size_t)A * (1 + ND));
+  double mom[ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) mom[a] = nodal_load(fs, N.nm + (size_t)A * (1 + ND) + 1 + a);
   const bool active = N.active[A];
+  const unsigned bm0 = fs.bcmask ? fs.bcmask[A] : 0u;
   const bool act = active && M != 0.0;
 #pragma unroll
   for (int a = 0; a < ND; a++) {
-    val[a] = act ? nodal_load(fs, N.nm + (size_t)A * (1 + ND) + 1 + a) / M : 0.0;
+    val[a] = act ? mom[a] / M : 0.0;
     fix[a] = false;
   }
-  const unsigned bm = (fs.bcmask && active) ? fs.bcmask[A] : 0u;
+  const unsigned bm = active ? bm0 : 0u;
   if (bm) {
     for (int i = 0; i < fs.bc.n; i++) {
       if (!((bm >> i) & 1u)) continue;
@@ -655,11 +660,16 @@ __device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedSte
   double dU[ND];
   bool fix[ND];
   const double M = nodal_load(fs, N.nm + (size_t)A * (1 + ND));
-  const bool act = N.active[A] && M != 0.0;
+  double f[ND];
+#pragma unroll
+  for (int a = 0; a < ND; a++) f[a] = nodal_load(fs, N.force + (size_t)A * ND + a);
+  const bool active = N.active[A];
+  const unsigned bm0 = fs.bcmask ? fs.bcmask[A] : 0u;
+  const bool act = active && M != 0.0;
   (void)dU;
 #pragma unroll
   for (int a = 0; a < ND; a++) fix[a] = false;
-  const unsigned bm = (fs.bcmask && N.active[A]) ? fs.bcmask[A] : 0u;
+  const unsigned bm = active ? bm0 : 0u;
   if (bm) {
     for (int i = 0; i < fs.bc.n; i++) {
       if (!((bm >> i) & 1u)) continue;
@@ -670,7 +680,7 @@ __device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedSte
   }
 #pragma unroll
   for (int a = 0; a < ND; a++)
-    acc[a] = (act && !fix[a]) ? fs.gv[a] + nodal_load(fs, N.force + (size_t)A * ND + a) / M : 0.0;
+    acc[a] = (act && !fix[a]) ? fs.gv[a] + f[a] / M : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
