@@ -468,8 +468,8 @@ __device__ __forceinline__ void store_block(const PView& P, int f0, int p, const
 // stored inputs when a level-B stage or a download asks (80 B per particle less to store in K3).
 template <int ND, int LAW = -1, bool CEP = false, bool FRIC = (LAW == NLPS_KLAW_FRICTIONAL), bool LAZY = false>
 __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* __restrict__ mats, const ParamsD& prm,
-                                             const double* Fn1, const double* DF, double J, double* tau) {
-  MatD m = mats[P.mat[p]];
+                                             const double* Fn1, const double* DF, double J, double* tau, int mat_idx = -1) {
+  MatD m = mats[mat_idx >= 0 ? mat_idx : P.mat[p]];  // (mat_idx: the caller has read the particle's material index already)
   StressIO<ND> o;
   o.fail = 0;
   o.kappa = 0.0;

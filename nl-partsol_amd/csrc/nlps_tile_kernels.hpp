@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256) void k_tile_order(PView P, GridD g, TileD td, 
 #ifndef NLPS_K3_TWOPASS_ALL
 #define NLPS_K3_TWOPASS_ALL 0
 #endif
+#ifndef NLPS_K3_PRELOAD_FN
+#define NLPS_K3_PRELOAD_FN 0  // measured: 40 B of scratch appear, K3 0.213 -> 0.217 ms
+#endif
 #ifndef NLPS_K3_RELOAD
 #define NLPS_K3_RELOAD 1
 #endif
@@ -1103,6 +1106,9 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     Lme<ND> c;
     double lam[ND], beta;
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
+    // (requested with the particle's other operands: the constants of its material are then one load away, not two, when
+    // the stress update asks for them behind the gather)
+    const int mat_idx = (MODE == 1) ? P.mat[p] : -1;
     const int base = window_base<ND>(c.ijk, w0);
     NLPS_YZ_LOCALS(c);
     PH(9)
@@ -1126,6 +1132,11 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     // (the level-B modes keep the single pass: with and without rate tensors they must give the same F bit for bit)
     // and the laws that stay at two waves per SIMD keep it too: there the second set of masked weights only costs)
     constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && (K3Waves<ND, LAW, MODE>::value >= 3 || NLPS_K3_TWOPASS_ALL);
+    // NLPS_K3_PRELOAD_FN (off): F_n requested between the two passes -- the moments pass touches no memory and keeps fewer
+    // values alive than the gather, so the nine loads would land under it instead of in front of the F update; at 168
+    // registers the nine values do not fit beside it (40 B of scratch, 2 % slower)
+    constexpr bool PRELOAD_FN = TWOPASS && (NLPS_K3_PRELOAD_FN != 0);
+    double Fn[ND * ND], fzz = 0.0;
     if (TWOPASS) {
 #pragma unroll 1
       for (int k = 0; k < KN; k++) {
@@ -1168,6 +1179,11 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
             U[a] = fma(w00, R0[a], U[a]);
           }
         }
+      }
+      if (PRELOAD_FN) {
+        int pm = p;
+        asm volatile("" : "+v"(pm));
+        load_block<ND>(P, fFN(P), pm, Fn, fzz);
       }
 #pragma unroll 1
       for (int k = 0; k < KN; k++) {
@@ -1382,7 +1398,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     int st = 0;
     if (!inverse<ND>(Jm1, J)) st |= ST_NEWTON;
     // DF = I + sum_A dU_A (x) grad N_A = I - (G/Z) J^-T            (compute-Strains.c:20-44)
-    double DF[ND * ND], Fn[ND * ND], Fn1[ND * ND], fzz;
+    double DF[ND * ND], Fn1[ND * ND];
 #pragma unroll
     for (int i = 0; i < ND; i++)
 #pragma unroll
@@ -1392,7 +1408,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
         for (int m = 0; m < ND; m++) v = fma(G[i * ND + m] * Zinv, Jm1[j * ND + m], v);
         DF[i * ND + j] = ((i == j) ? 1.0 : 0.0) - v;
       }
-    load_block<ND>(P, fFN(P), pl, Fn, fzz);
+    if (!PRELOAD_FN) load_block<ND>(P, fFN(P), pl, Fn, fzz);
 #pragma unroll
     for (int i = 0; i < ND; i++)
 #pragma unroll
@@ -1450,7 +1466,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
 #pragma unroll
     for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, pl) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
     double tau[ND * ND], B[ND * ND];
-    st |= stress_update<ND, LAW, false, (LAW == NLPS_KLAW_FRICTIONAL), true>(P, pl, mats, prm, Fn1, DF, Jn1, tau);
+    st |= stress_update<ND, LAW, false, (LAW == NLPS_KLAW_FRICTIONAL), true>(P, pl, mats, prm, Fn1, DF, Jn1, tau, mat_idx);
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), -1.0);
     PH(11)
     if (fo_ok) {
