@@ -3350,6 +3350,7 @@ static int ensure_bcs(nlps_gpu* h, const nlps_bcc* bcc, int nbcc) {
   bool same = (int)h->bcs.size() == nbcc;
   for (int i = 0; same && i < nbcc; i++) same = h->bcs[i].host_nodes == bcc[i].nodes && h->bcs[i].n == bcc[i].nnodes;
   if (same) return 0;
+  if (materialise_nodal(h)) return 1;  // (the nodal arrays of the last folded step still want the old sets' mask)
   for (auto& b : h->bcs)
     if (b.dnodes) (void)hipFree(b.dnodes);
   h->bcs.clear();
