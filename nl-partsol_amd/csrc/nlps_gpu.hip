@@ -3790,7 +3790,35 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (ND == 2) hipLaunchKernelGGL((k_slab_gather<2, 2>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
     else hipLaunchKernelGGL((k_slab_gather<3, 3>), dim3(nblk(r.an + r.bn)), dim3(BLK), 0, h->stream, r.a0, r.an, r.b0, r.bn, h->g, td, h->N.force);
   };
+  const bool fuse_early = h->fuse_search && h->P.np > 0;
+  // Folded form (k3_tile_lazy / k5_tile_lazy): one law, the Dirichlet sets small enough to travel as kernel arguments:
+  // no nodal kernels between the stages (dU, accelerations, reactions are made later if somebody asks).  With a ghost
+  // exchange too, in every overlap form: a K3 / K5 launch comes behind the pick-up of the exchange its nodes need (interior
+  // tiles never touch a band node), exactly where the nodal kernel of its node range stood.
+  // (measured: 3 % faster per step at 1 M particles -- three launches less -- and equal within the noise at 4 M and 8 M,
+  // where the window loads of 17 k tiles redo the two divisions per node 16 times over: on below 2 M particles,
+  // NLPS_LAZY_NODAL=2 always)
+  const bool lazy = (h->lazy_nodal == 2 || (h->lazy_nodal == 1 && h->P.np <= 2000000)) && fuse_early && h->fuse_search == 1 && !det && h->uniform_law >= 0 &&
+                    h->uniform_law <= NLPS_KLAW_FRICTIONAL && nbcc <= NLPS_MAX_BC_INLINE;
+  LazyNodal ln;
+  if (lazy) {
+    memset(&ln, 0, sizeof ln);
+    ln.fs.bc.n = nbcc;
+    for (int i = 0; i < nbcc; i++) {
+      ln.fs.bc.dim[i] = bcc[i].dim;
+      ln.fs.bc.bits[i] = h->bcs[i].n > 0 ? dirbits_of(bcc[i], step, h->nsteps) : 0;
+      for (int k = 0; k < 3; k++) ln.fs.bc.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
+    }
+    ln.fs.bcmask = nbcc > 0 ? h->bcmask_d : nullptr;
+    ln.fs.plain_loads = 1;
+    for (int a = 0; a < 3; a++) ln.fs.gv[a] = gv[a];
+    ln.n0 = h->n0;
+    ln.nwn = h->nwn;
+    ln.node_cnt = node_lists(h) ? h->node_cnt_d : nullptr;
+    ln.ntw = h->ntw;  // (ln.tile_count: after search_and_lists, which swaps the two counter arrays)
+  }
   auto nodal_dU = [&](int part) {
+    if (lazy) return;  // (K3 makes dU of its window nodes itself)
     const NodeRanges r = node_ranges(h, part);
     if (r.an + r.bn == 0) return;
     BcStep bs;
@@ -3828,6 +3856,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   const bool fuse = h->fuse_search && h->P.np > 0;
   bool tiles_cleared = false;
   auto nodal_accel = [&](int part) {
+    if (lazy) return;  // (K5 makes the accelerations itself; K3's workgroups have reset the search accumulators)
     const NodeRanges r = node_ranges(h, part);
     const bool fbin = fuse && h->fuse_search == 1;
     int* ctile = (fbin && !tiles_cleared) ? h->tile_count2_d + h->tile0 : nullptr;
@@ -3949,32 +3978,10 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     }
 #undef NLPS_K5
   };
-  // Folded form (k3_tile_lazy / k5_tile_lazy): one GPU without a ghost exchange, one law, the Dirichlet sets small enough
-  // to travel as kernel arguments: no nodal kernels between the stages (made later if somebody asks for the nodal arrays)
-  // (measured: 3 % faster per step at 1 M particles -- three launches less -- and equal within the noise at 4 M and 8 M,
-  // where the window loads of 17 k tiles redo the two divisions per node 16 times over: on below 2 M particles,
-  // NLPS_LAZY_NODAL=2 always)
-  const bool lazy = (h->lazy_nodal == 2 || (h->lazy_nodal == 1 && h->P.np <= 2000000)) && fuse && h->fuse_search == 1 && !det && !h->rccl && !h->halo && h->uniform_law >= 0 &&
-                    h->uniform_law <= NLPS_KLAW_FRICTIONAL && nbcc <= NLPS_MAX_BC_INLINE;
-  LazyNodal ln;
-  if (lazy) {
-    memset(&ln, 0, sizeof ln);
-    ln.fs.bc.n = nbcc;
-    for (int i = 0; i < nbcc; i++) {
-      ln.fs.bc.dim[i] = bcc[i].dim;
-      ln.fs.bc.bits[i] = h->bcs[i].n > 0 ? dirbits_of(bcc[i], step, h->nsteps) : 0;
-      for (int k = 0; k < 3; k++) ln.fs.bc.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
-    }
-    ln.fs.bcmask = nbcc > 0 ? h->bcmask_d : nullptr;
-    ln.fs.plain_loads = 1;
-    for (int a = 0; a < 3; a++) ln.fs.gv[a] = gv[a];
-    ln.n0 = h->n0;
-    ln.nwn = h->nwn;
-    ln.node_cnt = node_lists(h) ? h->node_cnt_d : nullptr;
-    ln.ntw = h->ntw;  // (ln.tile_count: after search_and_lists, which swaps the two counter arrays)
-  }
-  auto launch_k3_lazy = [&]() {
-    const TileD td = tile_view(h, 0);
+  auto launch_k3_lazy = [&](int cls, bool signal) {
+    TileD td = tile_view(h, cls);
+    if (signal) arm_signal(h, td, 1);
+    ln.tile_count = h->tile_count2_d + h->tile0;  // (after search_and_lists, which swaps the two counter arrays)
 #define NLPS_K3L(NDv, LAWv)                                                                                              \
   hipLaunchKernelGGL((k3_tile_lazy<NDv, LAWv>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
                      h->mats_d, h->prm, h->gstatus_d, ln)
@@ -3994,11 +4001,13 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     }
 #undef NLPS_K3L
   };
-  auto launch_k5_lazy = [&]() {
-    const TileD td = tile_view(h, 0);
-    ks.tc = tile_cnt(h, true);
-    ks.tc.count = h->tile_count2_d;
-    ks_made = true;
+  auto launch_k5_lazy = [&](int cls) {
+    const TileD td = tile_view(h, cls);
+    if (!ks_made) {  // (one TileCnt per step: it consumes the re-home flag of the adaptive re-sort)
+      ks.tc = tile_cnt(h, true);
+      ks.tc.count = h->tile_count2_d;
+      ks_made = true;
+    }
 #define NLPS_K5L(NDv, LAWv)                                                                                             \
   hipLaunchKernelGGL((k5_tile_lazy<NDv, LAWv>), dim3(h->ntw * K5_SPLIT), dim3(K5_BLK), 0, h->stream, h->P, h->g, h->N, td, \
                      dt, gamma_nm, ks, ln, h->gstatus_d)
@@ -4011,6 +4020,14 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else NLPS_K5L(3, 2);
     }
 #undef NLPS_K5L
+  };
+  auto k3 = [&](int cls, bool signal = false) {
+    if (lazy) launch_k3_lazy(cls, signal);
+    else launch_k3(cls, signal);
+  };
+  auto k5 = [&](int cls) {
+    if (lazy) launch_k5_lazy(cls);
+    else launch_k5(cls);
   };
   // One launch for K2, K3 and K5 (k_step_fused): one GPU without a ghost exchange, 3-D, one law, the Dirichlet sets
   // small enough to travel as kernel arguments.  The nodal kernels between the stages run lazily, only when somebody
@@ -4059,6 +4076,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     fs.trace = nullptr;
     fs.nofence = 0;
     fs.plain_loads = 0;
+    fs.persistent = 1;
     if (const char* e = getenv("NLPS_FUSED_NOFENCE")) fs.nofence = atoi(e);
     static int* trace_h = nullptr;
     if (getenv("NLPS_FUSED_TRACE")) {
@@ -4133,36 +4151,27 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   // the node window are reset by k_step_clear inside search_and_lists)
   if (search_and_lists(h, false, true, dt, gamma_nm, ov2 ? 2 : (ov ? 1 : 0))) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-  if (lazy) {
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    ln.tile_count = h->tile_count2_d + h->tile0;
-    launch_k3_lazy();
-    HIPCHK(hipGetLastError());
-    if (h->timing) {
-      HIPCHK(hipEventRecord(h->ev[4], h->stream));
-      HIPCHK(hipEventRecord(h->ev[5], h->stream));
-    }
-    launch_k5_lazy();
-    HIPCHK(hipGetLastError());
+  if (lazy) {  // (what nlps_gpu_explicit_nodal needs to make the nodal arrays of this step later)
     h->nodal_stale = true;
     h->last_bc = ln.fs.bc;
     h->last_bm = ln.fs.bcmask;
     for (int a = 0; a < 3; a++) h->last_gv[a] = gv[a];
-  } else if (ov2) {
+  }
+  if (ov2) {
     // mode 2: K2 is in flight as ONE launch; its boundary tiles release the exchange of the shared layers of nm, which
     // runs beside its interior tiles; the handle's stream picks the result up before the nodal kernel
     if (halo(h, h->N.nm, 1 + ND, 8, 0, 3)) return 1;
     if (halo(h, h->N.nm, 1 + ND, 8, 0, 2)) return 1;
     nodal_dU(0);
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    launch_k3(0, true);
+    k3(0, true);
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
     if (halo(h, h->N.force, ND, 8, 0, 4)) return 1;
     if (halo(h, h->N.force, ND, 8, 0, 2)) return 1;
     nodal_accel(0);
     if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
-    launch_k5(0);
+    k5(0);
     HIPCHK(hipGetLastError());
   } else {
   // with ghost bands the shared layers are gathered first (only boundary tiles reach them) and go on their way
@@ -4175,14 +4184,14 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     nodal_dU(1);
     // timing brackets: the K3 bucket starts before the interior tiles (the band nodes' dU then counts as K3 time)
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    launch_k3(2);
+    k3(2);
     if (halo(h, h->N.nm, 1 + ND, 8, 0, 2)) return 1;
     nodal_dU(2);
-    launch_k3(1);
+    k3(1);
   } else {
     nodal_dU(0);
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    launch_k3(0);
+    k3(0);
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[4], h->stream));
@@ -4193,14 +4202,14 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     gather_force(1);
     nodal_accel(1);
     if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
-    launch_k5(2);
+    k5(2);
     if (halo(h, h->N.force, ND, 8, 0, 2)) return 1;
     nodal_accel(2);
-    launch_k5(1);
+    k5(1);
   } else {
     nodal_accel(0);
     if (h->timing) HIPCHK(hipEventRecord(h->ev[5], h->stream));
-    launch_k5(0);
+    k5(0);
   }
   HIPCHK(hipGetLastError());
   }  // !ov2

@@ -578,6 +578,7 @@ struct FusedStep {
   int* trace;            // developer switch NLPS_FUSED_TRACE: host-visible progress marks, 8 ints per workgroup
   int nofence;           // developer switch NLPS_FUSED_NOFENCE (timing experiments): 1 no release, 2 no acquire
   int plain_loads;       // the nodal sums were flushed by an EARLIER launch (k3_tile_lazy, k5_tile_lazy): ordinary loads do
+  int persistent;        // 1 inside k_step_fused (tiles publish per-tile flags, no exchange signal); 0 in the folded step
   const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
   BcStep bc;             // their components and values at this step
   double gv[3];          // gravity
@@ -943,7 +944,7 @@ __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NV
     }
   }
   PH(5)
-  if (!fs) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
+  if (!fs || !fs->persistent) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
 }
 // NT / SPLIT: threads per workgroup and workgroups per tile.  The default is (BLK, K2_SPLIT); deterministic mode runs one
 // wave per tile (64, 1): the sorted tile list is then accumulated in list order by a single instruction stream.
@@ -1572,7 +1573,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     }
   }
   PH(14)
-  if (!fs) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
+  if (!fs || !fs->persistent) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
 }
 template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
 __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value))) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
@@ -1627,10 +1628,12 @@ __global__ __launch_bounds__(K3_BLK, (K3Waves<ND, LAW, 1>::value)) void k3_tile_
       if (ln.node_cnt) ln.node_cnt[ln.n0 + i] = 0;
     }
   }
+  const int nbnd = td.sig_flag ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;  // (overlap mode 2, as k3_tile)
+  tile_signal_empty(td, nbnd);
   TileWork tw;
   if (!tile_work_item<K3_SPLIT>(td, tw)) return;
   const L lds{dvxy, dvz, duxy, duz, fac, sel, &nsel, wcnt};
-  k3_body<ND, LAW, 1, false, K3_BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, 0, lds, &ln.fs);
+  k3_body<ND, LAW, 1, false, K3_BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, nbnd, lds, &ln.fs);
 }
 
 // Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)
@@ -1924,7 +1927,8 @@ FUSED_STAGE void fused_stage_k2(const FusedArgs* a, int wb, int tile, double* sh
   TileWork tw{tile, 0, 1, wb};
   FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(ParamsD, prm, prm)
   FUSED_GET(double, dt, dt) FUSED_GET(double, gamma_nm, gamma_nm) FUSED_GET(IntPtr, gstatus, gstatus)
-  FusedStep fs;  // (K2 only asks whether it is there)
+  FusedStep fs;  // (K2 only asks whether it is there and persistent)
+  fs.persistent = 1;
   k2_body<ND, true, BLK>(P, g, N, td, prm, dt, gamma_nm, gstatus, tw, 0, sh, reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA), &fs);
 }
 template <int ND, int LAW>
