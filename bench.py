@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 # algorithmic bytes per particle per stage, FP64, 3-D (SURVEY.md §8d / BASELINE.md §3.4)
 BYTES_3D = {"S1": 100, "S2": 123, "S3": 371, "S4": 215, "S5": 408, "step": 1217}
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PARTITION_TOL = 1e-9        # partitioned vs whole cloud (max relative field error): ONE constant for the step-down and the abort
 FP64_VEC_PEAK_TFLOPS = 78.6  # half the 157.3 TF FP32 vector peak
 
 
@@ -448,7 +449,7 @@ def partition_check(ctx):
     while True:  # an overlapped exchange form whose partitioned run disagrees with the whole cloud is stepped down, 2 -> 1 -> 0
         res, info = _partition_run(ctx, case, cells, margin, nsteps, dt, bcs, want, ref)
         ref = res.pop("ref")
-        good = res["max_rel_err"] <= 1e-8 and res["index_maps_equal"] and not (res["status_flags"] & ST_HALO)
+        good = res["max_rel_err"] <= PARTITION_TOL and res["index_maps_equal"] and not (res["status_flags"] & ST_HALO)
         tried.append({"halo_overlap_mode": info["halo_overlap_mode"], "ok": bool(good)})
         mode_now = info["halo_overlap_mode"] or 0
         if good or mode_now == 0:
@@ -637,13 +638,17 @@ def main():
     ctx = Ctx(a)
     rank, world = ctx.rank, ctx.world
     check = partition_check(ctx) if world > 1 and not a.no_partition_check else None
-    if check is not None and (check["max_rel_err"] > 1e-9 or not check["index_maps_equal"] or check["status_flags"]):
+    if check is not None and (check["max_rel_err"] > PARTITION_TOL or not check["index_maps_equal"] or check["status_flags"]):
         raise SystemExit("bench: the partitioned run does not reproduce the single-solver run: %r" % check)
     rec, case, kms = run_config(ctx, a.scaling)
     other = "strong" if a.scaling == "weak" else "weak"
-    rec_other = None
+    rec_other, other_skipped = None, None
     if not a.no_second_scaling:
-        rec_other, _, _ = run_config(ctx, other, with_kernels=world > 1)
+        if other == "strong" and int(round((a.particles_total / 8.0) ** (1.0 / 3.0))) < 8 * world:
+            # (too few cell layers for this many ranks: the primary record stands, the second is left out and says why)
+            other_skipped = "--particles-total %d gives fewer than 8 cell layers per rank at %d ranks" % (a.particles_total, world)
+        else:
+            rec_other, _, _ = run_config(ctx, other, with_kernels=world > 1)
     stirred = None
     second = None
     if world == 1 and not a.no_stirred:
@@ -721,6 +726,8 @@ def main():
         }
         if rec_other is not None:
             out[other] = rec_other
+        elif other_skipped:
+            out[other] = {"skipped": other_skipped}
         if check is not None:
             out["partition_check"] = check
         if stirred is not None:

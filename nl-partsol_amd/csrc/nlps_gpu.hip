@@ -156,7 +156,7 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
     if (s_lo < tc.win_lo || s_hi > tc.win_hi) {
       // flagged AND left out of the lists: its stencil holds nodes nothing of this rank resets or exchanges (the per-node
       // counters of the canonical lists among them), so no kernel may take it; it keeps its state, the re-sort keeps it
-      // (k_append_unbinned), a migration hands it on
+      // (k_append_unlisted), a migration hands it on
       atomicOr(&P.status[p], ST_HALO);
       atomicOr(tc.gstatus, ST_HALO);
       t = -1;
@@ -209,17 +209,6 @@ __device__ __forceinline__ int class3_of(const GridD& g, const int* ijk) {
     mul *= 3;
   }
   return c;
-}
-
-// in front of k_step_fused: its queue head, and what the search that rides on its K5 stage accumulates into
-__global__ void k_fused_prep(int n0, int nnodes, unsigned char* __restrict__ seed, int* __restrict__ node_cnt,
-                             int* __restrict__ tile_count, int ntiles, unsigned* __restrict__ q_head) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) *q_head = 0u;
-  if (t < ntiles) tile_count[t] = 0;
-  if (t >= nnodes) return;
-  seed[(size_t)n0 + t] = 0;
-  if (node_cnt) node_cnt[(size_t)n0 + t] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1322,15 +1311,20 @@ __global__ void k_scatter(T* __restrict__ out, const T* __restrict__ in, const i
   if (i < n) out[idx[i]] = in[i];
 }
 
-// The tile lists only hold the particles the search could bin (tile >= 0).  Before the lists serve as the permutation
-// of a re-sort, the particles it flagged instead (ST_CONNECT, ST_HALO: tile = -1) are appended behind them, so the
-// permutation covers the whole cloud whatever the status word says (a flagged particle carries no order-dependent
-// sum: the positions among themselves come from a counter).
-// last_start / last_count: scan entry of the last tile of the node window (their sum = number of binned particles).
-__global__ void k_append_unbinned(int np, const int* __restrict__ tile, const int* __restrict__ last_start,
+// Periodic re-sort with the tile lists as the permutation: the particles that are in NO list of the step that built the
+// lists (flagged by its search instead of binned: failed element search, stencil outside the node window) go behind them.
+// Membership is read off the lists themselves -- P.tile[] may already belong to the NEXT step (the search k5_tile runs
+// ahead), so "tile < 0" would miss a particle that was listed and is flagged now, and count one twice.
+__global__ void k_mark_listed(int np, const int* __restrict__ last_start, const int* __restrict__ last_count,
+                              const int* __restrict__ order, unsigned char* __restrict__ listed) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = min(np, *last_start + *last_count);
+  if (q < total) listed[order[q]] = 1;
+}
+__global__ void k_append_unlisted(int np, const unsigned char* __restrict__ listed, const int* __restrict__ last_start,
                                   const int* __restrict__ last_count, int* __restrict__ counter, int* __restrict__ order) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= np || tile[p] >= 0) return;
+  if (p >= np || listed[p]) return;
   const int pos = *last_start + *last_count + atomicAdd(counter, 1);
   if (pos < np) order[pos] = p;
 }
@@ -1398,17 +1392,7 @@ struct nlps_gpu {
   // counters of that search are in place, the next explicit step starts at the activation kernel.
   bool searched = false, ahead = false;
   int fuse_search = 1;  // developer switch NLPS_FUSE_SEARCH
-  // k_step_fused (one launch for K2, K3, K5): queue head + per-tile flags, the step's sequence number, what the lazily
-  // run nodal kernels need to reproduce dU / accelerations / reactions for nlps_gpu_explicit_nodal
-  // OFF: on the GPU boxes of round 3 the launch never completed once a second stage had items, even with the stage bodies
-  // and every wait and publish taken out (while tools/fused_sync_test.hip, the same skeleton without the physics, ran
-  // in 0.1 ms): unfinished, kept behind the developer switch NLPS_FUSED_STEP=1 ("k_step_fused")
   int lazy_nodal = 1;  // the folded explicit step (k3_tile_lazy / k5_tile_lazy): 1 below 2 M particles, 2 always, 0 never (NLPS_LAZY_NODAL)
-  int fused_step = 0;
-  unsigned* fused_q_d = nullptr;
-  struct FusedArgs* fused_args_d = nullptr;
-  unsigned* fused_done_d = nullptr;  // [2][ntiles]
-  unsigned fused_seq = 0;
   int ncu = 256;
   bool nodal_stale = false;
   BcStep last_bc;
@@ -1523,6 +1507,7 @@ struct nlps_gpu {
   } while (0)
 
 static inline int nblk(int n, int b = BLK) { return n > 0 ? (n + b - 1) / b : 1; }
+static int materialise_nodal(nlps_gpu* h);  // the nodal arrays the folded explicit step left unmade (defined with the step)
 
 static bool is_device_ptr(const void* p) {
   hipPointerAttribute_t a;
@@ -1682,7 +1667,9 @@ extern "C" int nlps_gpu_set_node_window(nlps_gpu* h, int layer_lo, int layer_hi)
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   apply_window(h, layer_lo, layer_hi);
-  // clean slate outside the new window (nothing resets those nodes any more)
+  // clean slate outside the new window (nothing resets those nodes any more); the nodal results of an explicit step
+  // before this call are gone with it, made or not
+  h->nodal_stale = false;
   const size_t nn = (size_t)h->g.nnodes, ND = (size_t)h->nd;
   HIPCHK(hipMemsetAsync(h->N.active, 0, nn, h->stream));
   HIPCHK(hipMemsetAsync(h->N.seed, 0, nn, h->stream));
@@ -1714,6 +1701,7 @@ extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_phases(nlps
 #endif
 
 extern "C" int nlps_gpu_set_ghost_bands(nlps_gpu* h, int band_lo, int band_hi, int overlap) {
+  if (materialise_nodal(h)) return 1;  // (the node ranges of the last step's nodal kernels are about to change)
   h->band_lo = band_lo;
   h->band_hi = band_hi;
   if (overlap == 2 && !h->rccl_wait_value) {
@@ -1827,11 +1815,12 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   h->prm.max_iter_radial = prm->max_iter_radial_returning;
   h->P.erosion = prm->driver_eigenerosion != 0 || prm->driver_eigensoftening != 0;
   h->P.softening = prm->driver_eigensoftening != 0 && prm->driver_eigenerosion == 0;
-  if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // developer switch, see k_tile_order
+#if NLPS_DEV  // developer builds only (tools/build_variant.sh): the shipped library reads no environment variable
+  if (const char* e = getenv("NLPS_TILE_ORDERING")) h->tile_ordering = atoi(e);  // see k_tile_order
   if (const char* e = getenv("NLPS_RESORT_FROM_LISTS")) h->resort_from_lists = atoi(e);
   if (const char* e = getenv("NLPS_FUSE_SEARCH")) h->fuse_search = atoi(e);
-  if (const char* e = getenv("NLPS_FUSED_STEP")) h->fused_step = atoi(e);
   if (const char* e = getenv("NLPS_LAZY_NODAL")) h->lazy_nodal = atoi(e);
+#endif
   {
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
@@ -1977,8 +1966,10 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->work1_d, (size_t)h->ntiles)) return 1;
   if (dev_alloc(h, &h->work2_d, (size_t)h->ntiles * 2)) return 1;
   if (dev_alloc(h, &h->nwork_d, 16)) return 1;
-  if (const char* e = getenv("NLPS_ADAPTIVE_RESORT")) h->adaptive_resort = atof(e);  // developer switch (0 = off)
+#if NLPS_DEV
+  if (const char* e = getenv("NLPS_ADAPTIVE_RESORT")) h->adaptive_resort = atof(e);  // (0 = off)
   if (const char* e = getenv("NLPS_NODE_LISTS")) h->node_lists_on = atoi(e);
+#endif
   if (dev_alloc(h, &h->node_cnt_d, (size_t)h->g.nnodes)) return 1;
   if (dev_alloc(h, &h->nrank_d, h->P.npad)) return 1;
   {
@@ -2090,10 +2081,14 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, bytes, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d, np, 0, 64,
                                               h->stream));
   }
-  if (from_lists) {  // particles the search flagged instead of binning go behind the lists (k_append_unbinned)
+  if (from_lists) {  // particles that are in no list go behind the lists (k_mark_listed / k_append_unlisted)
+    unsigned char* listed = reinterpret_cast<unsigned char*>(h->gather_tmp);  // [npad] bytes of the gather scratch, idle here
     HIPCHK(hipMemsetAsync(h->mig_cnt_d, 0, sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(listed, 0, (size_t)np, h->stream));
     const int last = h->tile0 + h->ntw - 1;
-    hipLaunchKernelGGL(k_append_unbinned, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, (const int*)h->P.tile,
+    hipLaunchKernelGGL(k_mark_listed, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, (const int*)h->tile_start_d + last,
+                       (const int*)h->tile_count_d + last, (const int*)h->order2_d, listed);
+    hipLaunchKernelGGL(k_append_unlisted, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, (const unsigned char*)listed,
                        (const int*)h->tile_start_d + last, (const int*)h->tile_count_d + last, h->mig_cnt_d, h->order2_d);
   }
   const int* idx = from_lists ? h->order2_d : h->sval2_d;  // new slot -> old slot
@@ -2265,6 +2260,22 @@ extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_set_tile_or
   h->ahead = false;
   return 0;
 }
+// Developer / test switches as an explicit call (never read from the environment in the shipped build): which of the
+// equivalent launch forms a handle uses.  Not part of include/nlps_gpu.h.  Results do not depend on any of them.
+extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_option(nlps_gpu* h, const char* name, double value) {
+  const std::string k(name ? name : "");
+  if (k == "lazy_nodal") h->lazy_nodal = (int)value;             // folded explicit step: 0 never, 1 below 2 M particles, 2 always
+  else if (k == "fuse_search") h->fuse_search = (int)value;      // the next step's search on K5: 0 off, 1 with binning, 2 without
+  else if (k == "resort_from_lists") h->resort_from_lists = (int)value;
+  else if (k == "node_lists") h->node_lists_on = (int)value;
+  else if (k == "tile_ordering") h->tile_ordering = (int)value;
+  else {
+    h->err = "nlps_gpu_debug_option: unknown option " + k;
+    return 1;
+  }
+  h->ahead = false;  // (lists made under another form are not reused)
+  return 0;
+}
 extern "C" int nlps_gpu_set_law_launch_mode(nlps_gpu* h, int mode) {
   if (mode != 1 && mode != 2) {
     h->err = "nlps_gpu_set_law_launch_mode: 1 = one launch per law, 2 = one kernel dispatching on the law";
@@ -2315,7 +2326,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   void* ptrs[] = {h->P.d, h->Pd_alt, h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->P.mlo, h->P.mhi, h->N.active, h->N.seed, h->N.nm,
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
-                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->fused_q_d, h->fused_args_d, h->fused_done_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->dmg_first0_d, h->dmg_last0_d, h->dmg_sorted0_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
+                  h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->dmg_first0_d, h->dmg_last0_d, h->dmg_sorted0_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
                   h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2575,6 +2586,7 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 static RcclApi g_rccl;
 static const char* rccl_load() {  // nullptr = loaded
@@ -2599,6 +2611,7 @@ static const char* rccl_load() {  // nullptr = loaded
   NLPS_SYM(GetErrorString, "ncclGetErrorString")
   NLPS_SYM(CommCount, "ncclCommCount")
   NLPS_SYM(CommUserRank, "ncclCommUserRank")
+  NLPS_SYM(CommAbort, "ncclCommAbort")
 #undef NLPS_SYM
   g_rccl.lib = L;
   return nullptr;
@@ -2776,6 +2789,7 @@ static int rccl_attach_common(nlps_gpu* h, ncclComm_t comm, bool own, int rank, 
     h->err = "nlps_gpu_rccl_attach: a communicator is attached already (nlps_gpu_rccl_detach first)";
     return 1;
   }
+  if (materialise_nodal(h)) return 1;  // (window and bands change below)
   const int nl = h->g.n[h->nd - 1];
   if (world < 1 || rank < 0 || rank >= world || (mode != 0 && mode != 1)) {
     h->err = "nlps_gpu_rccl_attach: bad rank / world / mode";
@@ -2870,6 +2884,7 @@ extern "C" int nlps_gpu_rccl_attach_comm(nlps_gpu* h, void* nccl_comm, int rank,
 extern "C" int nlps_gpu_rccl_detach(nlps_gpu* h) {
   RcclHalo* R = h->rccl;
   if (!R) return 0;
+  if (materialise_nodal(h)) return 1;
   (void)hipDeviceSynchronize();
   for (auto& kv : R->ev) {
     if (kv.second.start) (void)hipEventDestroy(kv.second.start);
@@ -2946,6 +2961,10 @@ extern "C" int nlps_gpu_rccl_info(nlps_gpu* h, int* nranks, int* rank, int* over
 // select + pack (nlps_gpu_migration_select), the row counts and then the rows themselves exchanged with the two
 // neighbours by ncclSend / ncclRecv on the handle's stream, commit.  self_loop (world 1 only): the rank is its own two
 // neighbours, so what leaves comes straight back -- every call on the wire runs on a one-GPU box.
+// Collective: every rank makes the same sequence of RCCL calls whatever happens locally.  A rank whose select fails or
+// whose capacity would overflow says so in a status word that all ranks agree on (one 4-byte all-reduce) BEFORE any row
+// moves: then every rank returns 1 with its cloud unchanged (a select without commit has no effect).  A HIP / RCCL error
+// after that point cannot be negotiated: the communicator is aborted so that the peers get an error, never a hang.
 static int rccl_migrate(nlps_gpu* h, int keep_lo, int keep_hi, int* sent_down, int* sent_up, int* received, bool self_loop) {
   RcclHalo* R = h->rccl;
   if (!R) {
@@ -2961,9 +2980,35 @@ static int rccl_migrate(nlps_gpu* h, int keep_lo, int keep_hi, int* sent_down, i
     if (R->rank == 0) keep_lo = 0;
     if (R->rank == R->world - 1) keep_hi = nl - 1;
   }
+  double* rows_in[2] = {nullptr, nullptr};
+  auto fatal = [&](const std::string& what) {  // unrecoverable local error in the middle of the collective
+    h->err = "nlps_gpu_rccl_migrate: " + what + " (communicator aborted)";
+    fprintf(stderr, "\033[1;31mError in nlps_gpu: %s\033[0m\n", h->err.c_str());
+    for (int k = 0; k < 2; k++)
+      if (rows_in[k]) (void)hipFree(rows_in[k]);
+    if (R->comm) (void)g_rccl.CommAbort(R->comm);
+    R->comm = nullptr;
+    return 1;
+  };
+#define MIG_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) return fatal(std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define MIG_RCCL(call)                                                                  \
+  do {                                                                                  \
+    ncclResult_t r_ = (call);                                                           \
+    if (r_ != ncclSuccess) return fatal(std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+  if (!R->comm) {
+    h->err = "nlps_gpu_rccl_migrate: the communicator was aborted by an earlier failure";
+    return 1;
+  }
   int n_out[2] = {0, 0}, rw = 0;
   void* rows_out[2] = {nullptr, nullptr};
-  if (nlps_gpu_migration_select(h, keep_lo, keep_hi, &n_out[0], &n_out[1], &rw, &rows_out[0], &rows_out[1])) return 1;
+  int bad = nlps_gpu_migration_select(h, keep_lo, keep_hi, &n_out[0], &n_out[1], &rw, &rows_out[0], &rows_out[1]) ? 1 : 0;
+  const std::string select_err = bad ? h->err : std::string();
+  if (bad) n_out[0] = n_out[1] = 0;
   if (sent_down) *sent_down = n_out[0];
   if (sent_up) *sent_up = n_out[1];
   if (received) *received = 0;
@@ -2973,39 +3018,52 @@ static int rccl_migrate(nlps_gpu* h, int keep_lo, int keep_hi, int* sent_down, i
     peer[0] = peer[1] = R->rank;
     has[0] = has[1] = true;
   }
-  if (!has[0] && !has[1]) return nlps_gpu_migration_commit(h, nullptr, 0, nullptr, 0);
-  if (!R->mig_cnt_d) HIPCHK(hipMalloc((void**)&R->mig_cnt_d, 4 * sizeof(int)));
+  if (!has[0] && !has[1]) {  // world 1: nobody to agree with
+    if (bad) return 1;
+    return nlps_gpu_migration_commit(h, nullptr, 0, nullptr, 0);
+  }
+  if (!R->mig_cnt_d) MIG_HIP(hipMalloc((void**)&R->mig_cnt_d, 8 * sizeof(int)));
   // 1. how many rows come from each neighbour
-  int cnt[4] = {n_out[0], n_out[1], 0, 0};
-  HIPCHK(hipMemcpyAsync(R->mig_cnt_d, cnt, 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  RCCLCHK(g_rccl.GroupStart());
+  int cnt[8] = {n_out[0], n_out[1], 0, 0, 0, 0, 0, 0};
+  MIG_HIP(hipMemcpyAsync(R->mig_cnt_d, cnt, 8 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  MIG_RCCL(g_rccl.GroupStart());
   for (int k = 0; k < 2; k++) {
     if (!has[k]) continue;
     // (self-loop: sends and receives between one pair match in the order posted, so what went "down" arrives as
     // "from below" -- which neighbour it stands for does not matter to the commit)
-    RCCLCHK(g_rccl.Send(R->mig_cnt_d + k, 1, ncclInt32, peer[k], R->comm, h->stream));
-    RCCLCHK(g_rccl.Recv(R->mig_cnt_d + 2 + k, 1, ncclInt32, peer[k], R->comm, h->stream));
+    MIG_RCCL(g_rccl.Send(R->mig_cnt_d + k, 1, ncclInt32, peer[k], R->comm, h->stream));
+    MIG_RCCL(g_rccl.Recv(R->mig_cnt_d + 2 + k, 1, ncclInt32, peer[k], R->comm, h->stream));
   }
-  RCCLCHK(g_rccl.GroupEnd());
-  HIPCHK(hipMemcpyAsync(cnt, R->mig_cnt_d, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  MIG_RCCL(g_rccl.GroupEnd());
+  MIG_HIP(hipMemcpyAsync(cnt, R->mig_cnt_d, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  MIG_HIP(hipStreamSynchronize(h->stream));
   const int n_in[2] = {cnt[2], cnt[3]};
-  if (n_in[0] < 0 || n_in[1] < 0 || (size_t)h->P.np + n_in[0] + n_in[1] > h->P.npad) {
-    h->err = "nlps_gpu_rccl_migrate: more immigrants than the capacity reserved at create (np + max(np/4, 1024))";
+  const bool overflow = n_in[0] < 0 || n_in[1] < 0 || (size_t)h->P.np + n_in[0] + n_in[1] > h->P.npad;
+  // 2. one status word for the whole communicator: 0 go, 1 some rank cannot
+  int status[2] = {(bad || overflow) ? 1 : 0, 0};
+  MIG_HIP(hipMemcpyAsync(R->mig_cnt_d + 4, status, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  MIG_RCCL(g_rccl.AllReduce(R->mig_cnt_d + 4, R->mig_cnt_d + 5, 1, ncclInt32, ncclMax, R->comm, h->stream));
+  MIG_HIP(hipMemcpyAsync(status + 1, R->mig_cnt_d + 5, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  MIG_HIP(hipStreamSynchronize(h->stream));
+  if (status[1] != 0) {  // every rank takes this branch together; nothing has moved, nothing is committed
+    if (bad) h->err = select_err;
+    else if (overflow) h->err = "nlps_gpu_rccl_migrate: more immigrants than the capacity reserved at create (np + max(np/4, 1024))";
+    else h->err = "nlps_gpu_rccl_migrate: another rank of the communicator could not migrate (its select failed or its capacity is exhausted); no particle moved";
     return 1;
   }
-  // 2. the rows
-  double* rows_in[2] = {nullptr, nullptr};
+  // 3. the rows
   for (int k = 0; k < 2; k++)
-    if (n_in[k] > 0) HIPCHK(hipMalloc((void**)&rows_in[k], (size_t)n_in[k] * rw * sizeof(double)));
-  RCCLCHK(g_rccl.GroupStart());
+    if (n_in[k] > 0) MIG_HIP(hipMalloc((void**)&rows_in[k], (size_t)n_in[k] * rw * sizeof(double)));
+  MIG_RCCL(g_rccl.GroupStart());
   for (int k = 0; k < 2; k++) {
     if (!has[k]) continue;
-    if (n_out[k] > 0) RCCLCHK(g_rccl.Send(rows_out[k], (size_t)n_out[k] * rw, ncclDouble, peer[k], R->comm, h->stream));
-    if (n_in[k] > 0) RCCLCHK(g_rccl.Recv(rows_in[k], (size_t)n_in[k] * rw, ncclDouble, peer[k], R->comm, h->stream));
+    if (n_out[k] > 0) MIG_RCCL(g_rccl.Send(rows_out[k], (size_t)n_out[k] * rw, ncclDouble, peer[k], R->comm, h->stream));
+    if (n_in[k] > 0) MIG_RCCL(g_rccl.Recv(rows_in[k], (size_t)n_in[k] * rw, ncclDouble, peer[k], R->comm, h->stream));
   }
-  RCCLCHK(g_rccl.GroupEnd());
-  HIPCHK(hipStreamSynchronize(h->stream));
+  MIG_RCCL(g_rccl.GroupEnd());
+  MIG_HIP(hipStreamSynchronize(h->stream));
+#undef MIG_HIP
+#undef MIG_RCCL
   const int st = nlps_gpu_migration_commit(h, rows_in[0], n_in[0], rows_in[1], n_in[1]);
   for (int k = 0; k < 2; k++)
     if (rows_in[k]) (void)hipFree(rows_in[k]);
@@ -3170,7 +3228,7 @@ static NodeRanges node_ranges(nlps_gpu* h, int part) {
   return {lo * plane, (il - lo) * plane, ih * plane, (hi + 1 - ih) * plane};
 }
 
-// The folded explicit step (and k_step_fused) never stored dU, the accelerations and the reactions of its step: made here,
+// The folded explicit step never stored dU, the accelerations and the reactions of its step: made here,
 // from the nodal sums of that step, before somebody reads them or overwrites the sums they come from.
 static int materialise_nodal(nlps_gpu* h) {
   if (!h->nodal_stale) return 0;
@@ -3222,6 +3280,7 @@ static void launch_k2(nlps_gpu* h, bool p2g, int cls, double dt, double gamma_nm
 static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double gamma_nm, int overlap = 0,
                             bool launch_lists_kernel = true) {
   int np = h->P.np;
+  if (!p2g && materialise_nodal(h)) return 1;  // (a level-B search rewrites the active flags the lazy nodal arrays depend on)
   // ahead: the search of this step was done by the last kernel of the previous one (k5_tile<., ., true>); only the
   // nodal accumulators are reset here
   const bool ahead = h->ahead && !init;
@@ -3288,7 +3347,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   } else if (overlap == 2) {  // the flags travelled behind the binning kernels; one launch, boundary tiles first
     if (halo(h, h->N.active, 1, 1, 1, 2)) return 1;
     launch_k2(h, p2g, 0, dt, gamma_nm, true);
-  } else if (launch_lists_kernel) {  // (k_step_fused runs K2 as the first stage of its own launch)
+  } else if (launch_lists_kernel) {
     launch_k2(h, p2g, 0, dt, gamma_nm);
   }
   HIPCHK(hipGetLastError());
@@ -3810,7 +3869,6 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       for (int k = 0; k < 3; k++) ln.fs.bc.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
     }
     ln.fs.bcmask = nbcc > 0 ? h->bcmask_d : nullptr;
-    ln.fs.plain_loads = 1;
     for (int a = 0; a < 3; a++) ln.fs.gv[a] = gv[a];
     ln.n0 = h->n0;
     ln.nwn = h->nwn;
@@ -4029,123 +4087,6 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (lazy) launch_k5_lazy(cls);
     else launch_k5(cls);
   };
-  // One launch for K2, K3 and K5 (k_step_fused): one GPU without a ghost exchange, 3-D, one law, the Dirichlet sets
-  // small enough to travel as kernel arguments.  The nodal kernels between the stages run lazily, only when somebody
-  // asks for the nodal arrays (nlps_gpu_explicit_nodal).
-  const bool fusedk = h->fused_step && fuse && h->fuse_search == 1 && ND == 3 && !det && !h->rccl && !h->halo &&
-                      h->uniform_law == NLPS_MAT_NEO_HOOKEAN && nbcc <= NLPS_MAX_BC_INLINE;
-  if (fusedk) {
-    if (search_and_lists(h, false, true, dt, gamma_nm, 0, false)) return 1;
-    if (h->timing) {
-      HIPCHK(hipEventRecord(h->ev[2], h->stream));
-      HIPCHK(hipEventRecord(h->ev[3], h->stream));
-    }
-    if (!h->fused_q_d) {
-      HIPCHK(hipMalloc((void**)&h->fused_q_d, 64));
-      HIPCHK(hipMalloc((void**)&h->fused_done_d, 2 * (size_t)h->ntiles * sizeof(unsigned)));
-      HIPCHK(hipMemsetAsync(h->fused_done_d, 0, 2 * (size_t)h->ntiles * sizeof(unsigned), h->stream));
-    }
-    hipLaunchKernelGGL(k_fused_prep, dim3(nblk(std::max(h->nwn, h->ntw))), dim3(BLK), 0, h->stream, h->n0, h->nwn, h->N.seed,
-                       node_lists(h) ? h->node_cnt_d : nullptr, h->tile_count2_d + h->tile0, h->ntw, h->fused_q_d);
-    FusedStep fs;
-    fs.q_head = h->fused_q_d;
-    fs.done2 = h->fused_done_d;
-    fs.done3 = h->fused_done_d + h->ntiles;
-    if (++h->fused_seq == 0u) {  // (the flags compare modulo 2^32: restart them with the counter)
-      HIPCHK(hipMemsetAsync(h->fused_done_d, 0, 2 * (size_t)h->ntiles * sizeof(unsigned), h->stream));
-      h->fused_seq = 1u;
-    }
-    fs.seq = h->fused_seq;
-    fs.nstages = 3;
-    if (const char* e = getenv("NLPS_FUSED_STAGES")) fs.nstages = atoi(e);
-    fs.bc.n = nbcc;
-    for (int i = 0; i < nbcc; i++) {
-      fs.bc.dim[i] = bcc[i].dim;
-      fs.bc.bits[i] = h->bcs[i].n > 0 ? dirbits_of(bcc[i], step, h->nsteps) : 0;
-      for (int k = 0; k < 3; k++) fs.bc.v[i][k] = (k < bcc[i].dim) ? bcc[i].value[(size_t)k * h->nsteps + step] : 0.0;
-    }
-    fs.bcmask = nbcc > 0 ? h->bcmask_d : nullptr;
-    for (int a = 0; a < 3; a++) fs.gv[a] = gv[a];
-    K5Search ksf;
-    ksf.rank1 = h->rank1_d;
-    ksf.bin = 1;
-    ksf.tc = tile_cnt(h, true);
-    ksf.tc.count = h->tile_count2_d;
-    int fgrid = 3 * h->ncu;
-    if (const char* e = getenv("NLPS_FUSED_GRID")) fgrid = atoi(e);
-    fs.trace = nullptr;
-    fs.nofence = 0;
-    fs.plain_loads = 0;
-    fs.persistent = 1;
-    if (const char* e = getenv("NLPS_FUSED_NOFENCE")) fs.nofence = atoi(e);
-    static int* trace_h = nullptr;
-    if (getenv("NLPS_FUSED_TRACE")) {
-      if (!trace_h) {
-        HIPCHK(hipHostMalloc((void**)&trace_h, 8 * sizeof(int) * 1024 + 128, hipHostMallocCoherent));
-        memset(trace_h + 8 * 1024, 0, 128);
-      }
-      memset(trace_h, 0xff, 8 * sizeof(int) * 1024);
-      fs.trace = trace_h;
-      static int* trace_d = nullptr;  // 3: per-stage times only, in device memory (host-memory atomics distort them)
-      if (atoi(getenv("NLPS_FUSED_TRACE")) == 3) {
-        if (!trace_d) {
-          HIPCHK(hipMalloc((void**)&trace_d, 8 * sizeof(int) * 1024 + 128));
-          HIPCHK(hipMemsetAsync(trace_d, 0, 8 * sizeof(int) * 1024 + 128, h->stream));
-        }
-        fs.trace = trace_d;
-      }
-    }
-    FusedArgs fa;
-    fa.P = h->P;
-    fa.g = h->g;
-    fa.N = h->N;
-    fa.td = tile_view(h, 0);
-    fa.mats = h->mats_d;
-    fa.prm = h->prm;
-    fa.dt = dt;
-    fa.gamma_nm = gamma_nm;
-    fa.gstatus = h->gstatus_d;
-    fa.ks = ksf;
-    fa.fs = fs;
-#if NLPS_FUSED_BYVAL
-    hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(fgrid), dim3(BLK), 0, h->stream, fa);
-#else
-    if (!h->fused_args_d) HIPCHK(hipMalloc((void**)&h->fused_args_d, sizeof(FusedArgs)));
-    HIPCHK(hipMemcpyAsync(h->fused_args_d, &fa, sizeof fa, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));  // (fa lives on this stack frame; a pinned staging block would avoid the wait)
-    hipLaunchKernelGGL((k_step_fused<3, NLPS_MAT_NEO_HOOKEAN>), dim3(fgrid), dim3(BLK), 0, h->stream,
-                       (const FusedArgs*)h->fused_args_d);
-#endif
-    if (fs.trace) {
-      const int nb = std::min(fgrid, 1024);
-      int* tr = trace_h;
-      auto dump = [nb, tr]() {
-        usleep(3000000);
-        for (int b = 0; b < nb; b++)
-          if (tr[8 * b + 4] != 5 || tr[8 * b + 5] != 5 || tr[8 * b + 6] != 5 || tr[8 * b + 7] != 5)
-            fprintf(stderr, "wg %d item %d marks %d %d %d %d\n", b, tr[8 * b], tr[8 * b + 4], tr[8 * b + 5], tr[8 * b + 6], tr[8 * b + 7]);
-        fprintf(stderr, "trace dumped\n");
-      };
-      const int tmode = atoi(getenv("NLPS_FUSED_TRACE"));
-      if (tmode == 2) std::thread(dump).detach();  // 2: the caller goes on (the first step only makes sense)
-      else if (tmode == 1) dump();
-      else {  // 3: workgroup time per stage, summed over the steps so far
-        HIPCHK(hipMemcpyAsync(trace_h + 8 * 1024, fs.trace + 8 * 1024, 128, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        const unsigned long long* a = reinterpret_cast<const unsigned long long*>(trace_h + 8 * 1024);
-        fprintf(stderr, "fused ticks wait %llu %llu %llu body %llu %llu %llu publish %llu %llu %llu\n", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8]);
-      }
-    }
-    HIPCHK(hipGetLastError());
-    if (h->timing) {
-      HIPCHK(hipEventRecord(h->ev[4], h->stream));
-      HIPCHK(hipEventRecord(h->ev[5], h->stream));
-    }
-    h->nodal_stale = true;
-    h->last_bc = fs.bc;
-    h->last_bm = fs.bcmask;
-    for (int a = 0; a < 3; a++) h->last_gv[a] = gv[a];
-  } else {
   h->nodal_stale = false;
   // S1 + S2 (ev[1] is recorded between the search and the lists/Newton/P2G kernel; the nodal accumulators of
   // the node window are reset by k_step_clear inside search_and_lists)
@@ -4213,7 +4154,6 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   }
   HIPCHK(hipGetLastError());
   }  // !ov2
-  }  // !fusedk
   h->P.flip ^= 1;  // F_n <- F_n+1, b_e,n <- b_e,n+1 by renaming
   h->rolled = true;
   h->searched = fuse;                      // K5 has updated the closest nodes for the positions it wrote ...
@@ -4240,7 +4180,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     h->ms[2] = t34;
     h->ms[3] = t56;
     h->ms[4] = t23 + t45;
-    h->ms[7] = fusedk ? 1.f : 0.f;  // 1: slot 2 is the whole of k_step_fused (K2 + K3 + K5 and the nodal work between them)
+    h->ms[7] = 0.f;
     h->ms[6] = 0.f;  // time the handle's stream spent in / waiting for the ghost-layer exchanges of this step
     for (int q = 0; q < h->nwait; q++) {
       float tw = 0.f;

@@ -11,6 +11,15 @@
 // physical SoA order is tile-major from the upload sort, so order[] is close to the identity.
 #pragma once
 
+// NLPS_DEV = 1 (tools/build_variant.sh): developer builds -- environment switches, phase timers and the ablation macros
+// below (which produce WRONG results by design).  The product build (nl-partsol_amd/build.py) never sets it.
+#ifndef NLPS_DEV
+#define NLPS_DEV 0
+#endif
+#if !NLPS_DEV && (defined(NLPS_ABL_ATOM) || defined(NLPS_ABL_GATHER) || defined(NLPS_PHASE_TIMING))
+#error "NLPS_ABL_* / NLPS_PHASE_TIMING are developer experiments: build with -DNLPS_DEV=1 (tools/build_variant.sh)"
+#endif
+
 template <int ND>
 struct TileCfg;
 // PS = LDS stride between z-planes of the window.  8x8 planes padded to 68 doubles: the 64 possible
@@ -559,84 +568,26 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 };
 
 // ------------------------------------------------------------------------------------------------
-// One launch for the three tile stages of the explicit step (k_step_fused, one GPU, no ghost exchange).  A kernel ends
-// with a tail: the last workgroups of K2 run on a half-empty chip before K3 may start -- measured ~40 us per stage at
-// 1 M particles, a sixth of the step -- although a K3 tile only needs the nodal sums of its OWN window, i.e. the K2
-// tiles around it.  Persistent workgroups take work items from one queue, all K2 tiles first, then the K3 tiles, then
-// the K5 tiles; a tile publishes a per-tile sequence number once its window flush has reached L2, and a tile of the
-// next stage waits for the (up to 3^d) tiles whose windows overlap its own.  An item only ever waits for items taken
-// from the queue before it, by workgroups that are running: no assumption on dispatch order or co-residency.  The
-// nodal kernels between the stages (dU = sum m N dD / M with the Dirichlet values; a = g + f / M) become part of the
-// window loads of K3 and K5, read with agent-scope loads that bypass the L1 of the CU.
+// The folded explicit step (k3_tile_lazy / k5_tile_lazy): the nodal kernels between the stages (dU = sum m N dD / M
+// with the Dirichlet values; a = g + f / M) become part of the window loads of K3 and K5.  What those loads need
+// beside the nodal sums: the Dirichlet sets of the step and gravity.
+// (Round 3 also held k_step_fused here -- K2, K3, K5 as ONE launch of persistent workgroups with per-tile hand-off
+// flags.  Measured slower than the three launches, 0.67 against 0.56 ms, after an early revision that hung for a reason
+// never established; taken out of the library in round 4, DESIGN.md 5a.  Last revision that holds it: 7527459.)
 // ------------------------------------------------------------------------------------------------
-struct FusedStep {
-  unsigned* q_head;      // work queue: items [0, n) K2, [n, 2n) K3, [2n, 3n) K5 over the n entries of the work list
-  unsigned* done2;       // [ntiles] sequence number of the last step whose K2 flush of this tile is in L2
-  unsigned* done3;       // the same for the force flush of K3
-  unsigned seq;          // this step's number (never 0)
-  int nstages;           // 3; developer switch NLPS_FUSED_STAGES runs the first stages only
-  int* trace;            // developer switch NLPS_FUSED_TRACE: host-visible progress marks, 8 ints per workgroup
-  int nofence;           // developer switch NLPS_FUSED_NOFENCE (timing experiments): 1 no release, 2 no acquire
-  int plain_loads;       // the nodal sums were flushed by an EARLIER launch (k3_tile_lazy, k5_tile_lazy): ordinary loads do
-  int persistent;        // 1 inside k_step_fused (tiles publish per-tile flags, no exchange signal); 0 in the folded step
+struct NodalFold {
   const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
-  BcStep bc;             // their components and values at this step
-  double gv[3];          // gravity
+  BcStep bc;               // their components and values at this step
+  double gv[3];            // gravity
 };
-// one lane per neighbouring tile polls its flag (relaxed, L1-bypassing loads; s_sleep between polls); false after
-// ~0.2 s of the constant 100 MHz clock
-__device__ __forceinline__ bool fused_wait(const unsigned* flag, unsigned seq) {
-  const unsigned long long t0 = wall_clock64();
-  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
-    if (wall_clock64() - t0 > 20000000ull) return false;
-    __builtin_amdgcn_s_sleep(16);
-  }
-  return true;
-}
-// all threads of a workgroup, before a window load of a later stage: the flushes of the tiles around `tile` are visible
-// (consumer side of MI355X_MICROARCH.md "Valid forms": relaxed polls, ONE agent acquire by the polling wave, its wait,
-// the workgroup barrier; the window loads that follow bypass L1 anyway, coherent_load)
-template <int ND>
-__device__ __forceinline__ void fused_wait_neighbours(const TileD& td, int tile, const unsigned* done, unsigned seq,
-                                                      int* __restrict__ gstatus, int nofence) {
-  const int t = threadIdx.x;
-  if (t < 64) {
-    if (t < (ND == 3 ? 27 : 9)) {
-      const int tx = tile % td.nt[0], ty = (tile / td.nt[0]) % td.nt[1], tz = tile / (td.nt[0] * td.nt[1]);
-      const int x = tx + t % 3 - 1, y = ty + (t / 3) % 3 - 1, z = (ND == 3) ? tz + t / 9 - 1 : 0;
-      if (x >= 0 && x < td.nt[0] && y >= 0 && y < td.nt[1] && z >= 0 && z < (ND == 3 ? td.nt[2] : 1)) {
-        const int nb = x + td.nt[0] * (y + td.nt[1] * z);
-        if (nb >= td.tile0 && nb < td.tile0 + td.ntw && td.count[nb] > 0)
-          if (!fused_wait(done + nb, seq)) atomicOr(gstatus, 32);  // ST_SYNC: reported, never a hang
-      }
-    }
-    if (!(nofence & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-}
-// after a window flush: every wave drains its atomics, the workgroup meets, one lane releases at agent scope
-__device__ __forceinline__ void fused_publish(unsigned* flag, unsigned seq, int nofence) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (!(nofence & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// a double that another workgroup's atomics may have changed since this CU last cached its line
-__device__ __forceinline__ double coherent_load(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // what k_nodal_dU makes of a node (U-Verlet.c:357-362 + :455-527), from the nodal sums as they stand in L2
-__device__ __forceinline__ double nodal_load(const FusedStep& fs, const double* p) { return fs.plain_loads ? *p : coherent_load(p); }
 template <int ND>
-__device__ __forceinline__ void fused_nodal_dU(const NView& N, const FusedStep& fs, int A, double* val, bool* fix) {
+__device__ __forceinline__ void fused_nodal_dU(const NView& N, const NodalFold& fs, int A, double* val, bool* fix) {
   // every operand is requested before the first one is looked at (one round of latency instead of three)
-  const double M = nodal_load(fs, N.nm + (size_t)A * (1 + ND));
+  const double M = *(N.nm + (size_t)A * (1 + ND));
   double mom[ND];
 #pragma unroll
-  for (int a = 0; a < ND; a++) mom[a] = nodal_load(fs, N.nm + (size_t)A * (1 + ND) + 1 + a);
+  for (int a = 0; a < ND; a++) mom[a] = *(N.nm + (size_t)A * (1 + ND) + 1 + a);
   const bool active = N.active[A];
   const unsigned bm0 = fs.bcmask ? fs.bcmask[A] : 0u;
   const bool act = active && M != 0.0;
@@ -660,13 +611,13 @@ __device__ __forceinline__ void fused_nodal_dU(const NView& N, const FusedStep& 
 }
 // what k_nodal_accel makes of it (U-Verlet.c:947-957)
 template <int ND>
-__device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedStep& fs, int A, double* acc) {
+__device__ __forceinline__ void fused_nodal_accel(const NView& N, const NodalFold& fs, int A, double* acc) {
   double dU[ND];
   bool fix[ND];
-  const double M = nodal_load(fs, N.nm + (size_t)A * (1 + ND));
+  const double M = *(N.nm + (size_t)A * (1 + ND));
   double f[ND];
 #pragma unroll
-  for (int a = 0; a < ND; a++) f[a] = nodal_load(fs, N.force + (size_t)A * ND + a);
+  for (int a = 0; a < ND; a++) f[a] = *(N.force + (size_t)A * ND + a);
   const bool active = N.active[A];
   const unsigned bm0 = fs.bcmask ? fs.bcmask[A] : 0u;
   const bool act = active && M != 0.0;
@@ -691,12 +642,11 @@ __device__ __forceinline__ void fused_nodal_accel(const NView& N, const FusedSte
 // K2: neighbour mask + beta + Newton + predictor + P2G(mass, m*dD)      (S1b + S2)
 // ------------------------------------------------------------------------------------------------
 // body of k2_tile for one work item; acc [NF * NWA] doubles and actrow [NROWS] words of LDS are the caller's.
-// fs != nullptr: part of k_step_fused (the tile publishes its flush instead of signalling an exchange stream, and
-// resets the search state of its own nodes for the search that rides on K5)
+// fs: unused by K2 (kept so that the three stage bodies share one signature)
 template <int ND, bool P2G, int NT>
 __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NView& N, const TileD& td, const ParamsD& prm,
                                         double dt, double gamma_nm, int* __restrict__ gstatus, const TileWork& tw, int nbnd,
-                                        double* acc, unsigned* actrow, const FusedStep* fs) {
+                                        double* acc, unsigned* actrow, const NodalFold* fs) {
   constexpr int W = TileCfg<ND>::W, NW = TileCfg<ND>::NW, NF = 1 + ND, NROWS = WinRows<ND>::NROWS;
   constexpr int WA = TileCfg<ND>::WA, PSA = TileCfg<ND>::PSA, NWA = TileCfg<ND>::NWA;
   constexpr int KN = Lme<ND>::KN;
@@ -944,7 +894,7 @@ __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NV
     }
   }
   PH(5)
-  if (!fs || !fs->persistent) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
+  tile_signal(td, wb, nbnd);
 }
 // NT / SPLIT: threads per workgroup and workgroups per tile.  The default is (BLK, K2_SPLIT); deterministic mode runs one
 // wave per tile (64, 1): the sorted tile list is then accumulated in list order by a single instruction stream.
@@ -980,8 +930,7 @@ struct K3Waves {
                                : (MODE == 1 && LAW == NLPS_MAT_DRUCKER_PRAGER) ? NLPS_K3_WAVES_DP
                                                                                : NLPS_K3_WAVES;
 };
-// the LDS of k3_tile, owned by the caller of k3_body (the kernel below, or k_step_fused, which shares one block of LDS
-// between its three stages)
+// the LDS of k3_tile, owned by the caller of k3_body (the kernels below)
 template <int ND, int MODE, bool FILT>
 struct K3Lds {
   static constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA;
@@ -1001,7 +950,7 @@ template <int ND, int LAW, int MODE, bool FILT, int NT>
 __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NView& N, const TileD& td,
                                         const MatD* __restrict__ mats, const ParamsD& prm, int* __restrict__ gstatus,
                                         const double* __restrict__ dVgrid, const TileWork& tw, int nbnd,
-                                        const K3Lds<ND, MODE, FILT>& lds, const FusedStep* fs) {
+                                        const K3Lds<ND, MODE, FILT>& lds, const NodalFold* fs) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr bool RATES = (MODE == 2);
   // gather window of dU: {x,y} as one 16-B double2 per node (ds_read_b128) + z as a separate 8-B array
@@ -1075,7 +1024,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
       idx = idx0;
       node = window_node<ND>(g, w0, idx, in);
     }
-    if (fs) {  // (k_step_fused: the nodal kernel's job, on the sums the K2 tiles around have published)
+    if (fs) {  // (folded step: the nodal kernel's job, on the sums the K2 launch flushed)
       double val[ND];
       bool fix[ND];
 #pragma unroll
@@ -1573,7 +1522,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     }
   }
   PH(14)
-  if (!fs || !fs->persistent) tile_signal(td, wb, nbnd);  // (k_step_fused publishes the flush itself)
+  tile_signal(td, wb, nbnd);
 }
 template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
 __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value))) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
@@ -1603,7 +1552,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
 // inside K5 accumulates into.  Three launches and ~35 us per step less at 1 M particles; the nodal arrays nobody reads
 // during the step are made when somebody asks (nlps_gpu_explicit_nodal, nodal_stale).
 struct LazyNodal {
-  FusedStep fs;  // bc, bcmask, gv (the queue fields are unused)
+  NodalFold fs;  // bc, bcmask, gv
   int n0, nwn;   // node window
   int* node_cnt;
   int* tile_count;
@@ -1691,7 +1640,7 @@ struct K5Search {
 template <int ND, int LAW, bool SEARCH>
 __device__ __forceinline__ void k5_body(const PView& P, const GridD& g, const NView& N, const TileD& td, double dt,
                                         double gamma_nm, const K5Search& ks, const TileWork& tw, double* axy, double* az,
-                                        const FusedStep* fs, int* __restrict__ gstatus) {
+                                        const NodalFold* fs, int* __restrict__ gstatus) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   const int tile = tw.tile, part = tw.part, nparts = tw.nparts;
   const int cnt = td.count[tile];
@@ -1707,7 +1656,7 @@ __device__ __forceinline__ void k5_body(const PView& P, const GridD& g, const NV
       idx = idx0;
       node = window_node<ND>(g, w0, idx, in);
     }
-    if (fs) {  // (k_step_fused: the nodal kernel's job, on the forces the K3 tiles around have published)
+    if (fs) {  // (folded step: the nodal kernel's job, on the forces the K3 launch flushed)
       double av[ND];
 #pragma unroll
       for (int a = 0; a < ND; a++) av[a] = 0.0;
@@ -1833,193 +1782,6 @@ __global__ __launch_bounds__(K5_BLK) void k5_tile_lazy(PView P, GridD g, NView N
   TileWork tw;
   if (!tile_work_item<K5_SPLIT>(td, tw)) return;
   k5_body<ND, LAW, true>(P, g, N, td, dt, gamma_nm, ks, tw, axy, az, &ln.fs, gstatus);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_step_fused: K2, K3 and K5 of the explicit step as ONE launch of persistent workgroups (see FusedStep)
-// ------------------------------------------------------------------------------------------------
-// (the three stages are real function calls: inlined into one body the persistent loop became a lane-masked loop nest of
-// ten thousand instructions)
-#ifndef NLPS_FUSED_CALLS
-#define NLPS_FUSED_CALLS 0
-#endif
-#ifndef NLPS_FUSED_BYVAL
-#define NLPS_FUSED_BYVAL 1
-#endif
-#if NLPS_FUSED_CALLS
-#define FUSED_STAGE __device__ __noinline__
-#else
-#define FUSED_STAGE __device__ __forceinline__
-#endif
-struct FusedArgs {
-  PView P;
-  GridD g;
-  NView N;
-  TileD td;
-  const MatD* mats;
-  ParamsD prm;
-  double dt, gamma_nm;
-  int* gstatus;
-  K5Search ks;
-  FusedStep fs;
-};
-// NLPS_FUSED_BYVAL 0: the argument block sits in device memory and every trip of the persistent loop reads what its
-// stage needs through constant-address-space loads (scalar, invariant) behind a pointer the optimiser cannot see through:
-// nothing of one stage stays in registers while another runs.  (As a kernel argument -- BYVAL 1 -- the whole block and
-// what the three stages derive from it is hoisted to the kernel entry and spilled: 338 v_writelane, 1083 v_readlane.)
-template <class T>
-__device__ __forceinline__ T load_const(const T* p) {
-  static_assert(sizeof(T) % 4 == 0, "dwords");
-  constexpr int n = sizeof(T) / 4;
-  typedef const __attribute__((address_space(4))) unsigned* cptr;
-  cptr c = (cptr)(reinterpret_cast<const unsigned*>(p));
-  unsigned w[n];
-#pragma unroll
-  for (int i = 0; i < n; i++) w[i] = c[i];
-  T t;
-  __builtin_memcpy(&t, w, sizeof(T));
-  return t;
-}
-// (a pointer that comes out of memory in pieces is a flat pointer: flat_load, flat_atomic.  One that is read AS a pointer
-// from the constant address space is taken for a global pointer by the back end, as kernel arguments are)
-template <class T>
-__device__ __forceinline__ T* load_ptr(T* const* p) {
-  typedef T* const __attribute__((address_space(4)))* cpp;
-  return *(cpp)p;
-}
-#define NLPS_G(x) v.x = load_ptr(&s->x);
-__device__ __forceinline__ void globalise(PView& v, const PView* s) {
-  NLPS_G(d) NLPS_G(I0) NLPS_G(I0n) NLPS_G(mat) NLPS_G(nn) NLPS_G(status) NLPS_G(mlo) NLPS_G(mhi) NLPS_G(tile) NLPS_G(rank)
-}
-__device__ __forceinline__ void globalise(NView& v, const NView* s) {
-  NLPS_G(active) NLPS_G(seed) NLPS_G(h_avg) NLPS_G(beta_t2) NLPS_G(nm) NLPS_G(dU) NLPS_G(force) NLPS_G(accel) NLPS_G(reaction) NLPS_G(fixed)
-}
-__device__ __forceinline__ void globalise(TileD& v, const TileD* s) {
-  NLPS_G(slab) NLPS_G(start) NLPS_G(count) NLPS_G(order) NLPS_G(order_m) NLPS_G(work[0]) NLPS_G(work[1]) NLPS_G(range) NLPS_G(phase)
-  NLPS_G(sig_cnt) NLPS_G(sig_flag)
-}
-__device__ __forceinline__ void globalise(TileCnt& v, const TileCnt* s) {
-  NLPS_G(count) NLPS_G(gstatus) NLPS_G(home) NLPS_G(foreign) NLPS_G(node_cnt) NLPS_G(nrank)
-}
-__device__ __forceinline__ void globalise(K5Search& v, const K5Search* s) {
-  NLPS_G(rank1)
-  globalise(v.tc, &s->tc);
-}
-__device__ __forceinline__ void globalise(FusedStep& v, const FusedStep* s) { NLPS_G(q_head) NLPS_G(done2) NLPS_G(done3) NLPS_G(trace) NLPS_G(bcmask) }
-template <class T>
-__device__ __forceinline__ void globalise(T*& v, T* const* s) { v = load_ptr(s); }
-__device__ __forceinline__ void globalise(GridD&, const GridD*) {}
-__device__ __forceinline__ void globalise(ParamsD&, const ParamsD*) {}
-__device__ __forceinline__ void globalise(double&, const double*) {}
-#undef NLPS_G
-typedef int* IntPtr;
-typedef const MatD* MatCPtr;
-#if NLPS_FUSED_BYVAL
-#define FUSED_GET(T, name, field) const T& name = a->field;
-#else
-#define FUSED_GET(T, name, field)  \
-  T name = load_const(&a->field); \
-  globalise(name, &a->field);
-#endif
-template <int ND>
-FUSED_STAGE void fused_stage_k2(const FusedArgs* a, int wb, int tile, double* sh) {
-  constexpr int NWA = TileCfg<ND>::NWA;
-  TileWork tw{tile, 0, 1, wb};
-  FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(ParamsD, prm, prm)
-  FUSED_GET(double, dt, dt) FUSED_GET(double, gamma_nm, gamma_nm) FUSED_GET(IntPtr, gstatus, gstatus)
-  FusedStep fs;  // (K2 only asks whether it is there and persistent)
-  fs.persistent = 1;
-  k2_body<ND, true, BLK>(P, g, N, td, prm, dt, gamma_nm, gstatus, tw, 0, sh, reinterpret_cast<unsigned*>(sh + (1 + ND) * NWA), &fs);
-}
-template <int ND, int LAW>
-FUSED_STAGE void fused_stage_k3(const FusedArgs* a, int wb, int tile, double* sh) {
-  using L3 = K3Lds<ND, 1, false>;
-  constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA;
-  TileWork tw{tile, 0, 1, wb};
-  double* duxy = sh;  // 16-byte aligned (NW is even)
-  double* duz = duxy + 2 * NW;
-  double* fac = duz + L3::N_DUZ;
-  double* dvxy = fac + ND * NWA;  // MODE 1 has no rate windows: two placeholders each
-  double* dvz = dvxy + 2;
-  int* ints = reinterpret_cast<int*>(dvz + 2);
-  const L3 lds{dvxy, dvz, duxy, duz, fac, ints, ints + 2, ints + 4};
-  FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(ParamsD, prm, prm)
-  FUSED_GET(MatCPtr, mats, mats) FUSED_GET(IntPtr, gstatus, gstatus) FUSED_GET(FusedStep, fs, fs)
-  k3_body<ND, LAW, 1, false, BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, 0, lds, &fs);
-}
-template <int ND, int LAW>
-FUSED_STAGE void fused_stage_k5(const FusedArgs* a, int wb, int tile, double* sh) {
-  constexpr int NW = TileCfg<ND>::NW;
-  TileWork tw{tile, 0, 1, wb};
-  FUSED_GET(PView, P, P) FUSED_GET(GridD, g, g) FUSED_GET(NView, N, N) FUSED_GET(TileD, td, td) FUSED_GET(K5Search, ks, ks)
-  FUSED_GET(double, dt, dt) FUSED_GET(double, gamma_nm, gamma_nm) FUSED_GET(IntPtr, gstatus, gstatus) FUSED_GET(FusedStep, fs, fs)
-  k5_body<ND, (LAW == NLPS_MAT_NEO_HOOKEAN || LAW == NLPS_MAT_HENCKY) ? 0 : 2, true>(P, g, N, td, dt, gamma_nm, ks, tw, sh, sh + 2 * NW,
-                                                                                     &fs, gstatus);
-}
-template <int ND, int LAW>
-#if NLPS_FUSED_BYVAL
-__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(const FusedArgs args_v) {
-  const FusedArgs* args = &args_v;
-#else
-__global__ __launch_bounds__(BLK, (K3Waves<ND, LAW, 1>::value)) void k_step_fused(const FusedArgs* __restrict__ args_g) {
-#endif
-  static_assert(K3_BLK == BLK && K5_BLK == BLK && K2_SPLIT == 1 && K3_SPLIT == 1 && K5_SPLIT == 1, "one work list, one block size");
-  using L3 = K3Lds<ND, 1, false>;
-  constexpr int NW = TileCfg<ND>::NW, NWA = TileCfg<ND>::NWA, NROWS = WinRows<ND>::NROWS;
-  // one block of LDS for the three stages: K2 {acc[(1+ND) NWA], actrow}, K3 {duxy, duz, fac, ...}, K5 {axy, az}
-  constexpr int N2 = (1 + ND) * NWA + (NROWS + 1) / 2;
-  constexpr int N3 = 2 * NW + L3::N_DUZ + ND * NWA + 2 + 2 + 8;
-  constexpr int N5 = 2 * NW + ((ND == 3) ? NW : 1);
-  constexpr int NSH = (N2 > N3 ? (N2 > N5 ? N2 : N5) : (N3 > N5 ? N3 : N5));
-  __shared__ __attribute__((aligned(16))) double sh[NSH];
-  __shared__ int s_item;
-  while (true) {
-#if !NLPS_FUSED_BYVAL
-    const FusedArgs* args = args_g;
-    asm volatile("" : "+s"(args));  // a new pointer every trip: nothing read through it is hoisted out of the loop
-    const FusedArgs* a = args;
-#else
-    const FusedArgs* a = args;
-#endif
-    FUSED_GET(TileD, td, td) FUSED_GET(FusedStep, fs, fs) FUSED_GET(IntPtr, gstatus, gstatus)
-    const int w_lo = td.range[0], nwork = td.range[1] - td.range[0];
-    const int total = fs.nstages * nwork;
-#define FTRACE(k, v)                                                                                         \
-  if (fs.trace && (threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                              \
-    __hip_atomic_store(fs.trace + 8 * (size_t)blockIdx.x + (k) + (k >= 4 ? (threadIdx.x >> 6) : 0), (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x == 0) s_item = (int)atomicAdd(fs.q_head, 1u);
-    __syncthreads();
-    const int item = __builtin_amdgcn_readfirstlane(s_item);  // wave-uniform by construction: scalar branches below
-    __syncthreads();  // (s_item is rewritten at the top of the next trip; the stage bodies re-initialise their LDS)
-    FTRACE(0, item) FTRACE(4, 1)
-    if (item >= total) {
-      FTRACE(4, 5)
-      break;
-    }
-    long long t0 = fs.trace ? wall_clock64() : 0;
-    const int stage = item / nwork;
-    const int wb = w_lo + (item - stage * nwork);
-    const int tile = td.work[0][wb].x;
-    // a tile of a later stage reads nodal sums of its window: the flushes of the tiles around it must have landed
-    if (stage == 1) fused_wait_neighbours<ND>(td, tile, fs.done2, fs.seq, gstatus, fs.nofence);
-    if (stage == 2) fused_wait_neighbours<ND>(td, tile, fs.done3, fs.seq, gstatus, fs.nofence);
-    FTRACE(4, 2)
-    long long t1 = fs.trace ? wall_clock64() : 0;
-    if (stage == 0) fused_stage_k2<ND>(args, wb, tile, sh);
-    else if (stage == 1) fused_stage_k3<ND, LAW>(args, wb, tile, sh);
-    else fused_stage_k5<ND, LAW>(args, wb, tile, sh);
-    FTRACE(4, 3)
-    long long t2 = fs.trace ? wall_clock64() : 0;
-    if (stage < 2) fused_publish((stage == 0 ? fs.done2 : fs.done3) + tile, fs.seq, fs.nofence);
-    FTRACE(4, 4)
-    if (fs.trace && threadIdx.x == 0) {  // 100 MHz ticks: [stage] waiting, [3 + stage] body, [6 + stage] publish
-      long long t3 = wall_clock64();
-      unsigned long long* acc = reinterpret_cast<unsigned long long*>(fs.trace + 8 * 1024);
-      atomicAdd(acc + stage, (unsigned long long)(t1 - t0));
-      atomicAdd(acc + 3 + stage, (unsigned long long)(t2 - t1));
-      atomicAdd(acc + 6 + stage, (unsigned long long)(t3 - t2));
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -451,6 +451,11 @@ class Solver:
         self.L.nlps_gpu_set_adaptive_resort.argtypes = [C.c_void_p, C.c_double, C.c_int]
         self._chk(self.L.nlps_gpu_set_adaptive_resort(self.h, float(budget), int(min_steps)))
 
+    def debug_option(self, name, value):
+        """developer / test switch between equivalent launch forms (nlps_gpu_debug_option; the library reads no environment)"""
+        self.L.nlps_gpu_debug_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        self._chk(self.L.nlps_gpu_debug_option(self.h, name.encode(), float(value)))
+
     def debug_displaced(self):
         v, d = C.c_int(0), C.c_double(0)
         self.L.nlps_gpu_debug_displaced.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]

@@ -1161,6 +1161,34 @@ def test_periodic_resort_keeps_particles_the_search_could_not_bin():
     S.close()
 
 
+def test_periodic_resort_with_particles_flagged_by_the_search_ahead():
+    """with the next step's search riding on K5, P.tile[] already belongs to the NEXT lists when a periodic
+    re-sort takes the LAST lists as its permutation.  A cloud flying upwards through the top of its node window loses
+    particles to status 16 in every step, also in the step right before a re-sort (listed then, flagged now) while others
+    were flagged earlier (in no list): every particle must come back exactly once, in the caller's order."""
+    n = nlps()
+    case = small_case(3, velocity=[0.0, 0.0, 60.0])
+    npart = case["cloud"]["x"].shape[0]
+    case["cloud"]["mass"] = case["cloud"]["mass"] * (1.0 + 1e-3 * np.arange(npart))  # a tag that survives the steps
+    nsteps = 7
+    S = gpu_setup(case, nsteps=nsteps)
+    z = case["cloud"]["x"][:, 2]
+    layer_hi = int(np.floor(z.max() / case["h"])) + 2  # the whole cloud fits at the start ...
+    S.set_node_window(0, layer_hi)
+    S.set_resort_interval(2)
+    S.set_adaptive_resort(0.0)
+    gb = n.BccSet([])
+    flagged = []
+    for t in range(nsteps):  # ... and 0.3 cells per step carry its top layers out, a few more particles every step
+        S.explicit_step(gb, t, 5e-3)
+        st = S.download_state(fields=["mass", "x_GC"])
+        assert np.array_equal(st["mass"], case["cloud"]["mass"]), f"step {t}: particles duplicated / dropped by the re-sort"
+        flagged.append(int(np.count_nonzero(st["x_GC"][:, 2] > (layer_hi - 1.5) * case["h"])))
+    assert S.status_flags() & 16
+    assert flagged[-1] > flagged[1] > 0, flagged
+    S.close()
+
+
 def test_config1_2d_10k_parity():
     """BASELINE configs[0] shape (2-D, 10 000 particles, explicit) on the HIP path against the oracle;
     LME + Hencky stand in for uGIMP / linear-elastic (no runnable reference equivalent)."""
@@ -1464,39 +1492,11 @@ def test_adaptive_resort_only_moves_memory():
         assert_close(a[k], b[k], 1e-10, f"adaptive re-sort on / off: {k}")
 
 
-@pytest.mark.skipif(not os.environ.get("NLPS_TEST_FUSED_STEP"), reason="k_step_fused is a developer switch (NLPS_TEST_FUSED_STEP=1 runs it)")
-def test_one_launch_step_matches_the_separate_kernels(monkeypatch):
-    """k_step_fused (K2, K3 and K5 of one explicit step as the stages of one persistent launch, tile flags in place of the
-    kernel boundaries): the same particle state as the three launches, and the nodal arrays it never stored come out of
-    nlps_gpu_explicit_nodal all the same."""
-    nsteps, dt = 6, 1e-4
-    case = small_case(3, velocity=[0.0, 0.0, -10.0])
-    n = nlps()
-    gb = n.BccSet([dirichlet_plane(case, 2, 2, nsteps)])
-    S = gpu_setup(case, nsteps=nsteps)
-    monkeypatch.setenv("NLPS_FUSED_STEP", "1")
-    Sf = gpu_setup(case, nsteps=nsteps)
-    monkeypatch.delenv("NLPS_FUSED_STEP")
-    Sf.set_timing(True)
-    for t in range(nsteps):
-        S.explicit_step(gb, t, dt)
-        Sf.explicit_step(gb, t, dt)
-    assert S.status_flags() == 0 and Sf.status_flags() == 0
-    assert Sf.get_timing()[7] == 1.0, "the one-launch form did not run"
-    a, b = S.download_state(), Sf.download_state()
-    assert np.array_equal(a["I0"], b["I0"])
-    for k in ("x", "vel", "acc", "Stress", "F_n", "J_n", "rho", "lambda"):
-        assert_close(b[k], a[k], 1e-11, f"{k}: one launch vs three")
-    na, nb = S.explicit_nodal(), Sf.explicit_nodal()
-    for k in ("mass", "dU", "force", "accel", "reaction"):
-        assert_close(nb[k], na[k], 1e-10, f"nodal {k}: one launch vs three", scale=1e-12)
-
-
 @pytest.mark.parametrize("ndim,material", [(2, DP), (3, NH)])
-def test_folded_step_matches_the_nodal_kernels(monkeypatch, ndim, material):
+def test_folded_step_matches_the_nodal_kernels(ndim, material):
     """Default on one GPU: K3 and K5 make dU and the accelerations of their window nodes themselves (k3_tile_lazy,
     k5_tile_lazy) and the nodal arrays are only made on request.  Same state, same nodal arrays as the form with the
-    nodal kernels between the stages (NLPS_LAZY_NODAL=0: what the multi-rank and deterministic paths run), also when
+    nodal kernels between the stages (debug option lazy_nodal = 0: what the deterministic path runs), also when
     the request comes late, after a download."""
     nsteps, dt = 5, 1e-4
     v = [0.0, -10.0] if ndim == 2 else [0.0, 0.0, -10.0]
@@ -1504,9 +1504,8 @@ def test_folded_step_matches_the_nodal_kernels(monkeypatch, ndim, material):
     n = nlps()
     gb = n.BccSet([dirichlet_plane(case, ndim - 1, 2, nsteps)])
     S = gpu_setup(case, nsteps=nsteps)
-    monkeypatch.setenv("NLPS_LAZY_NODAL", "0")
     Sn = gpu_setup(case, nsteps=nsteps)
-    monkeypatch.delenv("NLPS_LAZY_NODAL")
+    Sn.debug_option("lazy_nodal", 0)
     grav = [0.0] * (ndim - 1) + [-9.81]
     for t in range(nsteps):
         S.explicit_step(gb, t, dt, gravity=grav)
