@@ -303,6 +303,31 @@ int nlps_gpu_nodal_kinetic_increments(nlps_gpu *h, double *dU_dt, double *dU_dt2
 int nlps_gpu_nodal_inertial_forces(nlps_gpu *h, double *R, const double *M, const double *dU, const double *Un_dt,
                                    const double *Un_dt2, const double *alpha, const double *gravity);
 
+/* __lagrangian_evaluation, U-Newmark-beta.c:970-1058 -- the callback SNES runs at every Newton iterate and every
+ * line-search trial of the maintained driver -- as ONE call: VecZeroEntries(R), then
+ *   __compute_nodal_velocity_increments (:1020), __local_compatibility_conditions (:1023-1024),
+ *   __constitutive_update (:1028), __nodal_internal_forces (:1030-1031), __nodal_traction_forces (:1033-1034),
+ *   __nodal_inertial_forces (:1036-1038).
+ * On the device: the caller's dU is gathered, DF / F_n1 / J_n1 (J <= 0 clamped to 0 like :1137-1142), the stress update
+ * and the scatter of the internal force run as ONE pass over the particles with DF and tau handed over in registers
+ * (what nlps_gpu_compatibility + _constitutive + _internal_forces do in three passes with DF, F_n1, tau through HBM in
+ * between), then one nodal kernel adds the traction and inertial terms and leaves 0 on the Dirichlet dofs.
+ * The particle state afterwards is what the three separate stages leave: DF, F_n1, J_n1, Stress, W, b_e_n1, Kappa_n1,
+ * EPS_n1, C_ep (the n state is not touched: the residual is evaluated many times from it), so
+ * nlps_gpu_tangent_assemble / nlps_gpu_roll_state / nlps_gpu_update_kinetics follow it exactly as they follow the stages.
+ * R, dU, Un_dt, Un_dt2, M: masked [N_A*d], host (VecGetArray) or device pointers; R is OVERWRITTEN.  alpha[6] as for
+ * the per-dof updates above, gravity[ndim] or NULL, loads / nloads / step / thickness / area0 as for
+ * nlps_gpu_nodal_traction_forces (nloads = 0: none).  Needs nlps_gpu_local_search + nlps_gpu_active_masks first.
+ * flags: NLPS_LAGR_RATES   also the rate tensors dt_DF, dt_F_n1 (compute-Strains.c:48-72,176-207; only the Newtonian-fluid
+ *                          law, which is not on this path, reads them: off by default) -- runs the separate stages;
+ *        NLPS_LAGR_SEPARATE the composition of the separate stage calls (same results; what the fused form is tested and
+ *                          timed against).  The separate stages also run when the damage hooks are on
+ *                          (driver_eigenerosion / _eigensoftening: every stress before any force) or the cloud mixes laws. */
+enum { NLPS_LAGR_RATES = 1, NLPS_LAGR_SEPARATE = 2 };
+int nlps_gpu_lagrangian_evaluation(nlps_gpu *h, double *R, const double *dU, const double *Un_dt, const double *Un_dt2,
+                                   const double *M, const double *alpha, const double *gravity, const nlps_bcc *loads,
+                                   int nloads, int step, double thickness, const double *area0, int flags);
+
 /* ------------------------------------------------------------------ tangent assembly */
 
 /* __jacobian_evaluation (U-Newmark-beta.c:1646-1830) with stiffness_density__Constitutive__

@@ -3682,20 +3682,22 @@ __global__ void k_traction(PView P, GridD g, int n, const int* __restrict__ ids,
       }
 }
 
-extern "C" int nlps_gpu_nodal_traction_forces(nlps_gpu* h, double* R, const nlps_bcc* loads, int nloads, int step,
-                                              double thickness, const double* area0) {
-  if (need_masks(h, "nlps_gpu_nodal_traction_forces")) return 1;
+// the traction sums of the Neumann contours in grid numbering: out[nnodes][ND] = - sum N_pA T A0_p (zeroed first);
+// *any = 0 when the contours hold no particle (out is then left alone)
+static int traction_to_grid(nlps_gpu* h, const char* who, double* out, const nlps_bcc* loads, int nloads, int step,
+                            double thickness, const double* area0, int* any) {
   const int ND = h->nd, np = h->P.np;
+  *any = 0;
   if (step < 0 || step >= h->nsteps) {
-    h->err = "nlps_gpu_nodal_traction_forces: step outside [0, nsteps)";
+    h->err = std::string(who) + ": step outside [0, nsteps)";
     return 1;
   }
   if (ND == 3 && !area0) {
-    h->err = "nlps_gpu_nodal_traction_forces: the 3-D build needs Phi.Area_0 (area0)";
+    h->err = std::string(who) + ": the 3-D build needs Phi.Area_0 (area0)";
     return 1;
   }
   if (h->migrated) {
-    h->err = "nlps_gpu_nodal_traction_forces: not available after a migration (particle order is by global id)";
+    h->err = std::string(who) + ": not available after a migration (particle order is by global id)";
     return 1;
   }
   // the traction vector carries over from contour to contour where a direction is switched off (:1457-1461)
@@ -3708,7 +3710,7 @@ extern "C" int nlps_gpu_nodal_traction_forces(nlps_gpu* h, double* R, const nlps
     for (int q = 0; q < loads[l].nnodes; q++) {
       const int p = loads[l].nodes[q];
       if (p < 0 || p >= np) {
-        h->err = "nlps_gpu_nodal_traction_forces: particle index outside the cloud";
+        h->err = std::string(who) + ": particle index outside the cloud";
         return 1;
       }
       ids.push_back(p);
@@ -3718,6 +3720,7 @@ extern "C" int nlps_gpu_nodal_traction_forces(nlps_gpu* h, double* R, const nlps
   }
   const int n = (int)ids.size();
   if (n == 0) return 0;
+  *any = 1;
   int* ids_d = nullptr;
   double *T_d = nullptr, *A_d = nullptr;
   HIPCHK(hipMalloc((void**)&ids_d, (size_t)n * sizeof(int)));
@@ -3727,16 +3730,24 @@ extern "C" int nlps_gpu_nodal_traction_forces(nlps_gpu* h, double* R, const nlps
   HIPCHK(hipMemcpyAsync(T_d, T.data(), (size_t)n * ND * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (ND == 3) HIPCHK(hipMemcpyAsync(A_d, A.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_inverse_perm, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->perm_d, np, h->sval_d);
-  HIPCHK(hipMemsetAsync(h->gridA, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
-  if (ND == 2) hipLaunchKernelGGL(k_traction<2>, dim3(nblk(n)), dim3(BLK), 0, h->stream, h->P, h->g, n, ids_d, h->sval_d, T_d, A_d, thickness, h->gridA);
-  else hipLaunchKernelGGL(k_traction<3>, dim3(nblk(n)), dim3(BLK), 0, h->stream, h->P, h->g, n, ids_d, h->sval_d, T_d, A_d, thickness, h->gridA);
+  HIPCHK(hipMemsetAsync(out, 0, (size_t)h->g.nnodes * ND * sizeof(double), h->stream));
+  if (ND == 2) hipLaunchKernelGGL(k_traction<2>, dim3(nblk(n)), dim3(BLK), 0, h->stream, h->P, h->g, n, ids_d, h->sval_d, T_d, A_d, thickness, out);
+  else hipLaunchKernelGGL(k_traction<3>, dim3(nblk(n)), dim3(BLK), 0, h->stream, h->P, h->g, n, ids_d, h->sval_d, T_d, A_d, thickness, out);
   HIPCHK(hipGetLastError());
-  const int st = from_grid(h, R, h->gridA, ND, ND, 0, 0, 1, nullptr);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // (the host vectors above are about to go)
   (void)hipFree(ids_d);
   (void)hipFree(T_d);
   if (A_d) (void)hipFree(A_d);
-  return st;
+  return 0;
+}
+
+extern "C" int nlps_gpu_nodal_traction_forces(nlps_gpu* h, double* R, const nlps_bcc* loads, int nloads, int step,
+                                              double thickness, const double* area0) {
+  if (need_masks(h, "nlps_gpu_nodal_traction_forces")) return 1;
+  int any = 0;
+  if (traction_to_grid(h, "nlps_gpu_nodal_traction_forces", h->gridA, loads, nloads, step, thickness, area0, &any)) return 1;
+  if (!any) return 0;
+  return from_grid(h, R, h->gridA, h->nd, h->nd, 0, 0, 1, nullptr);
 }
 
 extern "C" int nlps_gpu_roll_state(nlps_gpu* h) {
@@ -4350,6 +4361,129 @@ extern "C" int nlps_gpu_nodal_inertial_forces(nlps_gpu* h, double* R, const doub
     return 1;
   }
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// __lagrangian_evaluation (U-Newmark-beta.c:970-1058): the residual of the maintained driver's SNES solve, evaluated at
+// every Newton iterate and line-search trial, as one device call
+// ------------------------------------------------------------------------------------------------
+// Closing nodal kernel: L = f_int (+ traction) + M (alpha_1 dU - alpha_2 v - alpha_3 a - b) on the free dofs, 0 on the
+// Dirichlet ones (VecZeroEntries :1001, then the three += of :1033-1041 in that order: __nodal_internal_forces skips the
+// Dirichlet dofs at :1359, __nodal_inertial_forces at :1543, k_traction's sums are taken for the free dofs only like
+// :1480).  force / trac: grid numbering [nnodes][ND]; everything else masked.
+template <int ND>
+__global__ void k_lagrangian_nodal(int nnodes, const int* __restrict__ n2m, const int* __restrict__ d2m,
+                                   const double* __restrict__ force, const double* __restrict__ trac, double* __restrict__ R,
+                                   const double* __restrict__ M, const double* __restrict__ dU, const double* __restrict__ v,
+                                   const double* __restrict__ a, double a1, double a2, double a3, double b0, double b1,
+                                   double b2) {
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  const int m = n2m[A];
+  if (m < 0) return;
+  const double b[3] = {b0, b1, b2};
+#pragma unroll
+  for (int f = 0; f < ND; f++) {
+    const size_t i = (size_t)m * ND + f;
+    double r = 0.0;
+    if (d2m[i] != -1) {
+      r += force[(size_t)A * ND + f];
+      if (trac) r += trac[(size_t)A * ND + f];
+      r += M[i] * (a1 * dU[i] - a2 * v[i] - a3 * a[i] - b[f]);
+    }
+    R[i] = r;
+  }
+}
+
+extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const double* dU, const double* Un_dt,
+                                              const double* Un_dt2, const double* M, const double* alpha,
+                                              const double* gravity, const nlps_bcc* loads, int nloads, int step,
+                                              double thickness, const double* area0, int flags) {
+  if (need_masks(h, "nlps_gpu_lagrangian_evaluation")) return 1;
+  if (!R || !dU || !Un_dt || !Un_dt2 || !M || !alpha) {
+    h->err = "nlps_gpu_lagrangian_evaluation: R, dU, Un_dt, Un_dt2, M and alpha are required";
+    return 1;
+  }
+  const int ND = h->nd;
+  const size_t n = (size_t)h->nactive * ND;
+  // The composition of the separate stage calls, in the order of :1023-1041 -- on request (NLPS_LAGR_SEPARATE: the form
+  // the fused one is measured and tested against), for what the fused kernel does not carry (rate tensors, which only the
+  // Newtonian-fluid law reads; the damage hooks, which sit between the stress update and the force scatter and need
+  // every particle's stress before any force; clouds with several laws)
+  const bool fused = !(flags & (NLPS_LAGR_SEPARATE | NLPS_LAGR_RATES)) && !h->P.erosion && h->uniform_law >= 0 &&
+                     h->uniform_law <= NLPS_KLAW_FRICTIONAL && h->P.np > 0;
+  if (!fused) {
+    double* dV = nullptr;
+    if (flags & NLPS_LAGR_RATES) {  // __compute_nodal_velocity_increments, :1020
+      HIPCHK(hipMalloc((void**)&dV, std::max<size_t>(n, 1) * sizeof(double)));
+      if (nlps_gpu_nodal_kinetic_increments(h, dV, nullptr, dU, Un_dt, Un_dt2, alpha)) {
+        (void)hipFree(dV);
+        return 1;
+      }
+    }
+    int st = nlps_gpu_compatibility(h, dU, dV);
+    if (dV) {
+      (void)hipStreamSynchronize(h->stream);
+      (void)hipFree(dV);
+    }
+    if (st) return 1;
+    if (nlps_gpu_constitutive(h)) return 1;
+    if (is_device_ptr(R)) HIPCHK(hipMemsetAsync(R, 0, n * sizeof(double), h->stream));
+    else memset(R, 0, n * sizeof(double));
+    if (nlps_gpu_internal_forces(h, R)) return 1;
+    if (nloads > 0 && nlps_gpu_nodal_traction_forces(h, R, loads, nloads, step, thickness, area0)) return 1;
+    return nlps_gpu_nodal_inertial_forces(h, R, M, dU, Un_dt, Un_dt2, alpha, gravity);
+  }
+  if (materialise_roll(h)) return 1;
+  if (materialise_nodal(h)) return 1;  // (the forces of the last explicit step are about to go)
+  h->level_b_fields = true;            // C_ep holds data from here on
+  VecIO io;
+  if (vec_begin(h, "nlps_gpu_lagrangian_evaluation", io)) return 1;
+  double* r = io.out(R, false);
+  const double *u = io.in(dU), *v = io.in(Un_dt), *a = io.in(Un_dt2), *m = io.in(M);
+  // the caller's dU in grid numbering (the gather windows read N.dU), the force accumulator of the node window reset
+  hipLaunchKernelGGL(k_expand, dim3(nblk(h->g.nnodes)), dim3(BLK), 0, h->stream, h->N.dU, u, h->n2m_d, h->g.nnodes, ND);
+  HIPCHK(hipMemsetAsync(h->N.force + (size_t)h->n0 * ND, 0, (size_t)h->nwn * ND * sizeof(double), h->stream));
+  {
+    TileD td = tile_view(h);
+    td.slab = nullptr;  // (level-B semantics: atomics also in deterministic mode, like kb_fint_tile)
+    const dim3 grid(h->ntw * K3_SPLIT), blk(K3_BLK);
+#define NLPS_K3R(NDv, LAWv)                                                                                          \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 3>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, \
+                     (const double*)nullptr)
+    const int law = h->uniform_law;
+    if (ND == 2) {
+      if (law == 0) NLPS_K3R(2, 0);
+      else if (law == 1) NLPS_K3R(2, 1);
+      else if (law == 2) NLPS_K3R(2, 2);
+      else if (law == 3) NLPS_K3R(2, 3);
+      else NLPS_K3R(2, 4);
+    } else {
+      if (law == 0) NLPS_K3R(3, 0);
+      else if (law == 1) NLPS_K3R(3, 1);
+      else if (law == 2) NLPS_K3R(3, 2);
+      else if (law == 3) NLPS_K3R(3, 3);
+      else NLPS_K3R(3, 4);
+    }
+#undef NLPS_K3R
+  }
+  HIPCHK(hipGetLastError());
+  if (halo(h, h->N.force, ND, 8, 0)) return 1;
+  int any = 0;
+  if (nloads > 0 && traction_to_grid(h, "nlps_gpu_lagrangian_evaluation", h->gridA, loads, nloads, step, thickness, area0, &any))
+    return 1;
+  double b[3] = {0, 0, 0};
+  if (gravity)
+    for (int k = 0; k < ND; k++) b[k] = gravity[k];
+  LAUNCH_ND((k_lagrangian_nodal<2>), (k_lagrangian_nodal<3>), nblk(h->g.nnodes), h->g.nnodes, (const int*)h->n2m_d,
+            (const int*)h->d2m_d, (const double*)h->N.force, any ? (const double*)h->gridA : (const double*)nullptr, r, m, u, v,
+            a, alpha[0], alpha[1], alpha[2], b[0], b[1], b[2]);
+  HIPCHK(hipGetLastError());
+  if (io.finish()) {
+    h->err = "nlps_gpu_lagrangian_evaluation: HIP error";
+    return 1;
+  }
+  return check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -915,6 +915,11 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
 // ------------------------------------------------------------------------------------------------
 // MODE 1: fused explicit stage (S3+S4).  MODE 0: __local_compatibility_conditions only (level B):
 // DF, F_n1, J_n1 with the implicit driver's clamp of J <= 0 (U-Newmark-beta.c:1137-1142).
+// MODE 3: the implicit driver's residual, __lagrangian_evaluation (U-Newmark-beta.c:970-1058), as ONE pass: the gather of the
+// caller's dU -> DF, F_n1, J_n1 with the implicit clamp -> Stress_integration__Constitutive__ with everything the level-B
+// constitutive stage stores (tau, W, b_e,n+1, kappa_n+1, eps_n+1, C_ep: the n state stays untouched, the residual is
+// evaluated many times from it) -> P2G of the internal force.  Same registers-only hand-over of DF, tau between the
+// stages as MODE 1, same kernel skeleton and occupancy; what it adds are the stores of the n+1 state.
 // MODE 2: MODE 0 plus the rate tensors dt_DF = sum dV_A (x) grad N_A and dt_F_n1 = dt_DF F_n + DF dt_F_n
 // (compute-Strains.c:48-72, 176-207) from a second gather window dV.
 // FILT (clouds with several laws): the launch handles only the tile's particles whose material follows LAW; they are
@@ -925,9 +930,9 @@ __global__ __launch_bounds__(NT, NT == 64 ? 1 : (ND == 2 ? NLPS_K2_WAVES_2D : NL
 template <int ND, int LAW, int MODE>
 struct K3Waves {
   static constexpr int value = ND == 2 ? NLPS_K3_WAVES_2D
-                               : (MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN) ? NLPS_K3_WAVES_NH
-                               : (MODE == 1 && LAW == NLPS_MAT_HENCKY)      ? NLPS_K3_WAVES_HENCKY
-                               : (MODE == 1 && LAW == NLPS_MAT_DRUCKER_PRAGER) ? NLPS_K3_WAVES_DP
+                               : ((MODE == 1 || MODE == 3) && LAW == NLPS_MAT_NEO_HOOKEAN) ? NLPS_K3_WAVES_NH
+                               : ((MODE == 1 || MODE == 3) && LAW == NLPS_MAT_HENCKY)      ? NLPS_K3_WAVES_HENCKY
+                               : ((MODE == 1 || MODE == 3) && LAW == NLPS_MAT_DRUCKER_PRAGER) ? NLPS_K3_WAVES_DP
                                                                                : NLPS_K3_WAVES;
 };
 // the LDS of k3_tile, owned by the caller of k3_body (the kernels below)
@@ -953,6 +958,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
                                         const K3Lds<ND, MODE, FILT>& lds, const NodalFold* fs) {
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr bool RATES = (MODE == 2);
+  constexpr bool SCATTER = (MODE == 1 || MODE == 3);  // the stress update and the force scatter follow the F update
   // gather window of dU: {x,y} as one 16-B double2 per node (ds_read_b128) + z as a separate 8-B array
   // (ds_read_b64): with node strides of 16 B and 8 B the tile's 64 I0 positions hit distinct banks; a
   // padded 32-B AoS row put every second node on the same banks (41 % conflict cycles measured).
@@ -1003,11 +1009,11 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
       cnt = nsel;
       listed = true;
       if (cnt == 0) {  // uniform: no particle of this law in the tile (its slab must still read as zeros)
-        if (MODE == 1 && td.slab) {
+        if (SCATTER && td.slab) {
           double* out = td.slab + ((size_t)tile * td.slab_n + td.slab_slot) * (ND * TileCfg<ND>::NWA);
           for (int qq = threadIdx.x; qq < TileCfg<ND>::NWA * ND; qq += NT) out[qq] = 0.0;
         }
-        if (MODE == 1) tile_signal(td, wb, nbnd);
+        if (SCATTER) tile_signal(td, wb, nbnd);
         return;
       }
     }
@@ -1058,7 +1064,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     // (requested with the particle's other operands: the constants of its material are then one load away, not two, when
     // the stress update asks for them behind the gather)
-    const int mat_idx = (MODE == 1) ? P.mat[p] : -1;
+    const int mat_idx = SCATTER ? P.mat[p] : -1;
     const int base = window_base<ND>(c.ijk, w0);
     NLPS_YZ_LOCALS(c);
     PH(9)
@@ -1081,7 +1087,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     // which is what lets the elastic laws run at three waves per SIMD; it costs ~350 more VALU instructions a particle.
     // (the level-B modes keep the single pass: with and without rate tensors they must give the same F bit for bit)
     // and the laws that stay at two waves per SIMD keep it too: there the second set of masked weights only costs)
-    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && MODE == 1 && (K3Waves<ND, LAW, MODE>::value >= 3 || NLPS_K3_TWOPASS_ALL);
+    constexpr bool TWOPASS = (NLPS_K3_TWOPASS != 0) && ND == 3 && SCATTER && (K3Waves<ND, LAW, MODE>::value >= 3 || NLPS_K3_TWOPASS_ALL);
     // NLPS_K3_PRELOAD_FN (off): F_n requested between the two passes -- the moments pass touches no memory and keeps fewer
     // values alive than the gather, so the nine loads would land under it instead of in front of the F update; at 168
     // registers the nine values do not fit beside it (40 B of scratch, 2 % slower)
@@ -1180,7 +1186,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
       for (int a = 0; a < ND; a++) Gx[a] = Gy[a] = Gz[a] = Hx[a] = Hy[a] = Hz[a] = 0.0;
       // DIRECT (3-D, no rate tensors): every row goes straight into the totals with its y*z weight -- 15 doubles of
       // plane partials less to keep alive (the kernel then fits three waves per SIMD), for 5 more FMAs per row
-      constexpr bool DIRECT = (NLPS_K3_DIRECT != 0) && ND == 3 && MODE == 1 && LAW == NLPS_MAT_NEO_HOOKEAN;
+      constexpr bool DIRECT = (NLPS_K3_DIRECT != 0) && ND == 3 && SCATTER && LAW == NLPS_MAT_NEO_HOOKEAN;
       const double zd0 = ez5[k], zd1 = zd0 * (double)(k - 2), zd2 = zd1 * (double)(k - 2);
 #pragma unroll NLPS_JUNROLL_K3
       for (int j = 0; j < 5; j++) {
@@ -1405,7 +1411,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
       store_block<ND>(P, F_DTDF, pl, dDF, 0.0, false);
       store_block<ND>(P, F_DTFN1, pl, dFn1, 0.0, false);
     }
-    if (MODE != 1) {
+    if (!SCATTER) {
       if (st) {
         atomicOr(&P.status[pl], st);
         atomicOr(gstatus, st);
@@ -1413,10 +1419,13 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
       continue;
     }
     // (the density update rho <- rho / det DF of U-Verlet.c:630-632 costs no traffic: rho J is invariant, F_RHOJ)
+    if (MODE == 1) {
 #pragma unroll
-    for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, pl) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
+      for (int a = 0; a < ND; a++) PF(P, F_DDIS + a, pl) = U[a] * Zinv;  // d_dis_p = sum N dU (used by K5)
+    }
     double tau[ND * ND], B[ND * ND];
-    st |= stress_update<ND, LAW, false, (LAW == NLPS_KLAW_FRICTIONAL), true>(P, pl, mats, prm, Fn1, DF, Jn1, tau, mat_idx);
+    // (MODE 3: C_ep kept for the tangent that may follow, everything to the n+1 slots)
+    st |= stress_update<ND, LAW, MODE == 3, (LAW == NLPS_KLAW_FRICTIONAL), MODE == 1>(P, pl, mats, prm, Fn1, DF, Jn1, tau, mat_idx);
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), -1.0);
     PH(11)
     if (fo_ok) {
@@ -1426,7 +1435,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
       // Measured at 1 M particles: Hencky at three waves per SIMD without scratch 0.290 ms (0.295 at two); Drucker-Prager
       // gains nothing from it (two waves with the reload 0.363 ms, three 0.358 ms with 212 B of scratch, 0.348 ms as it
       // was): those kernels are bound by their instruction count (4100 / 5900 static), not by latency.
-      constexpr bool RELOAD = (NLPS_K3_RELOAD != 0) && ND == 3 && MODE == 1 && LAW != NLPS_MAT_NEO_HOOKEAN && K3Waves<ND, LAW, MODE>::value >= 3;
+      constexpr bool RELOAD = (NLPS_K3_RELOAD != 0) && ND == 3 && SCATTER && LAW != NLPS_MAT_NEO_HOOKEAN && K3Waves<ND, LAW, MODE>::value >= 3;
       Lme<ND> cs;
       if (RELOAD) {
         int p2 = pl;
@@ -1500,7 +1509,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     }
     PH(12)
   }
-  if (MODE != 1) return;
+  if (!SCATTER) return;
   __syncthreads();
   PH(13)
   if (td.slab) {
@@ -1537,8 +1546,8 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
   __shared__ int sel[L::SELCAP];
   __shared__ int nsel;
   __shared__ int wcnt[NT / 64];
-  const int nbnd = (MODE == 1 && td.sig_flag) ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;
-  if (MODE == 1) tile_signal_empty(td, nbnd);
+  const int nbnd = ((MODE == 1 || MODE == 3) && td.sig_flag) ? td.range[4 + 2 * (K3_SPLIT - 1) + 1] : 0;
+  if (MODE == 1 || MODE == 3) tile_signal_empty(td, nbnd);
   TileWork tw;
   if (!tile_work_item<K3_SPLIT>(td, tw)) return;
   const L lds{dvxy, dvz, duxy, duz, fac, sel, &nsel, wcnt};

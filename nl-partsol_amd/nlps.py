@@ -64,7 +64,7 @@ HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int
 _LIB = None
 
 # every symbol include/nlps_gpu.h declares
-SYMBOLS = ["nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_gpu_synchronize",
+SYMBOLS = ["nlps_gpu_lagrangian_evaluation", "nlps_gpu_create", "nlps_gpu_destroy", "nlps_gpu_last_error", "nlps_gpu_synchronize",
            "nlps_gpu_download_state", "nlps_gpu_download_lists", "nlps_gpu_shape_functions", "nlps_gpu_download_active",
            "nlps_gpu_status_flags", "nlps_gpu_initialize_lme", "nlps_gpu_local_search", "nlps_gpu_active_masks",
            "nlps_gpu_set_node_numbering",
@@ -531,6 +531,24 @@ class Solver:
         gv = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float64)
         self._chk(self.L.nlps_gpu_nodal_inertial_forces(self.h, _vp(R), _vp(M), _vp(dU), _vp(Un_dt), _vp(Un_dt2), _d(al),
                                                         _d(gv)))
+        return R
+
+    LAGR_RATES, LAGR_SEPARATE = 1, 2
+
+    def lagrangian_evaluation(self, dU, Un_dt, Un_dt2, M, alpha, gravity=None, loads=None, step=0, thickness=1.0,
+                              area0=None, flags=0, out=None):  # __lagrangian_evaluation
+        """The residual of the implicit driver's SNES solve as one device call (nlps_gpu_lagrangian_evaluation).
+        Vectors: numpy arrays (host) or torch tensors (device); out = the residual vector to overwrite (default: a new
+        numpy array)."""
+        self.L.nlps_gpu_lagrangian_evaluation.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [_dp, _dp, C.POINTER(Bcc), C.c_int,
+                                                          C.c_int, C.c_double, C.c_void_p, C.c_int]
+        R = np.zeros(self.nactive * self.ndim) if out is None else out
+        al = np.ascontiguousarray(alpha, dtype=np.float64)
+        gv = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float64)
+        a0 = None if area0 is None else np.ascontiguousarray(area0, dtype=np.float64)
+        self._chk(self.L.nlps_gpu_lagrangian_evaluation(
+            self.h, _vp(R), _vp(dU), _vp(Un_dt), _vp(Un_dt2), _vp(M), _d(al), _d(gv), None if loads is None else loads.arr,
+            0 if loads is None else loads.n, int(step), float(thickness), None if a0 is None else a0.ctypes.data, int(flags)))
         return R
 
     def jacobian_evaluation(self, alpha_1=0.0, lumped_mass=None, apply_dirichlet=False):  # __jacobian_evaluation

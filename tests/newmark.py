@@ -11,7 +11,8 @@ def newmark_parameters(beta, gamma, dt):  # __compute_Newmark_parameters, :497-5
 
 def newmark_step(stage, ndim, bcs_list, step, nsteps, dt, gravity, beta=0.25, gamma=0.5, tol=1e-10, max_iter=12):
     """stage: object with local_search(), masks(bcs, step) -> (n2m, d2m, na), lumped_mass(), nodal_field_n(M),
-    compatibility(dU, dU_dt), constitutive(), internal_forces(), tangent(alpha_1, M) -> dense K with Dirichlet
+    compatibility(dU, dU_dt), constitutive(), internal_forces() -- or lagrangian(dU, Un_dt, Un_dt2, M, alpha, gravity) in
+    their place --, tangent(alpha_1, M) -> dense K with Dirichlet
     identity rows, roll(), update_kinetics(dU, Un_dt, dU_dt, dU_dt2).  Returns (dU, residual history)."""
     a = newmark_parameters(beta, gamma, dt)
     stage.local_search()                                           # :197
@@ -40,13 +41,16 @@ def newmark_step(stage, ndim, bcs_list, step, nsteps, dt, gravity, beta=0.25, ga
             dU_dt, _ = stage.kinetic_increments(dU, Un_dt, Un_dt2, alpha)
         else:
             dU_dt = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2    # :1836-1856
-        stage.compatibility(dU, dU_dt)                                          # :1026
-        stage.constitutive()                                                    # :1031
-        R = stage.internal_forces()                                             # :1033 (Dirichlet dofs skipped)
-        if hasattr(stage, "inertial_forces"):
-            R = stage.inertial_forces(R, M, dU, Un_dt, Un_dt2, alpha, gravity)
+        if hasattr(stage, "lagrangian"):                                        # __lagrangian_evaluation as one call
+            R = stage.lagrangian(dU, Un_dt, Un_dt2, M, alpha, gravity)
         else:
-            R[free] += (M * (a["a1"] * dU - a["a2"] * Un_dt - a["a3"] * Un_dt2 - bvec))[free]   # :1519-1557
+            stage.compatibility(dU, dU_dt)                                          # :1026
+            stage.constitutive()                                                    # :1031
+            R = stage.internal_forces()                                             # :1033 (Dirichlet dofs skipped)
+            if hasattr(stage, "inertial_forces"):
+                R = stage.inertial_forces(R, M, dU, Un_dt, Un_dt2, alpha, gravity)
+            else:
+                R[free] += (M * (a["a1"] * dU - a["a2"] * Un_dt - a["a3"] * Un_dt2 - bvec))[free]   # :1519-1557
         res = float(np.linalg.norm(R[free]))
         history.append(res)
         if res <= tol * max(1.0, history[0]):

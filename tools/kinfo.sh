@@ -1,23 +1,25 @@
 #!/bin/bash
-# Developer tool: register / scratch / LDS figures of the step kernels of one build:  tools/kinfo.sh [extra hipcc flags]
+# Developer tool: register / scratch / LDS figures of the tile kernels of one build:  tools/kinfo.sh [extra hipcc flags]
+# (every k2_tile / k3_tile / k3_tile_lazy / k5_tile / k5_tile_lazy instantiation of the 3-D build, demangled)
 cd "$(dirname "$0")/.."
 mkdir -p build/kd
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden "$@" \
+[ -n "$KINFO_REUSE" ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fvisibility=hidden "$@" \
   --cuda-device-only -S -o build/kd/info.s nl-partsol_amd/csrc/nlps_gpu.hip 2>/dev/null
 python3 - <<'PY'
-import re
+import re, subprocess
 txt = open('build/kd/info.s').read()
-for name in ["_Z7k2_tileILi3ELb1ELi256ELi1EE", "_Z7k3_tileILi3ELi0ELi1ELb0ELi256EE", "_Z7k3_tileILi3ELi1ELi1ELb0ELi256EE",
-             "_Z7k3_tileILi3ELi2ELi1ELb0ELi256EE", "_Z7k5_tileILi3ELi0EE", "_Z8k_searchILi3EE"]:
-    m = re.search(r"\.amdhsa_kernel (%s\S*)(.*?)\.end_amdhsa_kernel" % re.escape(name), txt, re.S)
-    if not m:
+for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+    name, body = m.group(1), m.group(2)
+    if not re.match(r"_Z\d+k[235]_tile", name):
         continue
-    body = m.group(2)
+    dem = subprocess.run(["/usr/bin/c++filt", name], capture_output=True, text=True).stdout.strip()
+    dem = dem.split("(")[0].replace("void ", "")
+    if "<3," not in dem:
+        continue
     g = lambda k: re.search(r"\.amdhsa_%s (\S+)" % k, body).group(1)
-    # instruction count
-    s = txt.find("\n" + m.group(1) + ":")
-    e = txt.find(".amdhsa_kernel " + m.group(1))
+    s = txt.find("\n" + name + ":")
+    e = txt.find(".amdhsa_kernel " + name)
     n = sum(1 for l in txt[s:e].split("\n") if l.startswith("\t") and not l.strip().startswith((".", ";")))
-    print("%-40s vgpr %s scratch %s lds %s instr %d" % (name[:40], g("next_free_vgpr"), g("private_segment_fixed_size"),
-                                                         g("group_segment_fixed_size"), n))
+    print("%-44s vgpr %3s agpr %3s scratch %4s lds %6s instr %5d" % (dem[:44], g("next_free_vgpr"), g("accum_offset") if False else "-",
+                                                         g("private_segment_fixed_size"), g("group_segment_fixed_size"), n))
 PY
