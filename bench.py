@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 # algorithmic bytes per particle per stage, FP64, 3-D (SURVEY.md §8d / BASELINE.md §3.4)
 BYTES_3D = {"S1": 100, "S2": 123, "S3": 371, "S4": 215, "S5": 408, "step": 1217}
+BYTES_2D = {"S1": 76, "S2": 94, "S3": 228, "S4": 136, "S5": 276, "step": 810}  # SURVEY 8d, the 2-D column
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PARTITION_TOL = 1e-9        # partitioned vs whole cloud (max relative field error): ONE constant for the step-down and the abort
 FP64_VEC_PEAK_TFLOPS = 78.6  # half the 157.3 TF FP32 vector peak
@@ -54,9 +55,14 @@ def parse():
     ap.add_argument("--migrate-every", type=int, default=0,
                     help="N > 1: hand particles whose closest node left the rank's slab to the neighbour every k "
                          "steps (0 = never: the default 25 steps move the cloud by 0.25 cells)")
-    ap.add_argument("--workload", choices=["step", "tangent"], default="step",
+    ap.add_argument("--workload", choices=["step", "tangent", "residual", "step2d"], default="step",
                     help="step: the explicit particle step (the headline metric); tangent: the Neo-Hookean tangent "
-                         "assembly of the implicit driver (SURVEY 8f n1), one JSON line per case")
+                         "assembly of the implicit driver (SURVEY 8f n1), one JSON line per case; residual: the implicit "
+                         "driver's residual callback (nlps_gpu_lagrangian_evaluation), fused vs separate stages, one "
+                         "JSON line per law (Neo-Hookean, Drucker-Prager); step2d: the 2-D explicit step alone (the "
+                         "`secondary` record of the default run as its own line, for the profiler)")
+    ap.add_argument("--residual-laws", default="nh,dp")
+    ap.add_argument("--no-implicit", action="store_true", help="skip the `implicit` record of the default run (N = 1 only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --cells^3 x 8 particles per rank; strong: --particles-total split into z-slabs")
     ap.add_argument("--particles-total", type=int, default=8000000, help="--scaling strong: size of the one job")
@@ -224,6 +230,164 @@ def bench_tangent(a):
             out["cpu_baseline"] = cpu[ndim]
         print(json.dumps(out), flush=True)
         S.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# --workload residual: nlps_gpu_lagrangian_evaluation, the residual callback of the maintained implicit driver
+# (__lagrangian_evaluation, U-Newmark-beta.c:970-1058: SNES runs it at every Newton iterate and line-search trial), as
+# one fused device call against the composition of the separate stage entries, with device-resident and with host
+# (VecGetArray) vectors; the oracle's composition of the same stages is the cpu_baseline leg
+# ---------------------------------------------------------------------------------------------------
+RESIDUAL_BYTES_3D = {"nh": BYTES_3D["S3"] + BYTES_3D["S4"], "dp": BYTES_3D["S3"] + BYTES_3D["S4"] + 176}  # S3 + S4 (+ S3' for D-P)
+
+
+def residual_cpu_baseline(cells, law):
+    """The oracle's composition of the stages of __lagrangian_evaluation (:1020-1038) on a bounded sample of the same
+    cloud: compatibility + constitutive + internal forces (OpenMP, the reference's omp-critical accumulation) + the
+    inertial term (numpy), 1 thread and this GPU's share of the host cores."""
+    os.environ.pop("OMP_NUM_THREADS", None)
+    from oracle import orc
+    orc.use_fast_build(True)
+    synth = importlib.import_module("nl-partsol_amd.synth")
+    margin = 5
+    gc = [cells + 2 * margin] * 3
+    gn = synth.grid_nodes(gc)
+    M = orc.OracleMesh(3, gn, [0.0] * 3, 1.0)
+    prm = orc.default_params()
+    mat = {"type": 0, "E": 1.0e7, "nu": 0.3} if law == "nh" else synth.drucker_prager_material()
+    mats = orc.make_materials([mat])
+    cloud = synth.make_cloud(3, gc, [margin] * 3, [cells] * 3, velocity=[0.0, 0.0, -10.0])
+    if law == "dp":
+        cloud["kappa_n"][:] = mat["kappa_0"]
+    P = orc.OracleParticles(cloud)
+    assert orc.initialize_lme(P, M, prm) == 0
+    n2m, na = orc.active_nodes(M)
+    nodes = synth.plane_nodes(gn, 2, margin)
+    bcs = orc.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, 1), dtype=np.int32), "value": np.zeros((3, 1))}])
+    d2m, _ = orc.active_dofs(n2m, na, 3, bcs, 0, 1)
+    Mv = orc.lumped_mass(P, M, n2m, na)
+    V, A = orc.nodal_field_n(Mv, P, M, n2m, d2m, na)
+    rng = np.random.default_rng(0)
+    dU = (2e-2 if law == "dp" else 1e-3) * rng.normal(size=na * 3)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    nall = min(ncpu, 16)
+    rates = {}
+    for nthr in sorted({1, nall}):
+        orc.set_num_threads(nthr)
+        ts = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            assert orc.compatibility(dU, None, P, M, n2m) == 0
+            assert orc.constitutive(P, mats, prm) == 0
+            R, st = orc.internal_forces(P, M, n2m, d2m, na)
+            R[d2m != -1] += (Mv * (4.0e6 * dU - 4.0e3 * V - A))[d2m != -1]
+            if it > 0:
+                ts.append(time.perf_counter() - t0)
+        rates[nthr] = P.np / float(np.median(ts))
+    best = max(rates, key=rates.get)
+    return {"value": rates[best], "unit": "particle-residuals/s", "cores": best, "kind": "port",
+            "threads_1": rates[1], "threads_all": rates[nall], "threads_all_count": nall, "host_cores": ncpu,
+            "sample": "%d^3 cells x 8 = %d particles, 3-D LME %s: oracle compatibility + constitutive + internal forces + "
+                      "inertial term, median of 3 evaluations after one warm-up, -Ofast -fopenmp"
+                      % (cells, P.np, "Neo-Hookean" if law == "nh" else "Drucker-Prager")}
+
+
+def bench_residual(a, stream=None, laws=("nh", "dp"), cpu=True, emit=True):
+    """-> list of records (one per law); with emit, one JSON line per law"""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    nlps = importlib.import_module("nl-partsol_amd.nlps")
+    synth = importlib.import_module("nl-partsol_amd.synth")
+    if stream is None:
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
+    recs = []
+    for law in laws:
+        case = build_case(0, 1, a.cells)
+        grav = [0.0, 0.0, -9.81]
+        amp = 1e-3
+        if law == "dp":
+            dp = synth.drucker_prager_material()
+            case["materials"] = [dp]
+            case["cloud"]["kappa_n"][:] = dp["kappa_0"]
+            amp = 2e-2  # large enough that part of the cloud yields (the return mapping is what configs[4] is about)
+        S = nlps.Solver(3, case["grid_n"], case["origin"], case["h"], case["cloud"], case["materials"], nsteps=1, stream=stream)
+        S.initialise_shapefun()
+        S.local_search()
+        nodes = synth.plane_nodes(case["grid_n"], 2, case["block_lo"][2])
+        gb = nlps.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, 1), dtype=np.int32), "value": np.zeros((3, 1))}])
+        S.active_masks(gb, 0)
+        n = S.nactive * 3
+        Mv = S.compute_nodal_lumped_mass()
+        V, A = S.get_nodal_field_n(Mv)
+        dt = 1.0e-3  # (an implicit step: 10 x the explicit limit of this cloud)
+        alpha = [1 / (0.25 * dt * dt), 1 / (0.25 * dt), 1.0, 0.5 / (0.25 * dt), -1.0, 0.0]
+        rng = np.random.default_rng(0)
+        dU = amp * rng.normal(size=n)
+        host = [dU, V, A, Mv]
+        dev = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in host]
+        R_h = np.zeros(n)
+        R_d = torch.zeros(n, dtype=torch.float64, device="cuda")
+        S.set_timing(True)
+
+        def run(vecs, R, flags):
+            ktimes = []
+            for _ in range(a.warmup):
+                S.lagrangian_evaluation(vecs[0], vecs[1], vecs[2], vecs[3], alpha, grav, out=R, flags=flags)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                S.lagrangian_evaluation(vecs[0], vecs[1], vecs[2], vecs[3], alpha, grav, out=R, flags=flags)
+                ktimes.append(S.get_timing()[2])
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / a.steps, float(np.mean(ktimes))
+
+        fused_dev, k_ms = run(dev, R_d, 0)
+        fused_host, _ = run(host, R_h, 0)
+        S.set_timing(False)
+        sep_dev, _ = run(dev, R_d, S.LAGR_SEPARATE)
+        sep_host, _ = run(host, R_h, S.LAGR_SEPARATE)
+        # the two forms agree (the parity tests hold them against the oracle; this is the bench checking itself)
+        S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, grav, out=R_d, flags=0)
+        r1 = R_d.cpu().numpy().copy()
+        S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, grav, out=R_d, flags=S.LAGR_SEPARATE)
+        agree = float(np.max(np.abs(r1 - R_d.cpu().numpy())) / max(np.max(np.abs(r1)), 1e-300))
+        st = S.download_state(fields=["EPS_n1", "EPS_n"])
+        yielding = float(np.mean(st["EPS_n1"] > st["EPS_n"]))
+        flags = S.status_flags()
+        npart = S.np
+        S.close()
+        alg = RESIDUAL_BYTES_3D[law]
+        achieved = npart * alg / (k_ms * 1e-3) / 1e9
+        rec = {"metric": "particle-residuals/sec (G2P grad + F-update + stress + P2G internal force, one SNES residual evaluation)",
+               "value": npart / (fused_dev * 1e-3), "unit": "particle-residuals/s", "n_gpus": 1, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": fused_dev, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "3-D cube, %d particles (%d^3 cells x 8), LME gamma=3, %s, one evaluation of "
+                                      "__lagrangian_evaluation (U-Newmark-beta.c:970-1058) per step; value = fused entry, "
+                                      "device-resident vectors" % (npart, a.cells, "Neo-Hookean E=1e7 nu=0.3" if law == "nh"
+                                                                   else "Drucker-Prager (%.0f %% of the particles yielding)" % (100 * yielding)),
+                          "active_dofs": int(n)},
+               "fused_ms": {"device_vectors": fused_dev, "host_vectors_VecGetArray": fused_host},
+               "separate_stages_ms": {"device_vectors": sep_dev, "host_vectors_VecGetArray": sep_host},
+               "fused_over_separate": sep_dev / fused_dev, "fused_vs_separate_max_rel_diff": agree, "status_flags": flags,
+               "roofline": {"bound": "hbm", "kernel": "k3_tile<3,%d,3> (MODE 3)" % (0 if law == "nh" else 2), "achieved": achieved,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "kernel_ms": k_ms, "algorithmic_bytes_per_particle": alg,
+                            "note": "kernel_ms: HIP events on the handle's stream around the MODE-3 launch inside the timed "
+                                    "evaluations (nlps_gpu_get_timing slot 2); algorithmic bytes = SURVEY 8d S3 + S4%s; "
+                                    "counter traffic: profiles/r04_residual_*" % (" + S3'" if law == "dp" else "")}}
+        if cpu and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = residual_cpu_baseline(a.cpu_cells, law)
+        recs.append(rec)
+        if emit:
+            print(json.dumps(rec), flush=True)
+    return recs
 
 
 def stirred_figure(nlps, synth, a, stream):
@@ -623,20 +787,56 @@ def secondary_2d(ctx):
     ms = 1e3 * (time.perf_counter() - t0) / a.steps
     flags = S.status_flags()
     npart = cloud["x"].shape[0]
+    # per kernel (the one regime where north_star's "40 % of HBM on the P2G scatter" is physically in reach): HIP-event
+    # brackets of further steps minus the calibration bracket, like the 3-D record; counter bytes from the rocprofv3 PMC
+    # passes of `bench.py --workload step2d` (tools/profile.sh twod -> profiles/hbm_traffic_2d.json)
+    S.set_timing(True)
+    kms = np.zeros(8)
+    reps = 20
+    for _ in range(reps):
+        S.explicit_step(bcs, nsteps - 1, dt)
+        kms += np.array(S.get_timing())
+    kms /= reps
+    S.set_timing(False)
+    kms[:4] = np.maximum(kms[:4] - float(kms[5]), 0.0)
     S.close()
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_2d.json")))
+    except Exception:
+        pmc = {}
+    names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update"]
+    alg = [0, BYTES_2D["S1"] + BYTES_2D["S2"], BYTES_2D["S3"] + BYTES_2D["S4"], BYTES_2D["S5"]]
+    per_kernel = {}
+    for i in range(1, 4):
+        t_s = kms[i] * 1e-3
+        if t_s <= 0:
+            continue
+        e = {"kernel_ms": float(kms[i]), "algorithmic_bytes_per_particle": alg[i],
+             "hbm_frac": npart * alg[i] / t_s / 1e9 / HBM_PEAK_GBS}
+        if names[i] in pmc:
+            e["traffic_bytes"] = pmc[names[i]] * npart / 1.0e6
+            e["traffic_frac"] = e["traffic_bytes"] / t_s / 1e9 / HBM_PEAK_GBS
+        per_kernel[names[i]] = e
     gbs = npart * 810.0 / (ms * 1e-3) / 1e9
     return {"workload": "2-D, %d particles (%d^2 cells x 4), LME gamma=3, Neo-Hookean, explicit step" % (npart, cells),
             "ms_per_step": ms, "value": npart / (ms * 1e-3), "unit": "particle-steps/s", "steps": a.steps,
             "algorithmic_bytes_per_particle_step": 810, "achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-            "status_flags": flags, "resorts_in_timed_region": 1}
+            "status_flags": flags, "resorts_in_timed_region": 1, "per_kernel": per_kernel,
+            "kernel_ms_all": {"search+activate": float(kms[0]), "lists+newton+p2g_mass_mom": float(kms[1]),
+                              "g2p_grad+stress+p2g_force": float(kms[2]), "g2p_update": float(kms[3]), "nodal": float(kms[4])}}
 
 
 def main():
     a = parse()
     if a.workload == "tangent":
         return bench_tangent(a)
+    if a.workload == "residual":
+        return bench_residual(a, laws=tuple(a.residual_laws.split(",")))
     ctx = Ctx(a)
     rank, world = ctx.rank, ctx.world
+    if a.workload == "step2d":
+        print(json.dumps(secondary_2d(ctx)), flush=True)
+        return
     check = partition_check(ctx) if world > 1 and not a.no_partition_check else None
     if check is not None and (check["max_rel_err"] > PARTITION_TOL or not check["index_maps_equal"] or check["status_flags"]):
         raise SystemExit("bench: the partitioned run does not reproduce the single-solver run: %r" % check)
@@ -655,6 +855,12 @@ def main():
         stirred = stirred_figure(ctx.nlps, ctx.synth, a, ctx.stream)
     if world == 1 and not a.no_secondary:
         second = secondary_2d(ctx)
+    implicit = None
+    if world == 1 and not a.no_implicit:  # the maintained driver's hot call at the same size (Neo-Hookean), short form
+        r = bench_residual(a, stream=ctx.stream, laws=("nh",), cpu=False, emit=False)[0]
+        implicit = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "fused_ms", "separate_stages_ms",
+                                      "fused_over_separate", "fused_vs_separate_max_rel_diff", "roofline", "status_flags")}
+        implicit["workload"] = r["config"]["workload"]
     if rank == 0:
         npart = rec["particles_rank0"]
         names = ["search+activate", "lists+newton+p2g_mass_mom", "g2p_grad+stress+p2g_force", "g2p_update", "nodal"]
@@ -730,6 +936,8 @@ def main():
             out[other] = {"skipped": other_skipped}
         if check is not None:
             out["partition_check"] = check
+        if implicit is not None:
+            out["implicit"] = implicit
         if stirred is not None:
             out["stirred_ms_per_step"] = stirred["ms_per_step"]
             out["stirred"] = stirred

@@ -4439,11 +4439,13 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
   h->level_b_fields = true;            // C_ep holds data from here on
   VecIO io;
   if (vec_begin(h, "nlps_gpu_lagrangian_evaluation", io)) return 1;
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));  // slots of nlps_gpu_get_timing: [0] staging, [2] the kernel, [4] nodal + copy back
   double* r = io.out(R, false);
   const double *u = io.in(dU), *v = io.in(Un_dt), *a = io.in(Un_dt2), *m = io.in(M);
   // the caller's dU in grid numbering (the gather windows read N.dU), the force accumulator of the node window reset
   hipLaunchKernelGGL(k_expand, dim3(nblk(h->g.nnodes)), dim3(BLK), 0, h->stream, h->N.dU, u, h->n2m_d, h->g.nnodes, ND);
   HIPCHK(hipMemsetAsync(h->N.force + (size_t)h->n0 * ND, 0, (size_t)h->nwn * ND * sizeof(double), h->stream));
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
   {
     TileD td = tile_view(h);
     td.slab = nullptr;  // (level-B semantics: atomics also in deterministic mode, like kb_fint_tile)
@@ -4468,6 +4470,7 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
 #undef NLPS_K3R
   }
   HIPCHK(hipGetLastError());
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));
   if (halo(h, h->N.force, ND, 8, 0)) return 1;
   int any = 0;
   if (nloads > 0 && traction_to_grid(h, "nlps_gpu_lagrangian_evaluation", h->gridA, loads, nloads, step, thickness, area0, &any))
@@ -4483,7 +4486,15 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
     h->err = "nlps_gpu_lagrangian_evaluation: HIP error";
     return 1;
   }
-  return check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()");
+  if (h->timing) HIPCHK(hipEventRecord(h->ev[6], h->stream));
+  if (check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()")) return 1;  // (synchronises)
+  if (h->timing) {
+    for (int q = 0; q < 8; q++) h->ms[q] = 0.f;
+    HIPCHK(hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[2]));
+    HIPCHK(hipEventElapsedTime(&h->ms[2], h->ev[2], h->ev[3]));
+    HIPCHK(hipEventElapsedTime(&h->ms[4], h->ev[3], h->ev[6]));
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

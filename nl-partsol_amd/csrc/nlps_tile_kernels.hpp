@@ -1426,7 +1426,8 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     double tau[ND * ND], B[ND * ND];
     // (MODE 3: C_ep kept for the tangent that may follow, everything to the n+1 slots)
     st |= stress_update<ND, LAW, MODE == 3, (LAW == NLPS_KLAW_FRICTIONAL), MODE == 1>(P, pl, mats, prm, Fn1, DF, Jn1, tau, mat_idx);
-    const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), -1.0);
+    // (MODE 1 accumulates -f_int, what the explicit scheme divides by the mass; MODE 3 the +f_int of the Lagrangian, :1359)
+    const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), MODE == 3 ? 1.0 : -1.0);
     PH(11)
     if (fo_ok) {
       // RELOAD (the laws whose stress update sets the register budget): the LME factors are rebuilt from the particle's

@@ -54,13 +54,15 @@ STATE = (("DF", "DF"), ("F_n1", "F_n1"), ("J_n1", "J_n1"), ("Stress", "stress"),
 N_STATE = (("F_n", "F_n"), ("J_n", "J_n"), ("b_e_n", "b_e_n"), ("Kappa_n", "kappa_n"), ("EPS_n", "eps_n"))
 
 
-def _compare_state(S, P, material, what, tol=TOL):
+def _compare_state(S, P, material, what, amp=1e-3, tol=TOL):
     st = S.download_state()
     plastic_law = material["type"] in (2, 3)
     for k, ok in STATE + N_STATE:
         if not plastic_law and k in ("b_e_n1", "Kappa_n1", "EPS_n1", "C_ep", "b_e_n", "Kappa_n", "EPS_n"):
             continue
-        assert_close(st[k], P[ok], tol, f"{what}: {k}")
+        # the stored energy of a small strain is a difference of O(E) terms: W ~ E amp^2 carries E x 1e-16 of rounding on
+        # either side, i.e. 1e-16 / amp^2 of its own magnitude
+        assert_close(st[k], P[ok], max(tol, 2e-16 / amp ** 2) if k == "W" else tol, f"{what}: {k}")
     return st
 
 
@@ -92,32 +94,34 @@ def test_lagrangian_evaluation_matches_the_oracle_composition(ndim, material):
     area0 = rng.uniform(0.2, 0.3, size=npart) if ndim == 3 else None
     gl = n.BccSet(loads)
     plastic_law = material["type"] in (2, 3)
-    # the SNES solver evaluates the residual at several iterates from ONE n state: three different dU in a row
-    for it, amp in enumerate((2e-2 if plastic_law else 1e-3, 5e-3 if plastic_law else 3e-4, 2e-2 if plastic_law else 1e-3)):
+    # The SNES solver evaluates the residual at several iterates from ONE n state: different dU in a row, each against a
+    # fresh oracle composition (Von-Mises moves its back stress in place at every evaluation, like upstream,
+    # Constitutive.c:116: two evaluations at one dU differ there, on both sides alike).  Then the same call as the
+    # composition of the separate stage entries, with the rate tensors, and with device-resident vectors.
+    import torch
+    big, small = (2e-2, 1e-2) if plastic_law else (1e-3, 2e-3)
+    variants = [("fused", big, 0, False), ("fused again", small, 0, False), ("fused, third", big, 0, False),
+                ("separate stages", big, S.LAGR_SEPARATE, False), ("rate tensors", small, S.LAGR_RATES, False),
+                ("device vectors", big, 0, True)]
+    for what, amp, flags, on_device in variants:
         dU = amp * rng.normal(size=na * ndim)
         R_o = _oracle_residual(o, P, M, mats, prm, n2m, d2m, na, ndim, dU, Un_dt, Un_dt2, Mv, a, grav, loads, step, nsteps,
                                0.5, area0)
-        R_g = S.lagrangian_evaluation(dU, Un_dt, Un_dt2, Mv, alpha, grav, gl, step, 0.5, area0)
-        assert_close(R_g, R_o, TOL, f"evaluation {it}: residual")
+        if on_device:  # a PETSc Vec of a GPU type: nothing crosses PCIe; R is overwritten, not accumulated into
+            dev = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in (dU, Un_dt, Un_dt2, Mv)]
+            R_d = torch.full((na * ndim,), 7.0, dtype=torch.float64, device="cuda")
+            S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, grav, gl, step, 0.5, area0, out=R_d)
+            R_g = R_d.cpu().numpy()
+        else:
+            R_g = S.lagrangian_evaluation(dU, Un_dt, Un_dt2, Mv, alpha, grav, gl, step, 0.5, area0, flags=flags)
+        assert_close(R_g, R_o, TOL, f"{what}: residual")
         assert np.all(R_g[d2m == -1] == 0.0), "Dirichlet dofs carry no residual"
-        _compare_state(S, P, material, f"evaluation {it}")
-        if plastic_law and it == 0:
+        st = _compare_state(S, P, material, what, amp)
+        if flags == S.LAGR_RATES:
+            assert_close(st["dt_DF"], P["dt_DF"], TOL, "dt_DF")
+            assert_close(st["dt_F_n1"], P["dt_F_n1"], TOL, "dt_F_n1")
+        if plastic_law and what == "fused":
             assert np.count_nonzero(P["eps_n1"] > P["eps_n"]) > 0, "the case must yield"
-    # the same call as the composition of the separate stage entries, and with the rate tensors
-    R_s = S.lagrangian_evaluation(dU, Un_dt, Un_dt2, Mv, alpha, grav, gl, step, 0.5, area0, flags=S.LAGR_SEPARATE)
-    assert_close(R_s, R_g, 1e-12, "separate stages vs the fused call")
-    _compare_state(S, P, material, "separate stages")
-    R_r = S.lagrangian_evaluation(dU, Un_dt, Un_dt2, Mv, alpha, grav, gl, step, 0.5, area0, flags=S.LAGR_RATES)
-    assert_close(R_r, R_g, 1e-12, "with rate tensors vs the fused call")
-    st = S.download_state()
-    assert_close(st["dt_DF"], P["dt_DF"], TOL, "dt_DF")
-    assert_close(st["dt_F_n1"], P["dt_F_n1"], TOL, "dt_F_n1")
-    # device-resident vectors (a PETSc Vec of a GPU type): same numbers, nothing crosses PCIe
-    import torch
-    dev = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in (dU, Un_dt, Un_dt2, Mv)]
-    R_d = torch.full((na * ndim,), 7.0, dtype=torch.float64, device="cuda")  # (overwritten, not accumulated into)
-    S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, grav, gl, step, 0.5, area0, out=R_d)
-    assert_close(R_d.cpu().numpy(), R_g, 1e-12, "device vectors vs host vectors")
     # what follows the residual in the driver follows it here: the roll and the particle update
     dV = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2
     dA = a["a1"] * dU - a["a2"] * Un_dt - (a["a3"] + 1) * Un_dt2

@@ -1,30 +1,58 @@
 #!/bin/bash
 # Collects what profiles/ holds, on a GPU box, from the repo root:
-#   gpurun -- 'bash tools/profile.sh r02'   then   python tools/summarize_pmc.py gpurun_out/prof_r02 r02
-#                                                  python tools/summarize_sq.py  gpurun_out/prof_r02_sq r02
-# Kernel stats and every PMC group are separate rocprofv3 runs (counters never together with other trace domains).
+#   gpurun -- 'bash tools/profile.sh r04 step residual twod dp'      (any subset of the parts; default: step)
+# then here:  python tools/summarize_pmc.py gpurun_out/prof_r04 r04 [parts]   and   python tools/summarize_sq.py ... (see there)
+# Kernel stats and every PMC group are separate rocprofv3 runs (counters never together with other trace domains); the
+# profiled program stands directly after `--`.
+#   step      bench.py (3-D, 1 M particles, Neo-Hookean explicit step): stats, FETCH_SIZE / WRITE_SIZE, five SQ groups
+#   residual  bench.py --workload residual (nlps_gpu_lagrangian_evaluation, fused and separate stages, NH and D-P): stats,
+#             FETCH_SIZE / WRITE_SIZE, two SQ groups
+#   twod      bench.py --workload step2d (2-D, 1 M particles): stats, FETCH_SIZE / WRITE_SIZE, two SQ groups
+#   dp        tools/kbench.py --law dp | hencky: stats, and the SQ groups for Drucker-Prager
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
+mkdir -p build/exp
 [ -x build/exp/hbm_calib ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o build/exp/hbm_calib tools/hbm_calib.hip
-TAG=${1:-r02}
+TAG=${1:-r04}; shift
+PARTS=${@:-step}
 O=gpurun_out/prof_$TAG
-B="--no-cpu-baseline --no-stirred --no-second-scaling --no-secondary"
 mkdir -p $O
-# 1. per-kernel durations of the bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 5 $B > $O.bench.log 2>&1
-# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes, plus the calibration copy (8-B lanes, known bytes)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 3 --warmup 2 $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 3 --warmup 2 $B > /dev/null 2>&1
+SQ5=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY")
+SQ2=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM")
+# the calibration copy (8-B lanes, known bytes): what FETCH_SIZE / WRITE_SIZE read for this code's access width on THIS box
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -- ./build/exp/hbm_calib > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -- ./build/exp/hbm_calib > /dev/null 2>&1
-# 3. SQ counters, three per pass
-S=gpurun_out/prof_${TAG}_sq
-rm -rf $S; mkdir -p $S
-for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
-  n=$(echo $C | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $S/$n -- python3 bench.py --steps 2 --warmup 1 $B > $S/$n.log 2>&1
+pmc_passes() {  # name, sq-group array name, program + arguments ...
+  local name=$1 groups=$2; shift 2
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${name}_fetch -- "$@" > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${name}_write -- "$@" > /dev/null 2>&1
+  local -n G=$groups
+  for C in "${G[@]}"; do
+    n=$(echo $C | tr ' ' '_')
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/${name}_sq/$n -- "$@" > $O/${name}_sq_$n.log 2>&1
+  done
+  echo "[profile] $name: counter passes done"
+}
+for PART in $PARTS; do
+  case $PART in
+  step)
+    B="--no-cpu-baseline --no-stirred --no-second-scaling --no-secondary --no-implicit"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_stats -- python3 bench.py --steps 20 --warmup 5 $B > $O.step.log 2>&1
+    pmc_passes step SQ5 python3 bench.py --steps 3 --warmup 2 $B
+    tail -1 $O.step.log | cut -c1-200 ;;
+  residual)
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/residual_stats -- python3 bench.py --workload residual --no-cpu-baseline --steps 10 --warmup 3 > $O.residual.log 2>&1
+    pmc_passes residual SQ2 python3 bench.py --workload residual --no-cpu-baseline --steps 3 --warmup 1
+    tail -2 $O.residual.log | cut -c1-200 ;;
+  twod)
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/twod_stats -- python3 bench.py --workload step2d --steps 20 --warmup 5 > $O.twod.log 2>&1
+    pmc_passes twod SQ2 python3 bench.py --workload step2d --steps 3 --warmup 2
+    tail -1 $O.twod.log | cut -c1-200 ;;
+  dp)
+    for LAW in hencky dp; do
+      rocprofv3 --kernel-trace --stats --output-format csv -d $O/kbench_${LAW}_stats -- python3 tools/kbench.py --law $LAW > $O.kbench_$LAW.log 2>&1
+    done
+    pmc_passes kbench_dp SQ5 python3 tools/kbench.py --law dp --steps 3
+    tail -1 $O.kbench_dp.log ;;
+  esac
 done
-# 4. the other laws of the path (K3 differs): kernel stats of tools/kbench.py, the program directly after --
-for LAW in hencky dp; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$LAW -- python3 tools/kbench.py --law $LAW > $O.kbench_$LAW.log 2>&1
-done
-tail -1 $O.bench.log | cut -c1-300
+ls $O
