@@ -99,7 +99,8 @@ def cpu_baseline(cells, budget_s=30.0):
     (LAPACK), so no port / reference ratio exists."""
     os.environ.pop("OMP_NUM_THREADS", None)
     from oracle import orc
-    orc.use_fast_build(True)
+    if getattr(orc, "_LIB", None) is None:
+        orc.use_fast_build(True)
     synth = importlib.import_module("nl-partsol_amd.synth")
     margin = 5
     gc = [cells + 2 * margin] * 3
@@ -247,7 +248,8 @@ def residual_cpu_baseline(cells, law):
     inertial term (numpy), 1 thread and this GPU's share of the host cores."""
     os.environ.pop("OMP_NUM_THREADS", None)
     from oracle import orc
-    orc.use_fast_build(True)
+    if getattr(orc, "_LIB", None) is None:
+        orc.use_fast_build(True)
     synth = importlib.import_module("nl-partsol_amd.synth")
     margin = 5
     gc = [cells + 2 * margin] * 3
@@ -335,22 +337,29 @@ def bench_residual(a, stream=None, laws=("nh", "dp"), cpu=True, emit=True):
         R_d = torch.zeros(n, dtype=torch.float64, device="cuda")
         S.set_timing(True)
 
-        def run(vecs, R, flags):
-            ktimes = []
+        spikes = {}
+
+        def run(vecs, R, flags, name=""):
+            ktimes, walls = [], []
             for _ in range(a.warmup):
                 S.lagrangian_evaluation(vecs[0], vecs[1], vecs[2], vecs[3], alpha, grav, out=R, flags=flags)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(a.steps):
+                t1 = time.perf_counter()
                 S.lagrangian_evaluation(vecs[0], vecs[1], vecs[2], vecs[3], alpha, grav, out=R, flags=flags)
+                walls.append(time.perf_counter() - t1)  # (every evaluation ends synchronised: it returns a status)
                 ktimes.append(S.get_timing()[2])
             torch.cuda.synchronize()
-            return 1e3 * (time.perf_counter() - t0) / a.steps, float(np.mean(ktimes))
+            mean = 1e3 * (time.perf_counter() - t0) / a.steps
+            spikes[name] = {"median_ms": 1e3 * float(np.median(walls)), "max_ms": 1e3 * float(np.max(walls))}
+            return mean, float(np.mean(ktimes))
 
-        fused_dev, k_ms = run(dev, R_d, 0)
-        fused_host, _ = run(host, R_h, 0)
+        fused_dev, k_ms = run(dev, R_d, 0, "fused_device")
+        fused_host, _ = run(host, R_h, 0, "fused_host")
+        fused_host_same, _ = run(host, R_h, S.LAGR_SAME_STEP)  # Un_dt, Un_dt2, M staged once per SNES solve
         S.set_timing(False)
-        sep_dev, _ = run(dev, R_d, S.LAGR_SEPARATE)
+        sep_dev, _ = run(dev, R_d, S.LAGR_SEPARATE, "separate_device")
         sep_host, _ = run(host, R_h, S.LAGR_SEPARATE)
         # the two forms agree (the parity tests hold them against the oracle; this is the bench checking itself)
         S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, grav, out=R_d, flags=0)
@@ -373,9 +382,10 @@ def bench_residual(a, stream=None, laws=("nh", "dp"), cpu=True, emit=True):
                                       "device-resident vectors" % (npart, a.cells, "Neo-Hookean E=1e7 nu=0.3" if law == "nh"
                                                                    else "Drucker-Prager (%.0f %% of the particles yielding)" % (100 * yielding)),
                           "active_dofs": int(n)},
-               "fused_ms": {"device_vectors": fused_dev, "host_vectors_VecGetArray": fused_host},
+               "fused_ms": {"device_vectors": fused_dev, "host_vectors_VecGetArray": fused_host,
+                            "host_vectors_same_step": fused_host_same},
                "separate_stages_ms": {"device_vectors": sep_dev, "host_vectors_VecGetArray": sep_host},
-               "fused_over_separate": sep_dev / fused_dev, "fused_vs_separate_max_rel_diff": agree, "status_flags": flags,
+               "per_call_wall_ms": spikes, "fused_over_separate": sep_dev / fused_dev, "fused_vs_separate_max_rel_diff": agree, "status_flags": flags,
                "roofline": {"bound": "hbm", "kernel": "k3_tile<3,%d,3> (MODE 3)" % (0 if law == "nh" else 2), "achieved": achieved,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "kernel_ms": k_ms, "algorithmic_bytes_per_particle": alg,

@@ -588,10 +588,16 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
       n[1] = Tdev[1] / J2;
       n[2] = Tdev[2] / J2;
     }
+    // Hardening law kappa = kappa_0 base^(1/m), kappa' = kappa_0 / (m eps_0) base^(1/m - 1) (Drucker-Prager.c:835-860).
+    // m = 1 (linear hardening, the reference's own test values and BASELINE configs[4]): pow(x, 1) = x and pow(x, 0) = 1
+    // exactly, so the branch below returns the bits of the two libm calls without making them -- three pow per yielding
+    // particle and iterate otherwise, executed by every wave that holds one yielding lane.
+    const bool linear_hardening = exp_param == 1.0;
+    const double dk_coef = kappa_0 / (exp_param * eps_0);
     {
       double base = 1.0 + eps_n / eps_0;
       if (base < 0.0) o.fail = 1;
-      d_kappa_k = (kappa_0 / (exp_param * eps_0)) * pow(base, 1.0 / exp_param - 1.0);
+      d_kappa_k = linear_hardening ? dk_coef * 1.0 : dk_coef * pow(base, 1.0 / exp_param - 1.0);
     }
     double ads = sqrt(1.0 + 3.0 * alpha_Q * alpha_Q);
     if (alpha_F == 0.0) o.fail = 1;
@@ -609,9 +615,9 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
         if (eps_k < 0.0) { o.fail = 1; break; }
         double base = 1.0 + eps_k / eps_0;
         if (base < 0.0) { o.fail = 1; break; }
-        kappa_k = kappa_0 * pow(base, 1.0 / exp_param);
+        kappa_k = linear_hardening ? kappa_0 * base : kappa_0 * pow(base, 1.0 / exp_param);
         if (kappa_k < 0.0) { o.fail = 1; break; }
-        d_kappa_k = (kappa_0 / (exp_param * eps_0)) * pow(base, 1.0 / exp_param - 1.0);
+        d_kappa_k = linear_hardening ? dk_coef * 1.0 : dk_coef * pow(base, 1.0 / exp_param - 1.0);
         PHI = NLPS_YIELD(d_gamma_k, kappa_k);
       }
 #pragma unroll

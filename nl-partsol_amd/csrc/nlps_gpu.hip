@@ -964,6 +964,17 @@ __global__ void k_expand(double* __restrict__ grid, const double* __restrict__ m
   for (int f = 0; f < nf; f++) grid[(size_t)A * nf + f] = (m >= 0) ? masked[(size_t)m * nf + f] : 0.0;
 }
 
+// k_expand of the residual call, which also resets the force accumulator of the node window (one launch for the two)
+__global__ void k_expand_reset(double* __restrict__ grid, const double* __restrict__ masked, const int* __restrict__ n2m,
+                               int nnodes, int nf, double* __restrict__ zero, int n0, int nwn) {
+  int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nnodes) return;
+  int m = n2m[A];
+  for (int f = 0; f < nf; f++) grid[(size_t)A * nf + f] = (m >= 0) ? masked[(size_t)m * nf + f] : 0.0;
+  if (A >= n0 && A < n0 + nwn)
+    for (int f = 0; f < nf; f++) zero[(size_t)A * nf + f] = 0.0;
+}
+
 // mode 0: out = grid[A*gstride + goff + (bcast?0:f)]
 // mode 1: out += ... skipping fixed dofs (d2m == -1)
 // mode 2: out = (fixed ? 0 : grid) / div[idx]
@@ -1447,6 +1458,7 @@ struct nlps_gpu {
   int* home_d = nullptr;
   int* foreign_d = nullptr;
   int* foreign_h = nullptr;
+  int* status_h = nullptr;  // pinned landing word of check_status (one asynchronous copy + one synchronise per check)
   bool rehome = true;
   double adaptive_resort = 0.8, debt = 0.0;  // default budget: about one re-sort's cost
   int adaptive_min_steps = 4;
@@ -1468,6 +1480,11 @@ struct nlps_gpu {
   unsigned long long* phase_d = nullptr;
   double* vec_d = nullptr;  // scratch pool for host vectors of the a21 per-dof updates
   size_t vec_cap = 0;
+  // nlps_gpu_lagrangian_evaluation with host vectors: device copies of Un_dt, Un_dt2, M, which do not change between the
+  // evaluations of one SNES solve (NLPS_LAGR_SAME_STEP reuses them: two transfers per evaluation instead of five)
+  double* lagr_d = nullptr;
+  size_t lagr_cap = 0;
+  bool lagr_valid = false;
   // tangent assembly, allocated on first use
   double* kst_d = nullptr;           // [nnodes][S][d*d]
   unsigned char* ktouched_d = nullptr;  // [nnodes][S]
@@ -1981,6 +1998,8 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   if (dev_alloc(h, &h->foreign_d, 64 * 32)) return 1;
   HIPCHK(hipHostMalloc((void**)&h->foreign_h, sizeof(int), hipHostMallocDefault));
   *h->foreign_h = 0;
+  HIPCHK(hipHostMalloc((void**)&h->status_h, sizeof(int), hipHostMallocDefault));
+  *h->status_h = 0;
 #if NLPS_PHASE_TIMING
   if (dev_alloc(h, &h->phase_d, 16 * 1024)) return 1;
 #endif
@@ -2333,6 +2352,8 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
   for (auto& b : h->bcs)
     if (b.dnodes) (void)hipFree(b.dnodes);
   if (h->foreign_h) (void)hipHostFree(h->foreign_h);
+  if (h->lagr_d) (void)hipFree(h->lagr_d);
+  if (h->status_h) (void)hipHostFree(h->status_h);
   for (int i = 0; i < 8; i++) (void)hipEventDestroy(h->ev[i]);
   for (hipEvent_t e : h->evw)
     if (e) (void)hipEventDestroy(e);
@@ -3365,9 +3386,10 @@ static int materialise_roll(nlps_gpu* h) {
 }
 
 static int check_status(nlps_gpu* h, int fatal_mask, const char* where) {
-  int st = 0;
+  // the status word travels to a pinned host word in stream order: one wait instead of a synchronise and a blocking copy
+  HIPCHK(hipMemcpyAsync(h->status_h, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(&st, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost));
+  const int st = *(volatile int*)h->status_h;
   if (st & fatal_mask) {
     char buf[160];
     snprintf(buf, sizeof buf, "Error in %s: particle failure flags 0x%x (1 Newton, 2 connectivity, 4 J<=0, 8 law, 16 outside node window)",
@@ -3482,6 +3504,7 @@ extern "C" int nlps_gpu_active_masks(nlps_gpu* h, const nlps_bcc* bcc, int nbcc,
     HIPCHK(hipMemcpy(nodes2mask, h->canon_d ? h->mask_idx_d : h->n2m_d, (size_t)nn * sizeof(int), hipMemcpyDeviceToHost));
   if (dofs2mask && order) HIPCHK(hipMemcpy(dofs2mask, h->d2m_d, (size_t)order * sizeof(int), hipMemcpyDeviceToHost));
   h->masks_valid = true;
+  h->lagr_valid = false;  // (the masked numbering may have changed: cached residual vectors are void)
   return 0;
 }
 
@@ -4441,10 +4464,31 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
   if (vec_begin(h, "nlps_gpu_lagrangian_evaluation", io)) return 1;
   if (h->timing) HIPCHK(hipEventRecord(h->ev[0], h->stream));  // slots of nlps_gpu_get_timing: [0] staging, [2] the kernel, [4] nodal + copy back
   double* r = io.out(R, false);
-  const double *u = io.in(dU), *v = io.in(Un_dt), *a = io.in(Un_dt2), *m = io.in(M);
+  const double* u = io.in(dU);
+  const double* cst[3] = {Un_dt, Un_dt2, M};  // constant over the evaluations of one SNES solve
+  if (!is_device_ptr(Un_dt) || !is_device_ptr(Un_dt2) || !is_device_ptr(M)) {
+    if (h->lagr_cap < 3 * n) {
+      if (h->lagr_d) HIPCHK(hipFree(h->lagr_d));
+      h->lagr_cap = 3 * n;
+      HIPCHK(hipMalloc((void**)&h->lagr_d, h->lagr_cap * sizeof(double)));
+      h->lagr_valid = false;
+    }
+    if ((flags & NLPS_LAGR_SAME_STEP) && !h->lagr_valid) {
+      h->err = "nlps_gpu_lagrangian_evaluation: NLPS_LAGR_SAME_STEP without an earlier evaluation since nlps_gpu_active_masks";
+      return 1;
+    }
+    for (int q = 0; q < 3; q++) {
+      if (is_device_ptr(cst[q])) continue;
+      double* d = h->lagr_d + (size_t)q * n;
+      if (!(flags & NLPS_LAGR_SAME_STEP)) HIPCHK(hipMemcpyAsync(d, cst[q], n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      cst[q] = d;
+    }
+    h->lagr_valid = true;
+  }
+  const double *v = cst[0], *a = cst[1], *m = cst[2];
   // the caller's dU in grid numbering (the gather windows read N.dU), the force accumulator of the node window reset
-  hipLaunchKernelGGL(k_expand, dim3(nblk(h->g.nnodes)), dim3(BLK), 0, h->stream, h->N.dU, u, h->n2m_d, h->g.nnodes, ND);
-  HIPCHK(hipMemsetAsync(h->N.force + (size_t)h->n0 * ND, 0, (size_t)h->nwn * ND * sizeof(double), h->stream));
+  hipLaunchKernelGGL(k_expand_reset, dim3(nblk(h->g.nnodes)), dim3(BLK), 0, h->stream, h->N.dU, u, h->n2m_d, h->g.nnodes, ND,
+                     h->N.force, h->n0, h->nwn);
   if (h->timing) HIPCHK(hipEventRecord(h->ev[2], h->stream));
   {
     TileD td = tile_view(h);

@@ -533,7 +533,7 @@ class Solver:
                                                         _d(gv)))
         return R
 
-    LAGR_RATES, LAGR_SEPARATE = 1, 2
+    LAGR_RATES, LAGR_SEPARATE, LAGR_SAME_STEP = 1, 2, 4
 
     def lagrangian_evaluation(self, dU, Un_dt, Un_dt2, M, alpha, gravity=None, loads=None, step=0, thickness=1.0,
                               area0=None, flags=0, out=None):  # __lagrangian_evaluation

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from util import DP, assert_close, dirichlet_plane, gpu_setup, make_case, nlps, orc
+from window_oracle import window_step_check
 
 pytestmark = pytest.mark.gpu
 
@@ -65,8 +66,13 @@ def test_config5_drucker_prager_8m_full_size():
     for t in range(5):
         S.explicit_step(gb, t, dt, 0.5, grav)
     before = S.download_state(STATE_N)
-    S.explicit_step(gb, 5, dt, 0.5, grav)
-    assert S.status_flags() == 0
+    # step 5 with VALUES under it: two blocks of 26^3 cells rebuilt in the oracle from the downloaded pre-step state --
+    # one in the interior, one on the floor (Dirichlet plane, where the column yields first) -- particle fields, index
+    # maps and nodal sums of everything the cut cannot have reached (tests/window_oracle.py)
+    deep = window_step_check(S, case, gb, [dirichlet_plane(case, 2, 5, 8)], 5, dt, 0.5, grav,
+                             [([40, 40, 40], [26, 26, 26]), ([42, 38, 1], [26, 26, 26])], [5, 5, 5], [105, 105, 105], 8,
+                             with_lists=False, label="8 M Drucker-Prager")
+    assert min(deep) >= 1000
     nodal_properties(S, case["cloud"]["mass"].sum())
     after = S.download_state(STATE_N1)
     assert np.all(after["J_n"] > 0) and np.isfinite(after["Stress"]).all()
@@ -109,3 +115,63 @@ def test_mixed_laws_1m_full_size():
     P = check_sample(case, idx, before, after)
     for m in range(3):
         assert np.abs(P["stress"][case["cloud"]["matidx"][idx] == m]).max() > 0.1
+
+
+def test_window_oracle_1m_neo_hookean():
+    """BASELINE configs[1] (1 M particles, the bench workload) twelve steps into its fall: the thirteenth step against
+    the oracle on three windows -- interior, free top surface, floor with its Dirichlet plane.  Everything that only
+    exists at this size sits under these values: 2 197 tiles over several rounds of workgroups, the XCD-compacted work
+    lists, canonical lists from the per-node counters, the search riding on K5, the folded step."""
+    n = nlps()
+    case = make_case(3, [60, 60, 60], [5, 5, 5], [50, 50, 50], velocity=[0.0, 0.0, -10.0])
+    nsteps = 14
+    S = gpu_setup(case, nsteps=nsteps)
+    assert S.np == 1_000_000
+    bc = dirichlet_plane(case, 2, 5, nsteps)
+    gb = n.BccSet([bc])
+    dt = 1e-3
+    for t in range(12):
+        S.explicit_step(gb, t, dt, 0.5, None)
+    blocks = [([17, 17, 17], [26, 26, 26]), ([15, 19, 33], [26, 26, 26]), ([19, 15, 1], [26, 26, 26])]
+    deep = window_step_check(S, case, gb, [bc], 12, dt, 0.5, None, blocks, [5, 5, 5], [55, 55, 55], nsteps, label="1 M")
+    assert min(deep) >= 1000, deep
+    S.close()
+
+
+def test_window_oracle_8m_neo_hookean():
+    """BASELINE configs[3]'s total size on one GPU (8 M particles: the unfolded step above 2 M particles, 17 576 tiles),
+    third step, two windows: interior and the corner where three free faces meet."""
+    n = nlps()
+    case = make_case(3, [110, 110, 110], [5, 5, 5], [100, 100, 100], velocity=[0.0, 0.0, -10.0])
+    nsteps = 4
+    S = gpu_setup(case, nsteps=nsteps)
+    assert S.np == 8_000_000
+    bc = dirichlet_plane(case, 2, 5, nsteps)
+    gb = n.BccSet([bc])
+    for t in range(2):
+        S.explicit_step(gb, t, 1e-3, 0.5, None)
+    blocks = [([42, 42, 42], [26, 26, 26]), ([83, 83, 83], [26, 26, 26])]
+    deep = window_step_check(S, case, gb, [bc], 2, 1e-3, 0.5, None, blocks, [5, 5, 5], [105, 105, 105], nsteps,
+                             with_lists=False, label="8 M")
+    assert min(deep) >= 1000, deep
+    S.close()
+
+
+def test_window_oracle_on_a_grid_of_more_than_65536_tiles():
+    """The tile scan has a second form for grids of 65 536 tiles and more (commit f578b41): 1 M particles inside a grid
+    of 260^3 nodes = 274 625 tiles, fourth step, one interior window."""
+    n = nlps()
+    case = make_case(3, [259, 259, 259], [100, 100, 100], [50, 50, 50], velocity=[3.0, -2.0, -10.0])
+    x = case["cloud"]["x"]
+    c = x.mean(axis=0)  # (a uniform translation leaves F = 1 and a stress of pure rounding: shear and squeeze the block)
+    case["cloud"]["vel"] = case["cloud"]["vel"] + np.stack([4.0 * (x[:, 2] - c[2]), -3.0 * (x[:, 0] - c[0]),
+                                                            -2.0 * (x[:, 2] - c[2])], axis=1) / 25.0
+    nsteps = 5
+    S = gpu_setup(case, nsteps=nsteps)
+    gb = n.BccSet([])
+    for t in range(3):
+        S.explicit_step(gb, t, 1e-3, 0.5, None)
+    deep = window_step_check(S, case, gb, [], 3, 1e-3, 0.5, None, [([112, 112, 112], [26, 26, 26])], [100, 100, 100],
+                             [150, 150, 150], nsteps, with_lists=False, label="274 625 tiles")
+    assert min(deep) >= 1000, deep
+    S.close()

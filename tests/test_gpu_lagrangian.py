@@ -102,7 +102,7 @@ def test_lagrangian_evaluation_matches_the_oracle_composition(ndim, material):
     big, small = (2e-2, 1e-2) if plastic_law else (1e-3, 2e-3)
     variants = [("fused", big, 0, False), ("fused again", small, 0, False), ("fused, third", big, 0, False),
                 ("separate stages", big, S.LAGR_SEPARATE, False), ("rate tensors", small, S.LAGR_RATES, False),
-                ("device vectors", big, 0, True)]
+                ("same step", big, S.LAGR_SAME_STEP, False), ("device vectors", big, 0, True)]
     for what, amp, flags, on_device in variants:
         dU = amp * rng.normal(size=na * ndim)
         R_o = _oracle_residual(o, P, M, mats, prm, n2m, d2m, na, ndim, dU, Un_dt, Un_dt2, Mv, a, grav, loads, step, nsteps,
@@ -112,6 +112,9 @@ def test_lagrangian_evaluation_matches_the_oracle_composition(ndim, material):
             R_d = torch.full((na * ndim,), 7.0, dtype=torch.float64, device="cuda")
             S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, grav, gl, step, 0.5, area0, out=R_d)
             R_g = R_d.cpu().numpy()
+        elif flags == S.LAGR_SAME_STEP:  # Un_dt, Un_dt2, M as staged by the evaluation before: the host arrays are not read
+            z = np.full(na * ndim, np.nan)
+            R_g = S.lagrangian_evaluation(dU, z, z, z, alpha, grav, gl, step, 0.5, area0, flags=flags)
         else:
             R_g = S.lagrangian_evaluation(dU, Un_dt, Un_dt2, Mv, alpha, grav, gl, step, 0.5, area0, flags=flags)
         assert_close(R_g, R_o, TOL, f"{what}: residual")
