@@ -267,3 +267,31 @@ int nlps_glue_update_particles_static(const nlps_glue *G, const double *dU /* Ve
   }
   return EXIT_SUCCESS;
 }
+
+/* U-Newmark-beta.c:970-1058, the body of __lagrangian_evaluation(snes, dU, Lagrangian, ctx) between its VecGetArray and
+ * VecRestoreArray calls: the reference's
+ *     VecZeroEntries(Lagrangian); dU_dt = __compute_nodal_velocity_increments(...);
+ *     __local_compatibility_conditions(...); __constitutive_update(...); __nodal_internal_forces(...);
+ *     __nodal_traction_forces(...); __nodal_inertial_forces(...);
+ * becomes ONE library call.  The pointers are the driver's own (VecGetArray / VecGetArrayRead of Lagrangian, dU and of
+ * ctx->Lumped_Mass, U_n_dt, U_n_dt2); alpha[6] = {alpha_1 .. alpha_6} of ctx->Time_Integration_Params (:497-514);
+ * neumann[] = MPM_Mesh.Neumann_Contours flattened like the Dirichlet boundaries (nodes = particle indices);
+ * first_evaluation_of_the_step != 0 for the first residual of a time step (the three vectors that do not change during
+ * the SNES solve are then copied to the device, afterwards reused).  Returns EXIT_SUCCESS / EXIT_FAILURE like the static. */
+int nlps_glue_lagrangian_evaluation(const nlps_glue *G, Particle MPM_Mesh, double *Lagrangian_ptr, const double *dU_ptr,
+                                    const double *Un_dt_ptr, const double *Un_dt2_ptr, const double *Lumped_Mass_ptr,
+                                    const double alpha[6], const double *gravity /* b of :1519-1557, or NULL */,
+                                    const nlps_bcc *neumann, int nneumann, int TimeStep, int first_evaluation_of_the_step) {
+#if NumberDimensions == 2
+  const double thickness = Thickness_Plain_Stress;
+  const double *area0 = NULL;
+#else
+  const double thickness = 1.0;
+  const double *area0 = MPM_Mesh.Phi.Area_0.nV; /* :1440-1444 */
+#endif
+  const int flags = first_evaluation_of_the_step ? 0 : NLPS_LAGR_SAME_STEP;
+  const int STATUS = nlps_gpu_lagrangian_evaluation(G->gpu, Lagrangian_ptr, dU_ptr, Un_dt_ptr, Un_dt2_ptr, Lumped_Mass_ptr, alpha,
+                                                    gravity, neumann, nneumann, TimeStep, thickness, area0, flags);
+  if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(G->gpu));
+  return STATUS;
+}

@@ -111,6 +111,12 @@ struct ParamsD {
 #ifndef NLPS_KUNROLL_MOM
 #define NLPS_KUNROLL_MOM 1
 #endif
+#ifndef NLPS_SCATTER_POP
+#define NLPS_SCATTER_POP 1  // scatter loops of K2 / K3: membership by pop_member (one vector instruction per node)
+#endif
+#ifndef NLPS_MASK_BY_COLUMNS
+#define NLPS_MASK_BY_COLUMNS 1  // K2's radius test by (i, j) columns with add-with-carry bit assembly (nlps_tile_kernels.hpp)
+#endif
 #ifndef NLPS_JUNROLL_MASK
 #define NLPS_JUNROLL_MASK 5  // neighbourhood-mask rows unrolled: no run-time index into ly2[] (8 selects per row); K2 0.294 -> 0.282 ms
 #endif
@@ -524,6 +530,11 @@ __device__ __forceinline__ void law_von_mises(const MatD& m, const ParamsD& prm,
 // Drucker-Prager backward Euler in principal log-strain space.  Statement order follows
 // Drucker-Prager.c:319-613 (elastic :410-432, classical return :457-530, apex return :532-590,
 // corrector :593-610); eigenvectors by column everywhere.
+// libm's pow as a real call: inlined, its register demand sets the allocation of the whole kernel and makes the HOT path
+// spill around a branch that linear hardening (m = 1) never takes (Drucker-Prager K3 at three waves per SIMD: 51 scratch
+// reloads sat inside the inlined pow, their stores at the head of the particle loop).
+__device__ __attribute__((noinline)) double pow_cold(double x, double y) { return pow(x, y); }
+
 template <int N>
 __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD& prm, const double* d_phi,
                                                    const double* b_e_n, double b_e_n_zz, double kappa_n,
@@ -597,7 +608,7 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
     {
       double base = 1.0 + eps_n / eps_0;
       if (base < 0.0) o.fail = 1;
-      d_kappa_k = linear_hardening ? dk_coef * 1.0 : dk_coef * pow(base, 1.0 / exp_param - 1.0);
+      d_kappa_k = linear_hardening ? dk_coef * 1.0 : dk_coef * pow_cold(base, 1.0 / exp_param - 1.0);
     }
     double ads = sqrt(1.0 + 3.0 * alpha_Q * alpha_Q);
     if (alpha_F == 0.0) o.fail = 1;
@@ -615,9 +626,9 @@ __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD&
         if (eps_k < 0.0) { o.fail = 1; break; }
         double base = 1.0 + eps_k / eps_0;
         if (base < 0.0) { o.fail = 1; break; }
-        kappa_k = linear_hardening ? kappa_0 * base : kappa_0 * pow(base, 1.0 / exp_param);
+        kappa_k = linear_hardening ? kappa_0 * base : kappa_0 * pow_cold(base, 1.0 / exp_param);
         if (kappa_k < 0.0) { o.fail = 1; break; }
-        d_kappa_k = linear_hardening ? dk_coef * 1.0 : dk_coef * pow(base, 1.0 / exp_param - 1.0);
+        d_kappa_k = linear_hardening ? dk_coef * 1.0 : dk_coef * pow_cold(base, 1.0 / exp_param - 1.0);
         PHI = NLPS_YIELD(d_gamma_k, kappa_k);
       }
 #pragma unroll
@@ -1190,6 +1201,17 @@ __device__ __forceinline__ double masked_weight(double e, unsigned bits, int i) 
 __device__ __forceinline__ double masked_zero(double e, unsigned bits, int i) {
   const int m = __builtin_amdgcn_sbfe((int)bits, (unsigned)i, 1u);
   return __hiloint2double(__double2hiint(e) & m, __double2loint(e) & m);
+}
+
+// Membership test of the scatter loops in ONE vector instruction per stencil node: the 25 bits of a plane sit at the top
+// of `b` (bit 24 of plane_bits at bit 31), b + b shifts the next one out into the carry, whose lane mask is the branch
+// condition as it stands (v_add_co_u32 writes it to a scalar pair; inverse_ballot hands that pair to the branch without
+// a compare).  Nodes therefore come in descending order, (j, i) = (4, 4) first.  The bit test it replaces was
+// v_and_b32 + v_cmp_ne_u32: 125 vector instructions less per particle in each of the two scatter loops.
+__device__ __forceinline__ bool pop_member(unsigned& b) {
+  unsigned long long m;
+  asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(b), "=s"(m));
+  return __builtin_amdgcn_inverse_ballot_w64(m);
 }
 
 // Wave-uniform test "does any lane of the wave hold a member in this stencil row".  The particles of a wave

@@ -3998,7 +3998,14 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 1, true>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
                      h->mats_d, h->prm, h->gstatus_d, (const double*)nullptr)
     const int law = h->uniform_law;
-    if (ND == 2) {
+#define NLPS_K3U(LAWv)                                                                                          \
+  hipLaunchKernelGGL((k3_tile<3, LAWv, 1, false, K3_BLK, true>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, \
+                     h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, (const double*)nullptr)
+    if (ND == 3 && h->nmats == 1 && law >= 1 && law <= 3) {  // one material (k3_body, UMAT)
+      if (law == 1) NLPS_K3U(1);
+      else if (law == 2) NLPS_K3U(2);
+      else NLPS_K3U(3);
+    } else if (ND == 2) {
       if (law == 0) NLPS_K3(2, 0);
       else if (law == 1) NLPS_K3(2, 1);
       else if (law == 2) NLPS_K3(2, 2);
@@ -4039,6 +4046,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     }
 #undef NLPS_K3F
 #undef NLPS_K3
+#undef NLPS_K3U
   };
   K5Search ks;
   ks.rank1 = h->rank1_d;
@@ -4077,8 +4085,15 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
 #define NLPS_K3L(NDv, LAWv)                                                                                              \
   hipLaunchKernelGGL((k3_tile_lazy<NDv, LAWv>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
                      h->mats_d, h->prm, h->gstatus_d, ln)
+#define NLPS_K3LU(LAWv)                                                                                                  \
+  hipLaunchKernelGGL((k3_tile_lazy<3, LAWv, true>), dim3(h->ntw * K3_SPLIT), dim3(K3_BLK), 0, h->stream, h->P, h->g, h->N, td, \
+                     h->mats_d, h->prm, h->gstatus_d, ln)
     const int law = h->uniform_law;
-    if (ND == 2) {
+    if (ND == 3 && h->nmats == 1 && law >= 1 && law <= 3) {  // one material: its constants by scalar loads (k3_body, UMAT)
+      if (law == 1) NLPS_K3LU(1);
+      else if (law == 2) NLPS_K3LU(2);
+      else NLPS_K3LU(3);
+    } else if (ND == 2) {
       if (law == 0) NLPS_K3L(2, 0);
       else if (law == 1) NLPS_K3L(2, 1);
       else if (law == 2) NLPS_K3L(2, 2);
@@ -4092,6 +4107,7 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
       else NLPS_K3L(3, 4);
     }
 #undef NLPS_K3L
+#undef NLPS_K3LU
   };
   auto launch_k5_lazy = [&](int cls) {
     const TileD td = tile_view(h, cls);
@@ -4498,7 +4514,14 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 3>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, \
                      (const double*)nullptr)
     const int law = h->uniform_law;
-    if (ND == 2) {
+#define NLPS_K3RU(LAWv)                                                                                              \
+  hipLaunchKernelGGL((k3_tile<3, LAWv, 3, false, K3_BLK, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, \
+                     h->gstatus_d, (const double*)nullptr)
+    if (ND == 3 && h->nmats == 1 && law >= 1 && law <= 3) {  // one material (k3_body, UMAT)
+      if (law == 1) NLPS_K3RU(1);
+      else if (law == 2) NLPS_K3RU(2);
+      else NLPS_K3RU(3);
+    } else if (ND == 2) {
       if (law == 0) NLPS_K3R(2, 0);
       else if (law == 1) NLPS_K3R(2, 1);
       else if (law == 2) NLPS_K3R(2, 2);
@@ -4512,6 +4535,7 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
       else NLPS_K3R(3, 4);
     }
 #undef NLPS_K3R
+#undef NLPS_K3RU
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));

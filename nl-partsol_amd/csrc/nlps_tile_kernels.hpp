@@ -716,6 +716,43 @@ __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NV
       if (ND == 3) lz2[i] = c.lz[i % KN] * c.lz[i % KN];
     }
     u64 mlo = 0ull, mhi = 0ull;
+#if NLPS_MASK_BY_COLUMNS
+    {
+      // Radius test of the 125 stencil nodes, one (i, j) column of five planes at a time: the left-to-right sum of
+      // generalised_Euclidean_distance (MatrixOp.c:895-920), (lx^2 + ly^2) + lz^2, shares its first addition over the
+      // five planes (150 additions instead of 250), and every outcome is shifted into the 25-bit word of its plane,
+      // word = 2 word + (sq <= T2) -- one compare and one add-with-carry per node instead of compare, select and or.
+      // Columns run from (4, 4) down to (0, 0) so that bit i + 5 j ends up in its place.  Same booleans, bit for bit.
+      unsigned pbk[KN];
+#pragma unroll
+      for (int k = 0; k < KN; k++) pbk[k] = 0u;
+#pragma unroll
+      for (int j = 4; j >= 0; j--)
+#pragma unroll
+        for (int i = 4; i >= 0; i--) {
+          double s = 0.0;
+          s += lx2[i];
+          s += ly2[j];
+#pragma unroll
+          for (int k = 0; k < KN; k++) {
+            double sq = s;
+            if (ND == 3) sq += lz2[k];
+            // (v_cmp_le_f64 is false for a NaN like the C comparison; the back end does not form the add-with-carry itself)
+            asm("v_cmp_le_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pbk[k]) : "v"(sq), "v"(T2) : "vcc");
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < KN; k++) {
+        unsigned act = 0u;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const int row = (by + j - 2) + (ND == 3 ? W * (bz + k - 2) : 0);
+          act |= ((actrow[row] >> (bx - 2)) & 31u) << (5 * j);
+        }
+        put_plane(mlo, mhi, pbk[k] & act, k);
+      }
+    }
+#else
 #pragma unroll NLPS_KUNROLL_MASK
     for (int k = 0; k < KN; k++) {
       const double lz2k = (ND == 3) ? lz2[k] : 0.0;
@@ -737,6 +774,7 @@ __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NV
       }
       put_plane(mlo, mhi, pbits, k);
     }
+#endif
     c.mlo = mlo;
     c.mhi = mhi;
     const int nn = __popcll(mlo) + __popcll(mhi);
@@ -844,6 +882,23 @@ __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NV
       const unsigned pb = plane_bits<ND>(c, k);
       const double wz = mz * ez5[k];
       const int basek = base + (ND == 3 ? PSA * (k - 2) : 0);
+#if NLPS_SCATTER_POP && !NLPS_SCATTER_BRANCHFREE
+      unsigned pbs = pb << 7;  // pop_member: bit 24 (j = 4, i = 4) first
+#pragma unroll
+      for (int j = 4; j >= 0; j--) {
+        const double w = wz * ey5[j];
+#pragma unroll
+        for (int i = 4; i >= 0; i--)
+          if (pop_member(pbs)) {
+            const int li = basek + (i - 2) + WA * (j - 2);
+            const double v0 = w * c.ex[i];
+            lds_add(&acc[li], v0);
+#pragma unroll
+            for (int a = 0; a < ND; a++) lds_add(&acc[(1 + a) * NWA + li], v0 * dd[a]);
+          }
+      }
+      continue;
+#endif
 #pragma unroll NLPS_JUNROLL_SCATTER
       for (int j = 0; j < 5; j++) {
         const unsigned bits = (pb >> (5 * j)) & 31u;
@@ -951,7 +1006,12 @@ struct K3Lds {
   int* nsel;     // [1]
   int* wcnt;     // [NT / 64]
 };
-template <int ND, int LAW, int MODE, bool FILT, int NT>
+// UMAT: the cloud holds ONE material (nlps_gpu_create: nmats == 1): its constants are read through a compile-time index,
+// i.e. by scalar loads into scalar registers, instead of through the per-lane MatIdx into vector registers that then live
+// through the whole stress update (9 doubles for Drucker-Prager: 72 -> 0 B of scratch at two waves per SIMD, Von-Mises
+// 32 -> 0).  Tried first without a second set of kernels: one trip of the update per distinct material of the wave with
+// the index from readfirstlane -- the loop-carried state made every law spill (Drucker-Prager 256 B).
+template <int ND, int LAW, int MODE, bool FILT, int NT, bool UMAT = false>
 __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NView& N, const TileD& td,
                                         const MatD* __restrict__ mats, const ParamsD& prm, int* __restrict__ gstatus,
                                         const double* __restrict__ dVgrid, const TileWork& tw, int nbnd,
@@ -1064,7 +1124,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     if (!load_lme<ND>(P, g, p, c, lam, beta)) continue;
     // (requested with the particle's other operands: the constants of its material are then one load away, not two, when
     // the stress update asks for them behind the gather)
-    const int mat_idx = SCATTER ? P.mat[p] : -1;
+    const int mat_idx = UMAT ? 0 : (SCATTER ? P.mat[p] : -1);
     const int base = window_base<ND>(c.ijk, w0);
     NLPS_YZ_LOCALS(c);
     PH(9)
@@ -1427,6 +1487,8 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
     // (MODE 3: C_ep kept for the tangent that may follow, everything to the n+1 slots)
     st |= stress_update<ND, LAW, MODE == 3, (LAW == NLPS_KLAW_FRICTIONAL), MODE == 1>(P, pl, mats, prm, Fn1, DF, Jn1, tau, mat_idx);
     // (MODE 1 accumulates -f_int, what the explicit scheme divides by the mass; MODE 3 the +f_int of the Lagrangian, :1359)
+    // (measured and dropped, round 4: DF^-T J^-1 formed BEFORE the stress update so that DF and J^-1 need not live through
+    // it -- the allocator then spills more, not less: Drucker-Prager at three waves 152 -> 192 B of scratch, Hencky 8 -> 44)
     const bool fo_ok = force_operator<ND>(B, tau, DF, Jm1, PF(P, F_VOL0, pl), MODE == 3 ? 1.0 : -1.0);
     PH(11)
     if (fo_ok) {
@@ -1474,6 +1536,25 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
         double cz[ND];
 #pragma unroll
         for (int a = 0; a < ND; a++) cz[a] = (ND == 3) ? fma(hB[a * ND + (2 % ND)], ck, Ba[a]) : Ba[a];
+#if NLPS_SCATTER_POP && !NLPS_SCATTER_BRANCHFREE
+        unsigned pbs = pb << 7;  // pop_member: bit 24 (j = 4, i = 4) first
+#pragma unroll
+        for (int j = 4; j >= 0; j--) {
+          const double w = wz * ey5[j];
+          double cr[ND];
+#pragma unroll
+          for (int a = 0; a < ND; a++) cr[a] = fma(hB[a * ND + 1], (double)(j - 2), cz[a]);
+#pragma unroll
+          for (int i = 4; i >= 0; i--)
+            if (pop_member(pbs)) {
+              const int li = basek + (i - 2) + WA * (j - 2);
+              const double we = w * c.ex[i];
+#pragma unroll
+              for (int a = 0; a < ND; a++) lds_add(&fac[a * NWA + li], we * fma(hB[a * ND + 0], (double)(i - 2), cr[a]));
+            }
+        }
+        continue;
+#endif
 #pragma unroll NLPS_JUNROLL_SCATTER
         for (int j = 0; j < 5; j++) {
           const unsigned bits = (pb >> (5 * j)) & 31u;
@@ -1534,7 +1615,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
   PH(14)
   tile_signal(td, wb, nbnd);
 }
-template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK>
+template <int ND, int LAW, int MODE, bool FILT = false, int NT = K3_BLK, bool UMAT = false>
 __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value))) void k3_tile(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                ParamsD prm, int* __restrict__ gstatus,
                                                const double* __restrict__ dVgrid) {
@@ -1552,7 +1633,7 @@ __global__ __launch_bounds__(NT, (NT == 64 ? 1 : (K3Waves<ND, LAW, MODE>::value)
   TileWork tw;
   if (!tile_work_item<K3_SPLIT>(td, tw)) return;
   const L lds{dvxy, dvz, duxy, duz, fac, sel, &nsel, wcnt};
-  k3_body<ND, LAW, MODE, FILT, NT>(P, g, N, td, mats, prm, gstatus, dVgrid, tw, nbnd, lds, nullptr);
+  k3_body<ND, LAW, MODE, FILT, NT, UMAT>(P, g, N, td, mats, prm, gstatus, dVgrid, tw, nbnd, lds, nullptr);
 }
 
 // The explicit step of one GPU without a ghost exchange, "folded" form: the nodal kernels between the stages are gone.
@@ -1568,7 +1649,7 @@ struct LazyNodal {
   int* tile_count;
   int ntw;
 };
-template <int ND, int LAW>
+template <int ND, int LAW, bool UMAT = false>
 __global__ __launch_bounds__(K3_BLK, (K3Waves<ND, LAW, 1>::value)) void k3_tile_lazy(PView P, GridD g, NView N, TileD td, const MatD* __restrict__ mats,
                                                                                   ParamsD prm, int* __restrict__ gstatus, LazyNodal ln) {
   using L = K3Lds<ND, 1, false>;
@@ -1592,7 +1673,7 @@ __global__ __launch_bounds__(K3_BLK, (K3Waves<ND, LAW, 1>::value)) void k3_tile_
   TileWork tw;
   if (!tile_work_item<K3_SPLIT>(td, tw)) return;
   const L lds{dvxy, dvz, duxy, duz, fac, sel, &nsel, wcnt};
-  k3_body<ND, LAW, 1, false, K3_BLK>(P, g, N, td, mats, prm, gstatus, nullptr, tw, nbnd, lds, &ln.fs);
+  k3_body<ND, LAW, 1, false, K3_BLK, UMAT>(P, g, N, td, mats, prm, gstatus, nullptr, tw, nbnd, lds, &ln.fs);
 }
 
 // Sums, for every node of two node ranges, the window slabs of the tiles whose window holds the node (<= 2 per axis)

@@ -26,6 +26,7 @@ ap.add_argument("--det", action="store_true", help="deterministic mode")
 ap.add_argument("--stir", type=int, default=0, help="untimed shear steps first (DESIGN.md stirred cloud)")
 ap.add_argument("--resort", action="store_true", help="one periodic re-sort of the fused step before the timed steps")
 ap.add_argument("--adaptive", type=float, default=0.0, help="adaptive re-sort budget (also during the stir and the timed steps)")
+ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE for nlps_gpu_debug_option (fuse_search, lazy_nodal, ...)")
 ap.add_argument("--tag", default=os.path.basename(os.environ.get("NLPS_GPU_LIB", "product")))
 a = ap.parse_args()
 nlps = importlib.import_module("nl-partsol_amd.nlps")
@@ -65,6 +66,8 @@ if a.no_order:
     S.L.nlps_gpu_debug_set_tile_ordering(S.h, 0)
 if a.det:
     S.set_deterministic(True)
+for kv in a.opt:
+    S.debug_option(kv.split("=")[0], float(kv.split("=")[1]))
 S.initialise_shapefun()
 E = max(m["E"] for m in case["materials"])
 dt = 0.1 * case["h"] / np.sqrt(E / 1000.0)
@@ -98,10 +101,7 @@ for t in range(5, 5 + a.steps):
     k += np.array(S.get_timing())
 k /= a.steps
 k[:4] = np.maximum(k[:4] - k[5], 0)
-if k[7] > 0.5:  # k_step_fused: one launch for K2 + K3 + K5 (its time sits in the K3 slot)
-    print("%s law=%s cells=%d: search %.3f fused K2+K3+K5 %.3f sum %.3f ms | flags %x" %
-          (a.tag, a.law, a.cells, k[0], k[2], k[:5].sum(), S.status_flags()), flush=True)
-else:
+if True:
     print("%s law=%s cells=%d: search %.3f K2 %.3f K3 %.3f K5 %.3f nodal %.3f sum %.3f ms | flags %x" %
           (a.tag, a.law, a.cells, k[0], k[1], k[2], k[3], k[4], k[:5].sum(), S.status_flags()), flush=True)
 if a.phases:
