@@ -572,8 +572,9 @@ struct WinRows {  // active flags of the window as one bit row per (y[,z]) line
 // with the Dirichlet values; a = g + f / M) become part of the window loads of K3 and K5.  What those loads need
 // beside the nodal sums: the Dirichlet sets of the step and gravity.
 // (Round 3 also held k_step_fused here -- K2, K3, K5 as ONE launch of persistent workgroups with per-tile hand-off
-// flags.  Measured slower than the three launches, 0.67 against 0.56 ms, after an early revision that hung for a reason
-// never established; taken out of the library in round 4, DESIGN.md 5a.  Last revision that holds it: 7527459.)
+// flags.  Measured slower than the three launches, 0.67 against 0.56 ms; its first revision hung on a barrier that waves
+// with an empty exec mask skipped (tools/isa_barriers.py).  Taken out of the library in round 4; last
+// revision that holds it: 7527459.)
 // ------------------------------------------------------------------------------------------------
 struct NodalFold {
   const unsigned* bcmask;  // Dirichlet sets per node (k_bc_mark) or nullptr
