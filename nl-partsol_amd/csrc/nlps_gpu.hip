@@ -133,6 +133,11 @@ struct TileCnt {
   // node, nrank[p] = the rank of p inside its node (arrival order of the atomic); nullptr = off
   int* node_cnt;
   int* nrank;
+  // defer != 0 (the search that rides on k5_tile, canonical lists on): only COUNT here -- the tile and node counters by
+  // atomics whose result nobody waits for -- and leave the ranks (positions inside the tile list and inside the node) to
+  // k_fill_orders of the next step, which takes them from cursors at full occupancy.  K5 runs three waves per SIMD: a
+  // returning atomic there is a stall nothing covers (+20 us of K5's 110 at 1 M particles).
+  int defer;
 };
 template <int ND>
 struct TileCfg;
@@ -168,18 +173,49 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
     }
   }
   const int lane = threadIdx.x & 63;
-  int rank = valid ? -1 : 0;
-  while (true) {
-    const u64 todo = __ballot(rank < 0);
-    if (!todo) break;
-    const int leader = __ffsll((unsigned long long)todo) - 1;
-    const int t0 = __shfl(t, leader);
-    const bool mine = (rank < 0) && (t == t0);
-    const u64 same = __ballot(mine);
+  if (tc.defer) {  // count only (see TileCnt::defer)
+    bool todo_l = valid;
+    while (true) {
+      const u64 todo = __ballot(todo_l);
+      if (!todo) break;
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const int t0 = __shfl(t, leader);
+      const bool mine = todo_l && (t == t0);
+      const u64 same = __ballot(mine);
+      if (lane == leader) atomicAdd(&tc.count[t0], (int)__popcll(same));  // (no result wanted: no wait)
+      if (mine) todo_l = false;
+    }
+    if (p < P.np) {
+      P.tile[p] = t;
+      if (tc.node_cnt && valid) atomicAdd(&tc.node_cnt[I0], 1);
+    }
+  } else {
+  // groups of lanes that share a tile: leader lane, group size and the lane's place in its group, by ballots alone ...
+  int rank = 0;
+  {
+    int my_leader = lane, my_off = 0, my_cnt = 0;
+    bool todo_l = valid;
+    while (true) {
+      const u64 todo = __ballot(todo_l);
+      if (!todo) break;
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const int t0 = __shfl(t, leader);
+      const bool mine = todo_l && (t == t0);
+      const u64 same = __ballot(mine);
+      if (mine) {
+        my_leader = leader;
+        my_off = (int)__popcll(same & ((1ull << lane) - 1ull));
+        my_cnt = (int)__popcll(same);
+        todo_l = false;
+      }
+    }
+    // ... then ONE returning atomic per group, all groups of the wave in the same instruction: one round trip to the
+    // counters however many tiles the wave's particles are in (a loop with the atomic inside paid one per tile: K5 of a
+    // stirred cloud 0.226 ms, of which 0.07 waiting here)
     int base = 0;
-    if (lane == leader) base = atomicAdd(&tc.count[t0], (int)__popcll(same));
-    base = __shfl(base, leader);
-    if (mine) rank = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+    if (valid && lane == my_leader) base = atomicAdd(&tc.count[t], my_cnt);
+    base = __shfl(base, my_leader);
+    if (valid) rank = base + my_off;
   }
   if (p < P.np) {
     P.tile[p] = t;  // -1: not binned (failed element search or outside the node window)
@@ -187,6 +223,7 @@ __device__ __forceinline__ void bin_particle(const PView& P, const GridD& g, con
     // (the lanes of a wave mostly hold distinct closest nodes -- the memory order is the canonical one -- so these
     // atomics spread over the node array)
     if (tc.node_cnt) tc.nrank[p] = valid ? atomicAdd(&tc.node_cnt[I0], 1) : 0;
+  }
   }
   if (tc.home) {
     bool away = false;
@@ -1168,30 +1205,60 @@ __global__ __launch_bounds__(1024) void k_dilate_scan(int n0, int nnodes, GridD 
 }
 // Both tile lists in one pass over the particles: order = as binned (position = rank of the wave-aggregated tile atomic:
 // runs of memory-consecutive particles), order2 = canonical (TileTab).
+// cursor != nullptr: the binning only counted (TileCnt::defer) -- the position inside the tile list comes from a cursor
+// that starts at the list's first slot (tile_scan_block), one wave-aggregated atomic per (wave, tile), lanes in memory
+// order; the rank inside the closest node counts the node's counter DOWN (every value c - 1 .. 0 once; the counter is
+// back at zero for the next binning, the layer tables of this step were made from it before this kernel).
 template <int ND>
 __global__ __launch_bounds__(BLK) void k_fill_orders(int np, const int* __restrict__ tile, const int* __restrict__ rank,
                                                      const int* __restrict__ nrank, int* __restrict__ I0a,
                                                      const int* __restrict__ I0n,
                                                      const int* __restrict__ start, GridD g, TileTab tab,
-                                                     int* __restrict__ order, int* __restrict__ order2) {
+                                                     int* __restrict__ order, int* __restrict__ order2,
+                                                     int* __restrict__ cursor, int* __restrict__ node_cnt) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= np) return;
-  const int t = tile[p];
+  const int t = p < np ? tile[p] : -1;
+  int pos = -1;
+  if (cursor) {  // (every lane of the wave takes part)
+    const int lane = threadIdx.x & 63;
+    int my_leader = lane, my_off = 0, my_cnt = 0;
+    bool todo_l = t >= 0;
+    while (true) {  // (groups by ballots, then one atomic per group in ONE instruction: see bin_particle)
+      const u64 todo = __ballot(todo_l);
+      if (!todo) break;
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const int t0 = __shfl(t, leader);
+      const bool mine = todo_l && (t == t0);
+      const u64 same = __ballot(mine);
+      if (mine) {
+        my_leader = leader;
+        my_off = (int)__popcll(same & ((1ull << lane) - 1ull));
+        my_cnt = (int)__popcll(same);
+        todo_l = false;
+      }
+    }
+    int base = 0;
+    if (t >= 0 && lane == my_leader) base = atomicAdd(&cursor[t], my_cnt);
+    base = __shfl(base, my_leader);
+    if (t >= 0) pos = base + my_off;
+  }
   if (t < 0) return;
   if (I0n) {  // the search was done ahead by k5_tile: its closest node becomes THE closest node (a particle that is in
     const int In = I0n[p];  // no list was not visited: its I0n equals I0)
     if (In != I0a[p]) I0a[p] = In;
   }
   constexpr int TB = TileCfg<ND>::TB;
-  const int s0 = start[t], pos = s0 + rank[p];
+  const int s0 = start[t];
+  if (!cursor) pos = s0 + rank[p];
   order[pos] = p;
   constexpr int NNW = TileTabCfg<ND>::NNW;
   const int* tb = tab.base + (size_t)t * TileTab::LMAX * NNW;
   if (tb[0] < 0) {
     order2[pos] = p;
+    if (cursor) atomicSub(&node_cnt[I0a[p]], 1);  // (the counter still has to come back to zero)
     return;
   }
-  const int I0 = I0a[p], r = nrank[p];
+  const int I0 = I0a[p], r = cursor ? atomicSub(&node_cnt[I0], 1) - 1 : nrank[p];
   const int bx = (I0 % g.n[0]) % TB, by = ((I0 / g.n[0]) % g.n[1]) % TB, bz = (ND == 3) ? (I0 / (g.n[0] * g.n[1])) % TB : 0;
   const int l = bx + TB * (by + TB * bz), w = l >> 6;
   const unsigned long long m = tab.mask[((size_t)t * TileTab::LMAX + r) * NNW + w];
@@ -1450,6 +1517,9 @@ struct nlps_gpu {
   int resort_from_lists = 1;     // developer switch NLPS_RESORT_FROM_LISTS (resort)
   // canonical lists from per-node counters (TileTab): node_cnt[nnodes], nrank[npad], layer tables [ntiles][LMAX]
   int *node_cnt_d = nullptr, *nrank_d = nullptr, *tabo_d = nullptr;
+  int* tile_cursor_d = nullptr;  // [ntiles + 1] list cursors of the deferred ranks (TileCnt::defer, k_fill_orders)
+  int defer_ranks = 1;           // the search riding on K5 only counts; ranks come from k_fill_orders (debug option defer_ranks)
+  bool ranks_deferred = false;   // ... and did so in the step before: the lists of this step take their ranks from cursors
   unsigned long long* tabm_d = nullptr;
   int node_lists_on = 1;         // developer switch NLPS_NODE_LISTS (0: the per-tile counting sort k_tile_order)
   // adaptive re-sort (nlps_gpu_set_adaptive_resort): see TileCnt::home.  The count of displaced particles of a step
@@ -1989,6 +2059,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
 #endif
   if (dev_alloc(h, &h->node_cnt_d, (size_t)h->g.nnodes)) return 1;
   if (dev_alloc(h, &h->nrank_d, h->P.npad)) return 1;
+  if (dev_alloc(h, &h->tile_cursor_d, (size_t)h->ntiles + 1)) return 1;
   {
     const size_t nnw = h->g.nd == 3 ? TileTabCfg<3>::NNW : TileTabCfg<2>::NNW;
     if (dev_alloc(h, &h->tabo_d, (size_t)h->ntiles * TileTab::LMAX * nnw)) return 1;
@@ -2288,6 +2359,7 @@ extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_option(nlps
   else if (k == "resort_from_lists") h->resort_from_lists = (int)value;
   else if (k == "node_lists") h->node_lists_on = (int)value;
   else if (k == "tile_ordering") h->tile_ordering = (int)value;
+  else if (k == "defer_ranks") h->defer_ranks = (int)value;  // the riding search only counts, k_fill_orders hands out the ranks
   else {
     h->err = "nlps_gpu_debug_option: unknown option " + k;
     return 1;
@@ -2346,7 +2418,7 @@ extern "C" int nlps_gpu_destroy(nlps_gpu* h) {
                   h->N.dU, h->N.force, h->N.accel, h->N.reaction, h->N.fixed, h->h_avg_d, h->beta_t2_d, h->n2m_d, h->d2m_d, h->canon_d, h->mask_flags_d, h->mask_idx_d,
                   h->fixedm_d, h->bsum_d, h->total_d, h->gstatus_d, h->gridA, h->gridB, h->maskedA, h->mats_d,
                   h->rank1_d, h->P.tile, h->P.rank, h->order_d, h->order2_d, h->tile_count_d, h->tile_count2_d, h->tile_start_d, h->work1_d, h->work2_d, h->nwork_d, h->slab_d, h->dmg_first_d, h->dmg_last_d, h->dmg_first0_d, h->dmg_last0_d, h->dmg_sorted0_d, h->perm_d, h->skey_d, h->skey2_d, h->sval_d, h->sval2_d,
-                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d};
+                  h->gather_tmp, h->cub_tmp, h->gid_d, h->leaving_d, h->mig_slot_d, h->mig_cnt_d, h->mig_down_d, h->mig_up_d, h->kst_d, h->ktouched_d, h->kcnt_d, h->koffs_d, h->kscan_tmp, h->khead_d, h->kng_d, h->vec_d, h->bcmask_d, h->home_d, h->foreign_d, h->node_cnt_d, h->nrank_d, h->tabo_d, h->tabm_d, h->tile_cursor_d};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& b : h->bcs)
@@ -3201,6 +3273,7 @@ static TileCnt tile_cnt(nlps_gpu* h, bool on) {
   tc.foreign = nullptr;
   tc.node_cnt = (on && node_lists(h)) ? h->node_cnt_d : nullptr;
   tc.nrank = h->nrank_d;
+  tc.defer = 0;
   if (on && h->adaptive_resort > 0.0 && !h->deterministic) {
     tc.home = h->home_d;
     tc.foreign = h->foreign_d;
@@ -3305,6 +3378,8 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   // ahead: the search of this step was done by the last kernel of the previous one (k5_tile<., ., true>); only the
   // nodal accumulators are reset here
   const bool ahead = h->ahead && !init;
+  const bool deferred = ahead && h->ranks_deferred && node_lists(h);  // that search only counted: ranks from cursors (k_fill_orders)
+  h->ranks_deferred = false;
   if (ahead) std::swap(h->tile_count_d, h->tile_count2_d);  // the counters that search filled size the lists from here on
   const bool clear_in_dilate = ahead && p2g;  // nothing but the nodal accumulators to reset: k_dilate_scan does it
   if (!clear_in_dilate)
@@ -3319,7 +3394,7 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
   {
     const int TB = h->nd == 3 ? TileCfg<3>::TB : TileCfg<2>::TB;
     TileScanArgs ts{h->tile_count_d + h->tile0, h->tile_start_d + h->tile0, h->ntw, h->tile0, h->ntiles / h->nt[h->nd - 1], TB,
-                    h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d};
+                    h->band_lo, h->band_hi, h->work1_d, h->work2_d, h->nwork_d, deferred ? h->tile_cursor_d + h->tile0 : nullptr};
     TileTab tab;
     for (int a = 0; a < 3; a++) tab.nt[a] = h->nt[a];
     tab.node_cnt = h->node_cnt_d;
@@ -3343,8 +3418,8 @@ static int search_and_lists(nlps_gpu* h, bool init, bool p2g, double dt, double 
     tab.mask = h->tabm_d;
     tab.base = h->tabo_d;
     const int* adopt = ahead ? h->P.I0n : nullptr;
-    if (h->nd == 2) hipLaunchKernelGGL(k_fill_orders<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, adopt, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
-    else hipLaunchKernelGGL(k_fill_orders<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, adopt, h->tile_start_d, h->g, tab, h->order_d, h->order2_d);
+    if (h->nd == 2) hipLaunchKernelGGL(k_fill_orders<2>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, adopt, h->tile_start_d, h->g, tab, h->order_d, h->order2_d, deferred ? h->tile_cursor_d : (int*)nullptr, h->node_cnt_d);
+    else hipLaunchKernelGGL(k_fill_orders<3>, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->nrank_d, h->P.I0, adopt, h->tile_start_d, h->g, tab, h->order_d, h->order2_d, deferred ? h->tile_cursor_d : (int*)nullptr, h->node_cnt_d);
   } else {
     if (ahead) hipLaunchKernelGGL(k_commit_I0, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, (const int*)h->P.I0n, h->P.I0);
     hipLaunchKernelGGL(k_fill_order, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->P.tile, h->P.rank, h->tile_start_d,
@@ -4057,6 +4132,8 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (fuse && !ks_made) {  // (one TileCnt per step: it consumes the re-home flag of the adaptive re-sort)
       ks.tc = tile_cnt(h, true);
       ks.tc.count = h->tile_count2_d;  // (tile_count_d sizes the lists this very launch walks)
+      ks.tc.defer = (h->defer_ranks && ks.bin && node_lists(h)) ? 1 : 0;
+      h->ranks_deferred = ks.tc.defer != 0;
       ks_made = true;
     }
 #define NLPS_K5(NDv, LAWv)                                                                               \
@@ -4114,6 +4191,8 @@ extern "C" int nlps_gpu_explicit_step(nlps_gpu* h, const nlps_bcc* bcc, int nbcc
     if (!ks_made) {  // (one TileCnt per step: it consumes the re-home flag of the adaptive re-sort)
       ks.tc = tile_cnt(h, true);
       ks.tc.count = h->tile_count2_d;
+      ks.tc.defer = (h->defer_ranks && ks.bin && node_lists(h)) ? 1 : 0;
+      h->ranks_deferred = ks.tc.defer != 0;
       ks_made = true;
     }
 #define NLPS_K5L(NDv, LAWv)                                                                                             \

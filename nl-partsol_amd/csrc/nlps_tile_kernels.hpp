@@ -287,6 +287,7 @@ struct TileScanArgs {
   int n, tile0, tpl, TB, band_lo, band_hi;
   int2 *work1, *work2;
   int* ranges;
+  int* cursor;  // [n] or nullptr: a copy of start[] for k_fill_orders to hand out list positions from (deferred ranks)
 };
 __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   const int* __restrict__ count = a.count;
@@ -338,6 +339,7 @@ __device__ __forceinline__ void tile_scan_block(const TileScanArgs& a) {
   for (int q = lo; q < hi; q++) {
     const int cq = count[q];
     start[q] = run;
+    if (a.cursor) a.cursor[q] = run;
     run += cq;
     if (cq > 0) {
       const int tz = (tile0 + q) / tpl;
