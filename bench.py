@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cells", type=int, default=50, help="cells per axis of one rank's block (50 -> 1 M particles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=16, help="cells per axis of the CPU-baseline sample")
+    ap.add_argument("--cpu-cells", type=int, default=20, help="cells per axis of the CPU-baseline sample (20 -> 64 000 particles, ~20 s of CPU work)")
     ap.add_argument("--halo", choices=["p2p", "allreduce"], default="p2p")
     ap.add_argument("--halo-impl", choices=["c", "torch"], default="c",
                     help="N > 1: c = the library's own RCCL exchange (nlps_gpu_rccl_attach: ncclSend/ncclRecv on a "
