@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from util import DP, assert_close, dirichlet_plane, gpu_setup, make_case, nlps, orc
-from window_oracle import window_step_check
+from window_oracle import window_residual_check, window_step_check
 
 pytestmark = pytest.mark.gpu
 
@@ -135,6 +135,10 @@ def test_window_oracle_1m_neo_hookean():
     blocks = [([17, 17, 17], [26, 26, 26]), ([15, 19, 33], [26, 26, 26]), ([19, 15, 1], [26, 26, 26])]
     deep = window_step_check(S, case, gb, [bc], 12, dt, 0.5, None, blocks, [5, 5, 5], [55, 55, 55], nsteps, label="1 M")
     assert min(deep) >= 1000, deep
+    # ... and the implicit driver's residual call (MODE 3 of the same kernel) on the state these 13 steps left: the search,
+    # the internal forces at the nodes and the particle state it leaves, on the interior and the floor window
+    nodes = window_residual_check(S, case, gb, [bc], 13, nsteps, [blocks[0], blocks[2]], [5, 5, 5], [55, 55, 55], label="1 M")
+    assert min(nodes) >= 500, nodes
     S.close()
 
 
