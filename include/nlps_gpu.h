@@ -322,7 +322,8 @@ int nlps_gpu_nodal_inertial_forces(nlps_gpu *h, double *R, const double *M, cons
  *                          law, which is not on this path, reads them: off by default) -- runs the separate stages;
  *        NLPS_LAGR_SEPARATE the composition of the separate stage calls (same results; what the fused form is tested and
  *                          timed against).  The separate stages also run when the damage hooks are on
- *                          (driver_eigenerosion / _eigensoftening: every stress before any force) or the cloud mixes laws.
+ *                          (driver_eigenerosion / _eigensoftening: every stress before any force).  A cloud of several laws
+ *                          runs one fused launch per law present.
  *        NLPS_LAGR_SAME_STEP host vectors only: Un_dt, Un_dt2 and M are the ones of the previous evaluation (they do not
  *                          change inside one SNES solve, U-Newmark-beta.c:241-300): their device copies are reused, an
  *                          evaluation then moves dU in and R out and nothing else (2 of 5 transfers).  An error without an

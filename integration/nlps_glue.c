@@ -295,3 +295,14 @@ int nlps_glue_lagrangian_evaluation(const nlps_glue *G, Particle MPM_Mesh, doubl
   if (STATUS != EXIT_SUCCESS) fprintf(stderr, "" RED "%s" RESET "\n", nlps_gpu_last_error(G->gpu));
   return STATUS;
 }
+
+/* U-Static.c:492-551, the same callback of the quasi-static driver: no rate vectors, the inertial term is - M b
+ * (:1005-1033).  The dynamic call with alpha = 0 gives exactly that (0 * dU - 0 * v - 0 * a - b); dU stands in for the
+ * two rate vectors, which are multiplied by zero. */
+int nlps_glue_lagrangian_evaluation_static(const nlps_glue *G, Particle MPM_Mesh, double *Lagrangian_ptr, const double *dU_ptr,
+                                           const double *Lumped_Mass_ptr, const double *b /* gravity or NULL */,
+                                           const nlps_bcc *neumann, int nneumann, int TimeStep) {
+  static const double alpha0[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  return nlps_glue_lagrangian_evaluation(G, MPM_Mesh, Lagrangian_ptr, dU_ptr, dU_ptr, dU_ptr, Lumped_Mass_ptr, alpha0, b, neumann,
+                                         nneumann, TimeStep, 1);
+}

@@ -4527,9 +4527,9 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
   // The composition of the separate stage calls, in the order of :1023-1041 -- on request (NLPS_LAGR_SEPARATE: the form
   // the fused one is measured and tested against), for what the fused kernel does not carry (rate tensors, which only the
   // Newtonian-fluid law reads; the damage hooks, which sit between the stress update and the force scatter and need
-  // every particle's stress before any force; clouds with several laws)
-  const bool fused = !(flags & (NLPS_LAGR_SEPARATE | NLPS_LAGR_RATES)) && !h->P.erosion && h->uniform_law >= 0 &&
-                     h->uniform_law <= NLPS_KLAW_FRICTIONAL && h->P.np > 0;
+  // every particle's stress before any force)
+  const bool fused = !(flags & (NLPS_LAGR_SEPARATE | NLPS_LAGR_RATES)) && !h->P.erosion && h->uniform_law <= NLPS_KLAW_FRICTIONAL &&
+                     h->P.np > 0;
   if (!fused) {
     double* dV = nullptr;
     if (flags & NLPS_LAGR_RATES) {  // __compute_nodal_velocity_increments, :1020
@@ -4593,6 +4593,29 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
   hipLaunchKernelGGL((k3_tile<NDv, LAWv, 3>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, h->gstatus_d, \
                      (const double*)nullptr)
     const int law = h->uniform_law;
+    // a cloud of several laws: one launch per law present of the kernel compiled for that law, every workgroup compacting
+    // its tile's particles of that law first (FILT, as the explicit step's per-law launches)
+#define NLPS_K3RF(NDv, LAWv)                                                                                          \
+  hipLaunchKernelGGL((k3_tile<NDv, LAWv, 3, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, \
+                     h->gstatus_d, (const double*)nullptr)
+    if (law < 0) {
+      for (int l = 0; l <= NLPS_KLAW_FRICTIONAL; l++) {
+        if (!(h->law_present & (1 << l))) continue;
+        if (ND == 2) {
+          if (l == 0) NLPS_K3RF(2, 0);
+          else if (l == 1) NLPS_K3RF(2, 1);
+          else if (l == 2) NLPS_K3RF(2, 2);
+          else if (l == 3) NLPS_K3RF(2, 3);
+          else NLPS_K3RF(2, 4);
+        } else {
+          if (l == 0) NLPS_K3RF(3, 0);
+          else if (l == 1) NLPS_K3RF(3, 1);
+          else if (l == 2) NLPS_K3RF(3, 2);
+          else if (l == 3) NLPS_K3RF(3, 3);
+          else NLPS_K3RF(3, 4);
+        }
+      }
+    } else
 #define NLPS_K3RU(LAWv)                                                                                              \
   hipLaunchKernelGGL((k3_tile<3, LAWv, 3, false, K3_BLK, true>), grid, blk, 0, h->stream, h->P, h->g, h->N, td, h->mats_d, h->prm, \
                      h->gstatus_d, (const double*)nullptr)
@@ -4615,6 +4638,7 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
     }
 #undef NLPS_K3R
 #undef NLPS_K3RU
+#undef NLPS_K3RF
   }
   HIPCHK(hipGetLastError());
   if (h->timing) HIPCHK(hipEventRecord(h->ev[3], h->stream));

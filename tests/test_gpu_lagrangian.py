@@ -270,3 +270,78 @@ def test_lagrangian_evaluation_after_explicit_steps_and_with_the_damage_hooks():
         S.close()
     assert_close(outs[0][0], outs[1][0], 1e-12, "damage hooks: the entry vs the stages one by one")
     assert np.array_equal(outs[0][1]["Damage_n1"], outs[1][1]["Damage_n1"])
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_quasi_static_residual(ndim):
+    """U-Static.c's __lagrangian_evaluation (:492-551): compatibility, constitutive update, internal forces, traction
+    forces and - M b on the free dofs (:1005-1033) -- the dynamic call with alpha = 0, dU standing in for the rate vectors."""
+    o, n = orc(), nlps()
+    rng = np.random.default_rng(17)
+    nsteps, step = 2, 0
+    case, M, P, prm, mats = _moved_case(ndim, HENCKY, nsteps, rng)
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
+    S = gpu_setup(case, init=False, nsteps=nsteps)
+    assert o.local_search(P, M, prm) == 0
+    S.local_search()
+    n2m, na = o.active_nodes(M)
+    d2m, _ = o.active_dofs(n2m, na, ndim, o.BccSet(bcs_list), step, nsteps)
+    S.active_masks(n.BccSet(bcs_list), step)
+    Mv = o.lumped_mass(P, M, n2m, na)
+    dU = 1e-3 * rng.normal(size=na * ndim)
+    b = [0.0] * (ndim - 1) + [-9.81]
+    assert o.compatibility(dU, None, P, M, n2m) == 0 and o.constitutive(P, mats, prm) == 0
+    R_o, st = o.internal_forces(P, M, n2m, d2m, na)
+    assert st == 0
+    free = d2m != -1
+    R_o[free] += (-Mv * np.tile(np.asarray(b), na))[free]
+    R_g = S.lagrangian_evaluation(dU, dU, dU, Mv, [0.0] * 6, b)
+    assert_close(R_g, R_o, TOL, "quasi-static residual")
+    assert np.all(R_g[~free] == 0.0)
+    _compare_state(S, P, HENCKY, "quasi-static residual")
+
+
+@pytest.mark.parametrize("ndim,layout", [(2, "interleaved"), (3, "interleaved"), (3, "layers")])
+def test_lagrangian_evaluation_of_a_cloud_of_three_laws(ndim, layout):
+    """Constitutive.c:28-258 dispatches per particle: a cloud that mixes Neo-Hookean, Hencky and Drucker-Prager particles
+    runs one fused launch per law (each workgroup compacts its tile's particles of that law); residual and particle state
+    against the oracle's composition, two evaluations in a row."""
+    o, n = orc(), nlps()
+    rng = np.random.default_rng(23)
+    nsteps, step = 2, 0
+    case, M, P0, prm, _ = _moved_case(ndim, DP, nsteps, rng)
+    soft_nh, soft_hencky = {"type": 0, "E": 2.0e4, "nu": 0.3}, {"type": 1, "E": 1.0e4, "nu": 0.25}
+    case["materials"] = [soft_nh, soft_hencky, DP]
+    npart = case["cloud"]["x"].shape[0]
+    if layout == "interleaved":
+        case["cloud"]["matidx"] = (np.arange(npart) % 3).astype(np.int32)
+    else:
+        z = case["cloud"]["x"][:, ndim - 1]
+        case["cloud"]["matidx"] = np.minimum(2, ((z - z.min()) / (z.max() - z.min() + 1e-9) * 3).astype(np.int32))
+    P = o.OracleParticles(case["cloud"])
+    mats = o.make_materials(case["materials"])
+    bcs_list = [dirichlet_plane(case, ndim - 1, 3, nsteps)]
+    S = gpu_setup(case, init=False, nsteps=nsteps)
+    assert o.local_search(P, M, prm) == 0
+    S.local_search()
+    n2m, na = o.active_nodes(M)
+    d2m, _ = o.active_dofs(n2m, na, ndim, o.BccSet(bcs_list), step, nsteps)
+    S.active_masks(n.BccSet(bcs_list), step)
+    Mv = o.lumped_mass(P, M, n2m, na)
+    V, A = o.nodal_field_n(Mv, P, M, n2m, d2m, na)
+    a = newmark_parameters(0.25, 0.5, 2.0e-3)
+    alpha = [a["a1"], a["a2"], a["a3"], a["a4"], a["a5"], a["a6"]]
+    grav = [0.0] * (ndim - 1) + [-9.81]
+    for it, amp in enumerate((2e-2, 1e-2)):
+        dU = amp * rng.normal(size=na * ndim)
+        R_o = _oracle_residual(o, P, M, mats, prm, n2m, d2m, na, ndim, dU, V, A, Mv, a, grav, None, step, nsteps, 1.0, None)
+        R_g = S.lagrangian_evaluation(dU, V, A, Mv, alpha, grav)
+        assert_close(R_g, R_o, TOL, f"three laws, evaluation {it}: residual")
+        st = S.download_state()
+        for k, ok in STATE + N_STATE:
+            if k == "W":
+                continue
+            assert_close(st[k], P[ok], TOL, f"three laws, evaluation {it}: {k}", scale=1e-6 if k in ("EPS_n1", "EPS_n") else None)
+    dp = case["cloud"]["matidx"] == 2
+    assert np.count_nonzero(P["eps_n1"][dp] > P["eps_n"][dp]) > 0, "the plastic third must yield"
+    assert np.all(P["eps_n1"][~dp] == 0.0)
