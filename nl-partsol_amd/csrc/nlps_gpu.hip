@@ -1218,7 +1218,16 @@ __global__ __launch_bounds__(BLK) void k_fill_orders(int np, const int* __restri
                                                      int* __restrict__ cursor, int* __restrict__ node_cnt) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = p < np ? tile[p] : -1;
-  int pos = -1;
+  int pos = -1, I0 = 0, r = 0;
+  if (t >= 0) {  // the search was done ahead by k5_tile: its closest node becomes THE closest node (a particle that is in
+    I0 = I0a[p];  // no list was not visited: its I0n equals I0)
+    if (I0n) {
+      const int In = I0n[p];
+      if (In != I0) I0a[p] = I0 = In;
+    }
+    // (asked for first: its round trip runs under the one of the list cursor below)
+    if (cursor) r = atomicSub(&node_cnt[I0], 1) - 1;
+  }
   if (cursor) {  // (every lane of the wave takes part)
     const int lane = threadIdx.x & 63;
     int my_leader = lane, my_off = 0, my_cnt = 0;
@@ -1243,10 +1252,6 @@ __global__ __launch_bounds__(BLK) void k_fill_orders(int np, const int* __restri
     if (t >= 0) pos = base + my_off;
   }
   if (t < 0) return;
-  if (I0n) {  // the search was done ahead by k5_tile: its closest node becomes THE closest node (a particle that is in
-    const int In = I0n[p];  // no list was not visited: its I0n equals I0)
-    if (In != I0a[p]) I0a[p] = In;
-  }
   constexpr int TB = TileCfg<ND>::TB;
   const int s0 = start[t];
   if (!cursor) pos = s0 + rank[p];
@@ -1255,10 +1260,9 @@ __global__ __launch_bounds__(BLK) void k_fill_orders(int np, const int* __restri
   const int* tb = tab.base + (size_t)t * TileTab::LMAX * NNW;
   if (tb[0] < 0) {
     order2[pos] = p;
-    if (cursor) atomicSub(&node_cnt[I0a[p]], 1);  // (the counter still has to come back to zero)
     return;
   }
-  const int I0 = I0a[p], r = cursor ? atomicSub(&node_cnt[I0], 1) - 1 : nrank[p];
+  if (!cursor) r = nrank[p];
   const int bx = (I0 % g.n[0]) % TB, by = ((I0 / g.n[0]) % g.n[1]) % TB, bz = (ND == 3) ? (I0 / (g.n[0] * g.n[1])) % TB : 0;
   const int l = bx + TB * (by + TB * bz), w = l >> 6;
   const unsigned long long m = tab.mask[((size_t)t * TileTab::LMAX + r) * NNW + w];
