@@ -1168,8 +1168,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
           double m[5], R0[ND], R1[ND];
 #pragma unroll
           for (int a = 0; a < ND; a++) R0[a] = R1[a] = 0.0;
-#pragma unroll
-          for (int i = 0; i < 5; i++) m[i] = masked_weight(c.ex[i], bits, i);
+          masked_row(m, c.ex, bits);
           const double mu[5] = {-2.0 * m[0], -m[1], 0.0, m[3], 2.0 * m[4]};
 #pragma unroll
           for (int i = 0; i < 5; i++) {
@@ -1211,9 +1210,9 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
 #pragma unroll
         for (int j = 0; j < 5; j++) {
           const unsigned bits = (pb >> (5 * j)) & 31u;
-          const double m0 = masked_weight(c.ex[0], bits, 0), m1 = masked_weight(c.ex[1], bits, 1),
-                       m2 = masked_weight(c.ex[2], bits, 2), m3 = masked_weight(c.ex[3], bits, 3),
-                       m4 = masked_weight(c.ex[4], bits, 4);
+          double mw[5];
+          masked_row(mw, c.ex, bits);
+          const double m0 = mw[0], m1 = mw[1], m2 = mw[2], m3 = mw[3], m4 = mw[4];
           const double s13 = m1 + m3, s04 = m0 + m4;
           const double A0 = m2 + s13 + s04, A1 = fma(2.0, m4 - m0, m3 - m1), A2 = fma(4.0, s04, s13);
           const double cj = (double)(j - 2);
@@ -1260,8 +1259,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
         double m[5], R0[ND], R1[ND], V0r[ND], V1r[ND];
 #pragma unroll
         for (int a = 0; a < ND; a++) R0[a] = R1[a] = V0r[a] = V1r[a] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) m[i] = masked_weight(c.ex[i], bits, i);  // non-members weigh 0
+        masked_row(m, c.ex, bits);  // non-members weigh 0
         const double w0 = -2.0 * m[0], w4 = 2.0 * m[4];
         const double mu[5] = {w0, -m[1], 0.0, m[3], w4};  // u_i m_i
 #pragma unroll
@@ -1808,13 +1806,14 @@ __device__ __forceinline__ void k5_body(const PView& P, const GridD& g, const NV
         for (int j = 0; j < 5; j++) {
           const unsigned bits = (pb >> (5 * j)) & 31u;
           if (!wave_row_used(bits)) continue;
-          double A0 = 0.0, R[ND];
+          double A0 = 0.0, R[ND], mw[5];
 #pragma unroll
           for (int a = 0; a < ND; a++) R[a] = 0.0;
+          masked_row(mw, c.ex, bits);
 #pragma unroll
           for (int i = 0; i < 5; i++) {  // branch-free: non-members weigh 0 (their window slot exists)
             const int li = basek + (i - 2) + W * (j - 2);
-            const double m0 = masked_weight(c.ex[i], bits, i);
+            const double m0 = mw[i];
             A0 += m0;
             const double2 v01 = a2[li];
             R[0] = fma(m0, v01.x, R[0]);
