@@ -79,6 +79,29 @@ def main():
     mine = {k: st[k] for k in ("x", "vel", "acc", "Stress", "F_n", "I0", "lambda")}
     mine["nn"] = nn
     mine["active"] = S.download_active()
+
+    # The implicit driver's residual on the partitioned cloud (nlps_gpu_lagrangian_evaluation, SURVEY 8e: "each residual
+    # evaluation needs the S4 reduction"): every rank evaluates it for ITS particles, the force scatter ends in the
+    # exchange of the shared layers, so a rank holds the complete residual of every node it has active -- compared node
+    # by node (through the two Nodes2Mask) with the whole cloud's below.  dU is a function of the node alone.
+    def residual_of(solver):
+        solver.local_search()
+        n2m, d2m = solver.active_masks(gb, NSTEPS - 1)
+        na = solver.nactive
+        ids = np.flatnonzero(n2m >= 0)
+        ijk = np.stack([(ids // int(np.prod(gn[:a]))) % gn[a] for a in range(ND)], axis=1).astype(np.float64)
+        dU = np.zeros((na, ND))
+        dU[n2m[ids]] = 1e-3 * np.sin(0.7 * ijk + np.arange(ND)[None, :])
+        Mv = solver.compute_nodal_lumped_mass()
+        V, A = solver.get_nodal_field_n(Mv)
+        a1, a2, a3 = 4.0e4, 4.0e2, 1.0
+        R = solver.lagrangian_evaluation(dU.ravel(), V, A, Mv, [a1, a2, a3, 0.0, 0.0, 0.0], [0.0] * (ND - 1) + [-9.81])
+        full = np.full((nnodes, ND), np.nan)
+        full[ids] = R.reshape(-1, ND)[n2m[ids]]
+        return full, solver.download_state(["F_n1", "Stress", "J_n1"])
+
+    mine["residual"], rst = residual_of(S)
+    mine["res_state"] = {k: rst[k] for k in ("F_n1", "Stress", "J_n1")}
     parts = [None] * world
     dist.gather_object(mine, parts if rank == 0 else None, dst=0)
     ok = True
@@ -107,6 +130,19 @@ def main():
             got = np.concatenate([p[k] for p in parts])
             util.assert_close(got, ref[k], 1e-11 if k != "lambda" else 1e-9, "%s partitioned vs whole" % k)
         assert np.abs(ref["Stress"]).max() > 1.0, "the case must deform"
+        Rw, wst = residual_of(G)
+        scale = np.nanmax(np.abs(Rw))
+        seen = np.zeros(nnodes, dtype=bool)
+        for r_, p_ in enumerate(parts):
+            have = ~np.isnan(p_["residual"][:, 0])
+            assert not np.isnan(Rw[have]).any(), "rank %d has a node active that the whole cloud has not" % r_
+            err = np.abs(p_["residual"][have] - Rw[have]).max() / scale
+            assert err <= 1e-10, "residual of rank %d vs whole cloud: %.3e" % (r_, err)
+            seen |= have
+        assert np.array_equal(seen, ~np.isnan(Rw[:, 0])), "every active node of the whole cloud is active on some rank"
+        for k in ("F_n1", "Stress", "J_n1"):
+            got = np.concatenate([p_["res_state"][k] for p_ in parts])
+            util.assert_close(got, wst[k], 1e-10, "%s after the residual call, partitioned vs whole" % k)
         print("MULTIRANK_GPU_OK ndim=%d world=%d particles=%d overlap=%s" % (ND, world, ref["x"].shape[0], overlap))
     dist.barrier()
     dist.destroy_process_group()
