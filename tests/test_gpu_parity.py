@@ -1233,6 +1233,13 @@ def test_config3_4m_neo_hookean_column_properties():
     assert np.all(d["J_n"] > 0) and np.isfinite(d["Stress"]).all()
     assert d["vel"][:, 2].mean() < 0
     assert S.status_flags() == 0
+    # values under the third step (tests/window_oracle.py): a block on the floor, where the column is compressed, and one
+    # at mid height, each rebuilt in the oracle from the downloaded state
+    from window_oracle import window_step_check
+    deep = window_step_check(S, case, gb, [dirichlet_plane(case, 2, 5, 3)], 2, dt, 0.5, [0.0, 0.0, -9.81],
+                             [([17, 17, 1], [26, 26, 26]), ([17, 17, 90], [26, 26, 26])], [5, 5, 5], [55, 55, 205], 3,
+                             with_lists=False, label="4 M column")
+    assert min(deep) >= 1000, deep
 
 
 def test_config5_drucker_prager_1m_properties():
