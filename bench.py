@@ -243,7 +243,7 @@ RESIDUAL_BYTES_3D = {"nh": BYTES_3D["S3"] + BYTES_3D["S4"], "dp": BYTES_3D["S3"]
 
 
 def residual_cpu_baseline(cells, law):
-    """The oracle's composition of the stages of __lagrangian_evaluation (:1020-1038) on a bounded sample of the same
+    """The oracle's composition of the stages of __lagrangian_evaluation (:1018-1036) on a bounded sample of the same
     cloud: compatibility + constitutive + internal forces (OpenMP, the reference's omp-critical accumulation) + the
     inertial term (numpy), 1 thread and this GPU's share of the host cores."""
     os.environ.pop("OMP_NUM_THREADS", None)

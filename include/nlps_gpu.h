@@ -305,9 +305,9 @@ int nlps_gpu_nodal_inertial_forces(nlps_gpu *h, double *R, const double *M, cons
 
 /* __lagrangian_evaluation, U-Newmark-beta.c:970-1058 -- the callback SNES runs at every Newton iterate and every
  * line-search trial of the maintained driver -- as ONE call: VecZeroEntries(R), then
- *   __compute_nodal_velocity_increments (:1020), __local_compatibility_conditions (:1023-1024),
- *   __constitutive_update (:1028), __nodal_internal_forces (:1030-1031), __nodal_traction_forces (:1033-1034),
- *   __nodal_inertial_forces (:1036-1038).
+ *   __compute_nodal_velocity_increments (:1018), __local_compatibility_conditions (:1021-1022),
+ *   __constitutive_update (:1026), __nodal_internal_forces (:1028-1029), __nodal_traction_forces (:1031-1032),
+ *   __nodal_inertial_forces (:1034-1036).
  * On the device: the caller's dU is gathered, DF / F_n1 / J_n1 (J <= 0 clamped to 0 like :1137-1142), the stress update
  * and the scatter of the internal force run as ONE pass over the particles with DF and tau handed over in registers
  * (what nlps_gpu_compatibility + _constitutive + _internal_forces do in three passes with DF, F_n1, tau through HBM in

@@ -4490,9 +4490,9 @@ extern "C" int nlps_gpu_nodal_inertial_forces(nlps_gpu* h, double* R, const doub
 // every Newton iterate and line-search trial, as one device call
 // ------------------------------------------------------------------------------------------------
 // Closing nodal kernel: L = f_int (+ traction) + M (alpha_1 dU - alpha_2 v - alpha_3 a - b) on the free dofs, 0 on the
-// Dirichlet ones (VecZeroEntries :1001, then the three += of :1033-1041 in that order: __nodal_internal_forces skips the
-// Dirichlet dofs at :1359, __nodal_inertial_forces at :1543, k_traction's sums are taken for the free dofs only like
-// :1480).  force / trac: grid numbering [nnodes][ND]; everything else masked.
+// Dirichlet ones (VecZeroEntries :1003, then the three += of :1028-1036 in that order: __nodal_internal_forces skips the
+// Dirichlet dofs at :1359, __nodal_inertial_forces at :1550, k_traction's sums are taken for the free dofs only like
+// :1489).  force / trac: grid numbering [nnodes][ND]; everything else masked.
 template <int ND>
 __global__ void k_lagrangian_nodal(int nnodes, const int* __restrict__ n2m, const int* __restrict__ d2m,
                                    const double* __restrict__ force, const double* __restrict__ trac, double* __restrict__ R,
@@ -4528,7 +4528,7 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
   }
   const int ND = h->nd;
   const size_t n = (size_t)h->nactive * ND;
-  // The composition of the separate stage calls, in the order of :1023-1041 -- on request (NLPS_LAGR_SEPARATE: the form
+  // The composition of the separate stage calls, in the order of :1018-1036 -- on request (NLPS_LAGR_SEPARATE: the form
   // the fused one is measured and tested against), for what the fused kernel does not carry (rate tensors, which only the
   // Newtonian-fluid law reads; the damage hooks, which sit between the stress update and the force scatter and need
   // every particle's stress before any force)
@@ -4536,7 +4536,7 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
                      h->P.np > 0;
   if (!fused) {
     double* dV = nullptr;
-    if (flags & NLPS_LAGR_RATES) {  // __compute_nodal_velocity_increments, :1020
+    if (flags & NLPS_LAGR_RATES) {  // __compute_nodal_velocity_increments, :1018
       HIPCHK(hipMalloc((void**)&dV, std::max<size_t>(n, 1) * sizeof(double)));
       if (nlps_gpu_nodal_kinetic_increments(h, dV, nullptr, dU, Un_dt, Un_dt2, alpha)) {
         (void)hipFree(dV);

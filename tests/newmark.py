@@ -44,9 +44,9 @@ def newmark_step(stage, ndim, bcs_list, step, nsteps, dt, gravity, beta=0.25, ga
         if hasattr(stage, "lagrangian"):                                        # __lagrangian_evaluation as one call
             R = stage.lagrangian(dU, Un_dt, Un_dt2, M, alpha, gravity)
         else:
-            stage.compatibility(dU, dU_dt)                                          # :1026
-            stage.constitutive()                                                    # :1031
-            R = stage.internal_forces()                                             # :1033 (Dirichlet dofs skipped)
+            stage.compatibility(dU, dU_dt)                                          # :1021
+            stage.constitutive()                                                    # :1026
+            R = stage.internal_forces()                                             # :1028 (Dirichlet dofs skipped)
             if hasattr(stage, "inertial_forces"):
                 R = stage.inertial_forces(R, M, dU, Un_dt, Un_dt2, alpha, gravity)
             else:

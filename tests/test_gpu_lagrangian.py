@@ -1,6 +1,6 @@
 """nlps_gpu_lagrangian_evaluation: the residual callback of the maintained implicit driver (__lagrangian_evaluation,
 U-Newmark-beta.c:970-1058) as ONE device call, against the oracle's composition of the stage functions it is made of
-(:1020-1038: velocity increments, compatibility, constitutive update, internal, traction and inertial forces)."""
+(:1018-1036: velocity increments, compatibility, constitutive update, internal, traction and inertial forces)."""
 import numpy as np
 import pytest
 
@@ -35,7 +35,7 @@ def _moved_case(ndim, material, nsteps, rng):
 
 def _oracle_residual(o, P, M, mats, prm, n2m, d2m, na, ndim, dU, Un_dt, Un_dt2, Mv, a, gravity, loads, step, nsteps,
                      thickness, area0, rates=True):
-    """__lagrangian_evaluation composed from the oracle's stage functions, in the order of :1020-1038"""
+    """__lagrangian_evaluation composed from the oracle's stage functions, in the order of :1018-1036"""
     dU_dt = a["a4"] * dU + (a["a5"] - 1) * Un_dt + a["a6"] * Un_dt2      # __compute_nodal_velocity_increments :1836-1856
     assert o.compatibility(dU, dU_dt if rates else None, P, M, n2m) == 0
     assert o.constitutive(P, mats, prm) == 0
