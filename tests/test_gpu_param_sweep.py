@@ -109,6 +109,19 @@ def test_sweep_stage_functions(ndim, material, cfg):
     R_g = S.nodal_internal_forces(np.zeros(na * ndim))
     assert_close(R_g, R_o, TOL, "internal forces")
     assert np.all(R_g[d2m == -1] == 0.0)
+    # the driver's ONE residual call at the same iterate (nlps_gpu_lagrangian_evaluation = __lagrangian_evaluation,
+    # U-Newmark-beta.c:970-1058): the three stages above + the inertial term, same state left behind
+    a1, a2, a3 = 4.0e4, 4.0e2, 1.0
+    grav = [0.0] * (ndim - 1) + [-9.81]
+    R_l = R_o.copy()
+    free = d2m != -1
+    R_l[free] += (Mv_o * (a1 * dU - a2 * V_o - a3 * A_o - np.tile(np.asarray(grav), na)))[free]
+    R_f = S.lagrangian_evaluation(dU, V_g, A_g, Mv_g, [a1, a2, a3, 0.0, 0.0, 0.0], grav)
+    assert_close(R_f, R_l, TOL, "residual by the one call")
+    st = S.download_state()
+    for k, ok in keys:
+        assert_close(st[k], P[ok], TOL, f"{k} after the one residual call",
+                     scale=(material["E"] * 1e-4 if k == "W" else None))
 
     o.roll_state(P)
     S.update_particles_internal_variables()
