@@ -922,7 +922,7 @@ def main():
                        "halo_overlap_mode": rec["halo_overlap_mode"], "rccl_nranks": rec["rccl_nranks"],
                        "overlap_forms_tried": rec["overlap_forms_tried"],
                        "resorts_in_timed_region": 1, "library_default_resort_interval": 50},
-            "roofline": {"bound": domk.get("bound", "hbm"), "kernel": names[dom], "achieved": achieved,
+            "roofline": {"bound": "hbm", "limiter": domk.get("bound", "hbm"), "kernel": names[dom], "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": domk.get("traffic_bytes"), "traffic_frac": domk.get("traffic_frac"),
                          "algorithmic_bytes_per_particle": alg[dom], "kernel_ms": float(kms[dom]),
@@ -931,7 +931,8 @@ def main():
                          "lds_busy_frac": domk.get("lds_busy_frac"),
                          "note": "achieved/peak/frac are the HBM roofline of the dominant kernel (algorithmic bytes / "
                                  "live kernel time); traffic_frac is the same with the HBM bytes the counters saw "
-                                 "(profiles/hbm_traffic.json); bound names the LARGEST of the three fractions: hbm, "
+                                 "(profiles/hbm_traffic.json); bound = hbm says which roofline achieved / peak are on; "
+                                 "limiter names the LARGEST of the three fractions: hbm, "
                                  "fp64_issue (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x time)) and lds "
                                  "(SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x time)); the SQ counts come from "
                                  "profiles/sq_counters.json (rocprofv3 PMC passes of this command)"},
