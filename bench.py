@@ -94,8 +94,8 @@ def build_case(rank, world, cells, margin=5, cells_z=None):
 def cpu_baseline(cells, budget_s=30.0):
     """Times the oracle's explicit step (a from-scratch CPU port with OpenMP and the reference's omp-critical nodal
     accumulation, U-Newmark-beta.c:582-586), built with the reference's release flags (-Ofast -fopenmp,
-    CMakeLists.txt:42,86), on a bounded 3-D sample of the same workload: one warm-up step, then the median of five
-    steps, at 1 thread and at all host cores.  kind = "port": the reference's own path cannot be built in this image
+    CMakeLists.txt:42,86), on a bounded 3-D sample of the same workload: one warm-up step, then the median of fifteen
+    steps at 1 thread (about 10 s) and of five at this GPU's share of the host cores.  kind = "port": the reference's own path cannot be built in this image
     (LAPACK), so no port / reference ratio exists."""
     os.environ.pop("OMP_NUM_THREADS", None)
     from oracle import orc
@@ -108,7 +108,7 @@ def cpu_baseline(cells, budget_s=30.0):
     M = orc.OracleMesh(3, gn, [0.0] * 3, 1.0)
     prm = orc.default_params()
     mats = orc.make_materials([{"type": 0, "E": 1.0e7, "nu": 0.3}])
-    nsteps = 8
+    nsteps = 20
     nodes = synth.plane_nodes(gn, 2, 0)
     bcs = orc.BccSet([{"nodes": nodes, "dim": 3, "dir": np.ones((3, nsteps), dtype=np.int32),
                        "value": np.zeros((3, nsteps))}])
@@ -132,7 +132,7 @@ def cpu_baseline(cells, budget_s=30.0):
         assert st.step(0, 1e-3) == 0  # warm-up (first touch, caches)
         t_warm = time.perf_counter() - t0
         ts = []
-        for t in range(1, 6):
+        for t in range(1, 16 if nthr == 1 else 6):
             if ts and time.perf_counter() - t_begin + max(ts) > budget_s * (0.5 if nthr == 1 else 1.0):
                 break  # bounded sample: the omp-critical accumulation can make a many-thread step very slow
             t0 = time.perf_counter()
