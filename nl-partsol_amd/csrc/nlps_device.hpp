@@ -114,6 +114,9 @@ struct ParamsD {
 #ifndef NLPS_SCATTER_POP
 #define NLPS_SCATTER_POP 1  // scatter loops of K2 / K3: membership by pop_member (one vector instruction per node)
 #endif
+#ifndef NLPS_JACOBI_RSQ
+#define NLPS_JACOBI_RSQ 1  // sym_eigen: the Jacobi rotation from two reciprocal square roots (no division, no sqrt)
+#endif
 #ifndef NLPS_MASK_BY_COLUMNS
 #define NLPS_MASK_BY_COLUMNS 1  // K2's radius test by (i, j) columns with add-with-carry bit assembly (nlps_tile_kernels.hpp)
 #endif
@@ -295,9 +298,17 @@ __device__ __forceinline__ void sym_eigen(double* w, double* v, const double* Ai
       const double apq = o[r];
       if (apq != 0.0) {
         const double df = d[q] - d[p];
+#if NLPS_JACOBI_RSQ
+        // the small-angle rotation from two reciprocal square roots (no division, no sqrt): with h = sqrt(df^2 + 4 apq^2),
+        // cos 2 theta = |df| / h, so c^2 = (1 + |df| / h) / 2 in [1/2, 1], s = sgn(df) apq / (h c), t = s / c
+        const double rh = rsqrt(fma(df, df, 4.0 * apq * apq));
+        const double c2 = fma(0.5 * fabs(df), rh, 0.5), ic = rsqrt(c2);
+        const double c = c2 * ic, sn = (df >= 0.0 ? apq : -apq) * rh * ic, t = sn * ic;
+#else
         // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = df / (2 apq)
         const double t = (df >= 0.0 ? 2.0 : -2.0) * apq / (fabs(df) + sqrt(fma(df, df, 4.0 * apq * apq)));
         const double c = rsqrt(fma(t, t, 1.0)), sn = t * c;
+#endif
         d[p] -= t * apq;
         d[q] += t * apq;
         o[r] = 0.0;
