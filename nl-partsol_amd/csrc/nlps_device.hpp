@@ -117,6 +117,14 @@ struct ParamsD {
 #ifndef NLPS_JACOBI_RSQ
 #define NLPS_JACOBI_RSQ 1  // sym_eigen: the Jacobi rotation from two reciprocal square roots (no division, no sqrt)
 #endif
+#ifndef NLPS_LAW_CONTRACT
+#define NLPS_LAW_CONTRACT 1  // a * b + c contracted to fma inside the constitutive laws and their 3 x 3 helpers (the library is built -ffp-contract=off for the index maps)
+#endif
+#if NLPS_LAW_CONTRACT
+#define NLPS_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define NLPS_FP_CONTRACT
+#endif
 #ifndef NLPS_MASK_BY_COLUMNS
 #define NLPS_MASK_BY_COLUMNS 1  // K2's radius test by (i, j) columns with add-with-carry bit assembly (nlps_tile_kernels.hpp)
 #endif
@@ -149,6 +157,7 @@ __device__ __forceinline__ double dsqr(double a) { return a == 0.0 ? 0.0 : a * a
 // ------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ double det(const double* A) {  // I3__TensorLib__, TensorLib.c:154-168
+  NLPS_FP_CONTRACT
   if (N == 2) return A[0] * A[3] - A[1] * A[2];
   return A[0] * A[4] * A[8] - A[0] * A[5] * A[7] + A[1] * A[5] * A[6] - A[1] * A[3] * A[8] +
          A[2] * A[3] * A[7] - A[2] * A[4] * A[6];
@@ -157,6 +166,7 @@ __device__ __forceinline__ double det(const double* A) {  // I3__TensorLib__, Te
 // inverse__MatrixLib__ (MatrixOp.c:320, LAPACK dgetrf/dgetri in the reference): adjugate / det
 template <int N>
 __device__ __forceinline__ bool inverse(double* Am1, const double* A) {
+  NLPS_FP_CONTRACT
   if (N == 2) {
     double d = A[0] * A[3] - A[1] * A[2];
     if (d == 0.0) return false;
@@ -269,6 +279,7 @@ __device__ __forceinline__ bool rcond_below_gate(const double* A) {
 // TensorLib.c:208 / Drucker-Prager.c:635).  Eigenvector A = COLUMN A of v, eigenvalues ascending like dsyev.
 template <int N>
 __device__ __forceinline__ void sym_eigen(double* w, double* v, const double* Ain) {
+  NLPS_FP_CONTRACT
   // cyclic Jacobi on the upper triangle (Rutishauser's update formulas): per rotation one sqrt, one
   // division and one reciprocal square root; the rotated pair is annihilated exactly.
   double d[N], o[N == 3 ? 3 : 1];  // diagonal; off-diagonals o[0] = a01, o[1] = a02, o[2] = a12
@@ -352,6 +363,7 @@ __device__ __forceinline__ void sym_eigen(double* w, double* v, const double* Ai
 
 template <int N>
 __device__ __forceinline__ void left_cauchy_green(double* b, const double* F) {  // compute-Strains.c:365-384
+  NLPS_FP_CONTRACT
 #pragma unroll
   for (int i = 0; i < N; i++)
 #pragma unroll
@@ -366,6 +378,7 @@ __device__ __forceinline__ void left_cauchy_green(double* b, const double* F) { 
 // sum_A T_A n_A (x) n_A with n_A = column A (Hencky.c:248-265; Drucker-Prager.c:755-776, 663-710)
 template <int N>
 __device__ __forceinline__ void ppal_to_xyz(double* T, const double* Tp, const double* v) {
+  NLPS_FP_CONTRACT
 #pragma unroll
   for (int i = 0; i < N; i++)
 #pragma unroll
@@ -396,6 +409,7 @@ struct StressIO {
 
 template <int N>
 __device__ __forceinline__ void law_neo_hookean(const MatD& m, const double* F, double J, StressIO<N>& o) {
+  NLPS_FP_CONTRACT
   double c0 = m.lame * 0.5 * (J * J - 1.0);
   double b[N * N];
   left_cauchy_green<N>(b, F);
@@ -417,6 +431,7 @@ __device__ __forceinline__ void law_neo_hookean(const MatD& m, const double* F, 
 
 template <int N>
 __device__ __forceinline__ void law_hencky(const MatD& m, const double* F, StressIO<N>& o) {
+  NLPS_FP_CONTRACT
   double b[N * N], v[N * N], w[3] = {0.0, 0.0, 1.0};  // 2-D: third eigenvalue fixed at 1 (Hencky.c:48)
   left_cauchy_green<N>(b, F);
   sym_eigen<N>(w, v, b);
@@ -438,6 +453,7 @@ __device__ __forceinline__ void law_hencky(const MatD& m, const double* F, Stres
 template <int N>
 __device__ __forceinline__ void law_von_mises(const MatD& m, const ParamsD& prm, const double* d_phi, const double* b_e_n,
                                               double b_e_n_zz, double eps_n, StressIO<N>& o) {
+  NLPS_FP_CONTRACT
   double btr[N * N], v[N * N], w[3] = {0, 0, 0};
 #pragma unroll
   for (int i = 0; i < N; i++)
@@ -550,6 +566,7 @@ template <int N>
 __device__ __forceinline__ void law_drucker_prager(const MatD& m, const ParamsD& prm, const double* d_phi,
                                                    const double* b_e_n, double b_e_n_zz, double kappa_n,
                                                    double eps_n, StressIO<N>& o) {
+  NLPS_FP_CONTRACT
   double btr[N * N], v[N * N], w[3] = {0, 0, 0};
 #pragma unroll
   for (int i = 0; i < N; i++)
@@ -1150,6 +1167,7 @@ struct Lme {
     e[0] = e0q4 * (Gi * Gi);
   }
   __device__ __forceinline__ void factors(const double* lam, double beta, double h) {
+  NLPS_FP_CONTRACT
     const double Q = exp_bounded(-beta * h * h), Q2 = Q * Q, Q4 = Q2 * Q2;
     axis_factors(ex, lx[2], lam[0], beta, h, Q, Q4);
     axis_factors(ey, ly[2], lam[1], beta, h, Q, Q4);
@@ -1275,6 +1293,7 @@ __device__ __forceinline__ bool wave_row_used(unsigned bits) {
 //   sum e l_x = a_x M0 - h M1x ,  sum e l_x l_y = a_x a_y M0 - h (a_x M1y + a_y M1x) + h^2 M2xy .
 template <int ND>
 __device__ __forceinline__ void lme_moments_h(const Lme<ND>& c, double& Zinv, double* r, double* Jm) {
+  NLPS_FP_CONTRACT
   NLPS_YZ_LOCALS(c);
   (void)ly5;
   (void)lz5;

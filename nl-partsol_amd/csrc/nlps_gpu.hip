@@ -542,6 +542,7 @@ __device__ __forceinline__ int stress_update(const PView& P, int p, const MatD* 
 template <int ND>
 __device__ __forceinline__ bool force_operator(double* B, const double* tau, const double* DF, const double* Jm1,
                                                double V0, double sign) {
+  NLPS_FP_CONTRACT
   double DFt[ND * ND], DFmT[ND * ND], M1[ND * ND];
 #pragma unroll
   for (int i = 0; i < ND; i++)

@@ -793,6 +793,7 @@ __device__ __forceinline__ void k2_body(const PView& P, const GridD& g, const NV
     int st = 0, NumIter = 0;
     double Zinv = 0.0;
     while (NumIter <= prm.max_iter_lme) {  // __lambda_Newton_Rapson, LME.c:272-353
+      NLPS_FP_CONTRACT
       double r[ND], J[ND * ND], Jm1[ND * ND];
       c.factors(lam, beta, g.h);
       lme_moments_h<ND>(c, Zinv, r, J);
@@ -1019,6 +1020,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
                                         const MatD* __restrict__ mats, const ParamsD& prm, int* __restrict__ gstatus,
                                         const double* __restrict__ dVgrid, const TileWork& tw, int nbnd,
                                         const K3Lds<ND, MODE, FILT>& lds, const NodalFold* fs) {
+  NLPS_FP_CONTRACT
   constexpr int W = TileCfg<ND>::W, PS = TileCfg<ND>::PS, NW = TileCfg<ND>::NW, KN = Lme<ND>::KN;
   constexpr bool RATES = (MODE == 2);
   constexpr bool SCATTER = (MODE == 1 || MODE == 3);  // the stress update and the force scatter follow the F update
