@@ -500,6 +500,22 @@ __device__ __forceinline__ void lds_add(double* a, double v) {
 #ifndef NLPS_FAST_WINDOWS
 #define NLPS_FAST_WINDOWS 1
 #endif
+// One z value of a gather window as its OWN ds_read_b64.  The back end pairs the reads of two neighbouring slots into
+// ds_read2_b64, which the LDS serves in 8 cycles over 32 banks (two ds_read_b64: 4 cycles over 64 banks) and which puts
+// the rows by and by + 2 of the tile on the same banks (rows of 8 doubles = 16 of its 32 slots): K5 spent 38 % of its
+// LDS cycles on those conflicts.  A volatile access is not paired; with planes of 68 the 32 lanes of a ds_read_b64
+// group (bx + 8 by + 68 bz, bz in {0, 1}) fall on 32 different 8-byte slots.
+#ifndef NLPS_Z_SINGLE_READS
+#define NLPS_Z_SINGLE_READS 1
+#endif
+__device__ __forceinline__ double lds_z(const double* z, int i) {
+#if NLPS_Z_SINGLE_READS
+  return *(const volatile __attribute__((address_space(3))) double*)(z + i);  // (z is a __shared__ array: keep the access a ds_read)
+#else
+  return z[i];
+#endif
+}
+
 // global node of window cell r (3-D); inside = false outside the grid
 __device__ __forceinline__ int window_cell3(const GridD& g, const int* w0, int r, bool& inside) {
   const int gi = w0[0] + (r & 7), gj = w0[1] + ((r >> 3) & 7), gk = w0[2] + (r >> 6);
@@ -1180,7 +1196,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
             const double u2 = c.lx[3];
 #else
             const double2 u01 = du2[li];
-            const double u2 = duz[(ND == 3) ? li : 0];
+            const double u2 = lds_z(duz, (ND == 3) ? li : 0);
 #endif
             const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
@@ -1268,7 +1284,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
         for (int i = 0; i < 5; i++) {  // branch-free (the window slot of a non-member exists)
           const int li = basek + (i - 2) + W * (j - 2);
           const double2 u01 = du2[li];
-          const double u2 = (ND == 3) ? duz[(ND == 3) ? li : 0] : 0.0;
+          const double u2 = (ND == 3) ? lds_z(duz, (ND == 3) ? li : 0) : 0.0;
           const double uu[3] = {u01.x, u01.y, u2};
 #pragma unroll
           for (int a = 0; a < ND; a++) {
@@ -1277,7 +1293,7 @@ __device__ __forceinline__ void k3_body(const PView& P, const GridD& g, const NV
           }
           if (RATES) {
             const double2 v01 = dv2[RATES ? li : 0];
-            const double v2 = (ND == 3) ? dvz[(RATES && ND == 3) ? li : 0] : 0.0;
+            const double v2 = (ND == 3) ? lds_z(dvz, (RATES && ND == 3) ? li : 0) : 0.0;
             const double vv[3] = {v01.x, v01.y, v2};
 #pragma unroll
             for (int a = 0; a < ND; a++) {
@@ -1820,7 +1836,7 @@ __device__ __forceinline__ void k5_body(const PView& P, const GridD& g, const NV
             const double2 v01 = a2[li];
             R[0] = fma(m0, v01.x, R[0]);
             R[1] = fma(m0, v01.y, R[1]);
-            if (ND == 3) R[2 % ND] = fma(m0, az[(ND == 3) ? li : 0], R[2 % ND]);
+            if (ND == 3) R[2 % ND] = fma(m0, lds_z(az, (ND == 3) ? li : 0), R[2 % ND]);
           }
           const double w = ey5[j] * z0;
           Z = fma(w, A0, Z);
