@@ -1534,6 +1534,7 @@ struct nlps_gpu {
   int* foreign_d = nullptr;
   int* foreign_h = nullptr;
   int* status_h = nullptr;  // pinned landing word of check_status (one asynchronous copy + one synchronise per check)
+  int* status_hd = nullptr; // the same word as the device sees it (hipHostGetDevicePointer): a kernel at the end of a call can leave the status there itself
   bool rehome = true;
   double adaptive_resort = 0.8, debt = 0.0;  // default budget: about one re-sort's cost
   int adaptive_min_steps = 4;
@@ -2076,6 +2077,7 @@ extern "C" int nlps_gpu_create(nlps_gpu** out, const nlps_grid* grid, const nlps
   *h->foreign_h = 0;
   HIPCHK(hipHostMalloc((void**)&h->status_h, sizeof(int), hipHostMallocDefault));
   *h->status_h = 0;
+  if (hipHostGetDevicePointer((void**)&h->status_hd, h->status_h, 0) != hipSuccess) h->status_hd = nullptr;  // (then check_status copies)
 #if NLPS_PHASE_TIMING
   if (dev_alloc(h, &h->phase_d, 16 * 1024)) return 1;
 #endif
@@ -2531,7 +2533,7 @@ extern "C" int nlps_gpu_download_lists(nlps_gpu* h, int* nn_out, int* list) {
   return 0;
 }
 
-static int check_status(nlps_gpu* h, int fatal_mask, const char* where);
+static int check_status(nlps_gpu* h, int fatal_mask, const char* where, bool mirrored = false);
 // Level A: the shape functions themselves.  One thread per requested particle (device slot): p_a = e_a / Z for the 5^d
 // stencil slots (0 for non-members) and dp_a = -p_a J^-1 l_a (LME.c:836-891: r and J from the same p), written per SLOT;
 // the host puts them into the particle's list order (the walk of nlps_gpu_download_lists).
@@ -3465,9 +3467,10 @@ static int materialise_roll(nlps_gpu* h) {
   return 0;
 }
 
-static int check_status(nlps_gpu* h, int fatal_mask, const char* where) {
+// mirrored: the last kernel of the call has already stored the status word into the pinned host word (status_hd)
+static int check_status(nlps_gpu* h, int fatal_mask, const char* where, bool mirrored) {
   // the status word travels to a pinned host word in stream order: one wait instead of a synchronise and a blocking copy
-  HIPCHK(hipMemcpyAsync(h->status_h, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (!mirrored) HIPCHK(hipMemcpyAsync(h->status_h, h->gstatus_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   const int st = *(volatile int*)h->status_h;
   if (st & fatal_mask) {
@@ -4499,8 +4502,11 @@ __global__ void k_lagrangian_nodal(int nnodes, const int* __restrict__ n2m, cons
                                    const double* __restrict__ force, const double* __restrict__ trac, double* __restrict__ R,
                                    const double* __restrict__ M, const double* __restrict__ dU, const double* __restrict__ v,
                                    const double* __restrict__ a, double a1, double a2, double a3, double b0, double b1,
-                                   double b2) {
+                                   double b2, const int* __restrict__ gstatus, int* __restrict__ status_out) {
   const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  // the failure flags of the stress update, left where the host reads them after its one synchronise (check_status,
+  // mirrored): every kernel that can set them has finished before this one starts
+  if (A == 0 && status_out) *status_out = *gstatus;
   if (A >= nnodes) return;
   const int m = n2m[A];
   if (m < 0) return;
@@ -4656,14 +4662,14 @@ extern "C" int nlps_gpu_lagrangian_evaluation(nlps_gpu* h, double* R, const doub
     for (int k = 0; k < ND; k++) b[k] = gravity[k];
   LAUNCH_ND((k_lagrangian_nodal<2>), (k_lagrangian_nodal<3>), nblk(h->g.nnodes), h->g.nnodes, (const int*)h->n2m_d,
             (const int*)h->d2m_d, (const double*)h->N.force, any ? (const double*)h->gridA : (const double*)nullptr, r, m, u, v,
-            a, alpha[0], alpha[1], alpha[2], b[0], b[1], b[2]);
+            a, alpha[0], alpha[1], alpha[2], b[0], b[1], b[2], (const int*)h->gstatus_d, h->status_hd);
   HIPCHK(hipGetLastError());
   if (io.finish()) {
     h->err = "nlps_gpu_lagrangian_evaluation: HIP error";
     return 1;
   }
   if (h->timing) HIPCHK(hipEventRecord(h->ev[6], h->stream));
-  if (check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()")) return 1;  // (synchronises)
+  if (check_status(h, ST_CONSTITUTIVE, "Stress_integration__Constitutive__()", h->status_hd != nullptr)) return 1;  // (synchronises)
   if (h->timing) {
     for (int q = 0; q < 8; q++) h->ms[q] = 0.f;
     HIPCHK(hipEventElapsedTime(&h->ms[0], h->ev[0], h->ev[2]));

@@ -345,3 +345,40 @@ def test_lagrangian_evaluation_of_a_cloud_of_three_laws(ndim, layout):
     dp = case["cloud"]["matidx"] == 2
     assert np.count_nonzero(P["eps_n1"][dp] > P["eps_n"][dp]) > 0, "the plastic third must yield"
     assert np.all(P["eps_n1"][~dp] == 0.0)
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_a_failed_stress_update_in_the_fused_residual_is_reported(on_device):
+    """Stress_integration__Constitutive__ failing inside the one call (here: a NaN displacement increment makes the
+    eigenvalues of b NaN, Hencky.c) comes back as an error with status flag 8 -- the last kernel of the call leaves the
+    status word where the host reads it after its one synchronise."""
+    import torch
+    n = nlps()
+    rng = np.random.default_rng(5)
+    nsteps, step, ndim = 2, 1, 3
+    case, M, P, prm, mats = _moved_case(ndim, HENCKY, nsteps, rng)
+    S = gpu_setup(case, init=False, nsteps=nsteps)
+    S.local_search()
+    n2m, d2m = S.active_masks(n.BccSet([dirichlet_plane(case, ndim - 1, 3, nsteps)]), step)
+    na = int(n2m.max()) + 1
+    a = newmark_parameters(0.25, 0.5, 2.0e-3)
+    alpha = [a["a1"], a["a2"], a["a3"], a["a4"], a["a5"], a["a6"]]
+    z = np.zeros(na * ndim)
+    Mv = np.ones(na * ndim)
+    dU = 1e-3 * rng.normal(size=na * ndim)
+    bad = dU.copy()
+    bad[(na // 2) * ndim] = np.nan
+
+    def evaluate(v):
+        if not on_device:
+            return S.lagrangian_evaluation(v, z, z, Mv, alpha, [0.0, 0.0, 0.0], None, step, 1.0, None)
+        dev = [torch.from_numpy(np.ascontiguousarray(q)).cuda() for q in (v, z, z, Mv)]
+        out = torch.zeros(na * ndim, dtype=torch.float64, device="cuda")
+        S.lagrangian_evaluation(dev[0], dev[1], dev[2], dev[3], alpha, [0.0, 0.0, 0.0], None, step, 1.0, None, out=out)
+        return out.cpu().numpy()
+
+    R = evaluate(dU)  # a finite increment first: no flag
+    assert np.all(np.isfinite(R)) and S.status_flags() == 0
+    with pytest.raises(n.NlpsError):
+        evaluate(bad)
+    assert S.status_flags() & 8  # (the flags stay: the reference exits at this point, Constitutive.c:18-258)
