@@ -4711,10 +4711,10 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
     hipLaunchKernelGGL(k_tangent_groups, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->skey2_d, h->khead_d, h->kng_d);
     const int ngrid = std::min(np, h->g.nnodes);  // upper bound of the number of groups; surplus workgroups exit
     if (ND == 2)
-      hipLaunchKernelGGL(k_tangent_nh_grouped<2>, dim3(ngrid), dim3(256), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
+      hipLaunchKernelGGL(k_tangent_nh_grouped<2>, dim3(ngrid), dim3(TAN_NT), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
                          h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d);
     else
-      hipLaunchKernelGGL(k_tangent_nh_grouped<3>, dim3(ngrid), dim3(256), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
+      hipLaunchKernelGGL(k_tangent_nh_grouped<3>, dim3(ngrid), dim3(TAN_NT), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
                          h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d);
   } else if (np > 0) {
     if (ND == 2) hipLaunchKernelGGL(k_tangent_nh<2>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);

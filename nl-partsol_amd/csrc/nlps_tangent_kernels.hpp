@@ -140,6 +140,14 @@ __global__ __launch_bounds__(64) void k_tangent_nh(PView P, GridD g, const MatD*
 // per-particle form atomic-bound).  The group's member tables live in LDS, indexed by the stencil code
 // s = i + 5 j + 25 k (zeros for non-members); TAN_GROUP particles per pass.
 static constexpr int TAN_GROUP = 8;
+// Threads of the grouped kernel: 8 waves, one per particle of a chunk in phase A.  Phase B stages the d x d blocks of
+// a wave's 64 node pairs in LDS and hands them to memory ELEMENT by element: lanes then follow consecutive doubles of
+// the stencil array -- pairs (sA, sB) with consecutive sB along x are consecutive blocks of row node A, 5 blocks = 45
+// doubles = 360 contiguous bytes in 3-D -- instead of every lane adding into its own block, 72 bytes from its
+// neighbour's.  The float atomics of this chip run at their full rate for wave instructions that cover 256 contiguous
+// bytes or two 128-byte segments and an order of magnitude below it for 64 scattered words (MI355X guide, global float
+// atomics): the blocks are this kernel's whole traffic, 140 GB of added bytes per million particles in 3-D.
+static constexpr int TAN_NT = 512, TAN_NW = TAN_NT / 64;
 
 // group heads of the I0-sorted particle list: head[g] = first position of group g, ngroups = count
 __global__ void k_tangent_groups(int np, const unsigned long long* __restrict__ keys, int* __restrict__ head,
@@ -157,7 +165,7 @@ __global__ void k_tangent_keys(PView P, unsigned long long* __restrict__ keys, i
 }
 
 template <int ND>
-__global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, const MatD* __restrict__ mats, int np,
+__global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g, const MatD* __restrict__ mats, int np,
                                                             const unsigned long long* __restrict__ keys,
                                                             const int* __restrict__ sorted, const int* __restrict__ head,
                                                             const int* __restrict__ ngroups, double* __restrict__ Kst,
@@ -172,7 +180,9 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
       sp_tau[TAN_GROUP][ND * ND], sp_V0[TAN_GROUP];
   __shared__ int law_of[TAN_GROUP];
   __shared__ u64 mem[TAN_GROUP][2];
-  __shared__ double tab[4][6][5];  // per wave: ex, ey, ez, lx, ly, lz of the particle it is building
+  __shared__ double tab[TAN_NW][6][5];  // per wave: ex, ey, ez, lx, ly, lz of the particle it is building
+  __shared__ double stage_v[TAN_NW][64 * ND * ND];  // phase B: the blocks of the wave's 64 pairs, pair-major
+  __shared__ long long stage_b[TAN_NW][64];         // their block index in the stencil array, -1 = nothing to add
   if ((int)blockIdx.x >= *ngroups) return;
   const int first = head[blockIdx.x];
   const unsigned long long key = keys[first];
@@ -184,8 +194,8 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
   for (int chunk = first; chunk <= last; chunk += TAN_GROUP) {
     const int nb = min(TAN_GROUP, last + 1 - chunk);
     __syncthreads();
-    // phase A: wave w builds the tables of particles w, w+4 of the chunk
-    for (int jj = wave; jj < nb; jj += 4) {
+    // phase A: wave w builds the tables of particle w of the chunk
+    for (int jj = wave; jj < nb; jj += TAN_NW) {
       const int p = sorted[chunk + jj];
       Lme<ND> c;
       double lam[ND], beta;
@@ -305,13 +315,16 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
     }
     __syncthreads();
     // phase B: the threads share the (sA, sB) pairs of the stencil; blocks are summed over the chunk
-    for (int q = threadIdx.x; q < MAXM * MAXM; q += 256) {
-      const int sA = q / MAXM, sB = q - sA * MAXM;
+    // (every lane of a wave makes the same trips: the staging below is wave-cooperative)
+    for (int q0 = wave * 64; q0 < MAXM * MAXM; q0 += TAN_NT) {
+      const int q = q0 + lane;
+      const bool valid = q < MAXM * MAXM;
+      const int sA = valid ? q / MAXM : 0, sB = valid ? q - sA * MAXM : 0;
       double acc[ND * ND];
 #pragma unroll
       for (int e = 0; e < ND * ND; e++) acc[e] = 0.0;
       bool any = false;
-      for (int jj = 0; jj < nb; jj++) {
+      for (int jj = 0; valid && jj < nb; jj++) {
         const bool inA = sA < 64 ? (mem[jj][0] >> sA) & 1ull : (mem[jj][1] >> (sA - 64)) & 1ull;
         const bool inB = sB < 64 ? (mem[jj][0] >> sB) & 1ull : (mem[jj][1] >> (sB - 64)) & 1ull;
         if (!(inA && inB)) continue;
@@ -372,14 +385,26 @@ __global__ __launch_bounds__(256) void k_tangent_nh_grouped(PView P, GridD g, co
           for (int j = 0; j < ND; j++)
             acc[i * ND + j] += k0c * g1[jj][sA][i] * g1[jj][sB][j] + (i == j ? kG : 0.0) + k1c * g1[jj][sA][j] * g1[jj][sB][i];
       }
-      if (!any) continue;
       const int ia = sA % 5, ja = (sA / 5) % 5, ka = sA / 25;
       const int nodeA = (i0 + ia - 2) + g.n[0] * ((j0 + ja - 2) + (ND == 3 ? g.n[1] * (k0 + ka - 2) : 0));
-      const size_t blk = (size_t)nodeA * S + tangent_offset_index<ND>(sA, sB);
-      double* out = Kst + blk * (ND * ND);
+      const long long blk = any ? (long long)nodeA * S + tangent_offset_index<ND>(sA, sB) : -1ll;
+      if (any) touched[blk] = 1;
+      constexpr int E = ND * ND;
 #pragma unroll
-      for (int e = 0; e < ND * ND; e++) atomic_add_f64(out + e, acc[e]);
-      touched[blk] = 1;
+      for (int e = 0; e < E; e++) stage_v[wave][lane * E + e] = acc[e];
+      stage_b[wave][lane] = blk;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int t = 0; t < E; t++) {
+        const int m = t * 64 + lane;  // element m of the wave's 64 x E doubles: block m / E, entry m % E
+        const long long b = stage_b[wave][m / E];
+        const double v = stage_v[wave][m];
+        if (b >= 0) atomic_add_f64(Kst + (size_t)b * E + (m % E), v);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // (the staging rows are rewritten by the next trip)
     }
   }
 }
