@@ -210,7 +210,8 @@ def bench_tangent(a):
         S.constitutive_update()
         Mv = S.compute_nodal_lumped_mass()
         S.jacobian_evaluation(1.0, Mv, True)  # warm-up (allocates the stencil array)
-        t_asm, t_all = [], []
+        t_asm, t_all, t_dev = [], [], []
+        S.jacobian_evaluation(1.0, Mv, True, on_device=True)  # (warm-up of the device-output form: torch's allocator)
         for _ in range(max(3, a.steps // 4)):
             nnz = C.c_longlong(0)
             t0 = time.perf_counter()
@@ -219,6 +220,9 @@ def bench_tangent(a):
             t0 = time.perf_counter()
             rows, cols, vals = S.jacobian_evaluation(1.0, Mv, True)
             t_all.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()  # assembly + triplets written into device arrays (MatSetValuesCOO of a GPU matrix type)
+            S.jacobian_evaluation(1.0, Mv, True, on_device=True)
+            t_dev.append(time.perf_counter() - t0)
         nn, _ = S.download_lists()
         pairs = float((nn.astype(np.int64) ** 2).sum())
         ta = float(np.median(t_asm))
@@ -226,6 +230,7 @@ def bench_tangent(a):
                "workload": name, "ndim": ndim, "particles": int(case["cloud"]["x"].shape[0]),
                "mean_neighbours": float(nn.mean()), "pair_blocks": pairs, "nnz": int(rows.size),
                "assemble_ms": 1e3 * ta, "assemble_plus_coo_download_ms": 1e3 * float(np.median(t_all)),
+               "assemble_plus_coo_on_device_ms": 1e3 * float(np.median(t_dev)),
                "value": pairs / ta, "unit": "blocks/s", "dtype": "f64", "data": "synthetic", "n_gpus": 1}
         if cpu:
             out["cpu_baseline"] = cpu[ndim]

@@ -4720,7 +4720,7 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
     if (ND == 2) hipLaunchKernelGGL(k_tangent_nh<2>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
     else hipLaunchKernelGGL(k_tangent_nh<3>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
   }
-  LAUNCH_ND((k_tangent_count<2>), (k_tangent_count<3>), nblk((int)nn), (int)nn, h->ktouched_d, h->kcnt_d);
+  LAUNCH_ND((k_tangent_count<2>), (k_tangent_count<3>), ((int)nn + 3) / 4, (int)nn, h->ktouched_d, h->kcnt_d);  // (one wave per row node)
   HIPCHK(hipGetLastError());
   size_t bytes = h->kscan_bytes;
   HIPCHK(hipcub::DeviceScan::ExclusiveSum(h->kscan_tmp, bytes, h->kcnt_d, h->koffs_d, (int)nn + 1, h->stream));
@@ -4753,12 +4753,19 @@ extern "C" int nlps_gpu_tangent_coo(nlps_gpu* h, double alpha_1, const double* l
     HIPCHK(hipMemcpyAsync(h->maskedA, lumped_mass, (size_t)h->nactive * ND * sizeof(double), hipMemcpyDefault, h->stream));
     mass_d = h->maskedA;
   }
+  if (is_device_ptr(rows) && is_device_ptr(cols) && is_device_ptr(vals)) {  // (MatSetValuesCOO of a GPU matrix type: no staging)
+    LAUNCH_ND((k_tangent_emit<2>), (k_tangent_emit<3>), (nn + 3) / 4, nn, h->g, h->ktouched_d, h->kst_d, h->koffs_d, h->n2m_d,
+              apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows, cols, vals);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   int *rows_d = nullptr, *cols_d = nullptr;
   double* vals_d = nullptr;
   HIPCHK(hipMalloc((void**)&rows_d, ne * sizeof(int)));
   HIPCHK(hipMalloc((void**)&cols_d, ne * sizeof(int)));
   HIPCHK(hipMalloc((void**)&vals_d, ne * sizeof(double)));
-  LAUNCH_ND((k_tangent_emit<2>), (k_tangent_emit<3>), nblk(nn), nn, h->g, h->ktouched_d, h->kst_d, h->koffs_d, h->n2m_d,
+  LAUNCH_ND((k_tangent_emit<2>), (k_tangent_emit<3>), (nn + 3) / 4, nn, h->g, h->ktouched_d, h->kst_d, h->koffs_d, h->n2m_d,
             apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows_d, cols_d, vals_d);
   int st = 0;
   if (hipGetLastError() != hipSuccess) st = 1;

@@ -409,16 +409,17 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
   }
 }
 
-// number of structurally visited blocks of every row node (both ends active by construction)
+// number of structurally visited blocks of every row node (both ends active by construction); one wave per row node
 template <int ND>
-__global__ void k_tangent_count(int nnodes, const unsigned char* __restrict__ touched, int* __restrict__ cnt) {
+__global__ __launch_bounds__(256) void k_tangent_count(int nnodes, const unsigned char* __restrict__ touched, int* __restrict__ cnt) {
   constexpr int S = TanCfg<ND>::S;
-  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int A = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (A >= nnodes) return;
-  int c = 0;
   const unsigned char* t = touched + (size_t)A * S;
-  for (int s = 0; s < S; s++) c += t[s];
-  cnt[A] = c;
+  int c = 0;
+  for (int s0 = 0; s0 < S; s0 += 64) c += (int)__popcll(__ballot(s0 + lane < S && t[s0 + lane]));
+  if (lane == 0) cnt[A] = c;
 }
 
 // __create_sparsity_pattern, U-Newmark-beta.c:1568-1632: visited columns per dof row (masked numbering)
@@ -431,36 +432,47 @@ __global__ void k_tangent_pattern(int nnodes, const int* __restrict__ cnt, const
   for (int i = 0; i < ND; i++) pattern[n2m[A] * ND + i] = ND * cnt[A];
 }
 
-// COO triplets in masked dof numbering; entry order: row node (grid order), stencil offset, i, j
+// COO triplets in masked dof numbering; entry order: row node (grid order), stencil offset, i, j.  One wave per row
+// node: it lists the node's visited offsets in LDS (ballots keep them ascending), then its lanes follow the node's
+// triplets element by element -- reads of the stencil array and writes of rows / cols / vals are contiguous (one thread
+// per row node walking its 729 offsets wrote 36 / 72 bytes apart from its neighbours: 60 GB/s).
 template <int ND>
-__global__ void k_tangent_emit(int nnodes, GridD g, const unsigned char* __restrict__ touched,
-                               const double* __restrict__ Kst, const int* __restrict__ offs,
-                               const int* __restrict__ n2m, const int* __restrict__ d2m, double alpha_1,
-                               const double* __restrict__ mass, int* __restrict__ rows, int* __restrict__ cols,
-                               double* __restrict__ vals) {
-  constexpr int S = TanCfg<ND>::S;
-  const int A = blockIdx.x * blockDim.x + threadIdx.x;
-  if (A >= nnodes) return;
-  size_t e = (size_t)offs[A] * (ND * ND);
+__global__ __launch_bounds__(256) void k_tangent_emit(int nnodes, GridD g, const unsigned char* __restrict__ touched,
+                                                      const double* __restrict__ Kst, const int* __restrict__ offs,
+                                                      const int* __restrict__ n2m, const int* __restrict__ d2m, double alpha_1,
+                                                      const double* __restrict__ mass, int* __restrict__ rows,
+                                                      int* __restrict__ cols, double* __restrict__ vals) {
+  constexpr int S = TanCfg<ND>::S, E = ND * ND;
+  __shared__ unsigned short list[4][S];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int A = blockIdx.x * 4 + wave;
+  if (A >= nnodes) return;  // (whole waves: the kernel has no workgroup barrier)
+  const unsigned char* t = touched + (size_t)A * S;
+  int cnt = 0;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool on = s < S && t[s];
+    const u64 bal = __ballot(on);
+    if (on) list[wave][cnt + (int)__popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)s;
+    cnt += (int)__popcll(bal);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int mA = n2m[A];
-  for (int s = 0; s < S; s++) {
-    if (!touched[(size_t)A * S + s]) continue;
+  const size_t e0 = (size_t)offs[A] * E;
+  for (int m = lane; m < cnt * E; m += 64) {
+    const int bp = m / E, e = m - bp * E, s = list[wave][bp];
     const int dx = s % 9 - 4, dy = (s / 9) % 9 - 4, dz = (ND == 3) ? s / 81 - 4 : 0;
     const int B = A + dx + g.n[0] * (dy + g.n[1] * dz);
     const int mB = n2m[B];
-    const double* blk = Kst + ((size_t)A * S + s) * (ND * ND);
-#pragma unroll
-    for (int i = 0; i < ND; i++)
-#pragma unroll
-      for (int j = 0; j < ND; j++) {
-        const int ra = mA * ND + i, cb = mB * ND + j;
-        double v = blk[i * ND + j];
-        if (ra == cb && mass) v += alpha_1 * mass[ra];  // :1797-1807
-        if (d2m && (d2m[ra] == -1 || d2m[cb] == -1)) v = (ra == cb) ? 1.0 : 0.0;  // MatZeroRowsColumnsIS, :1822
-        rows[e] = ra;
-        cols[e] = cb;
-        vals[e] = v;
-        e++;
-      }
+    const int i = e / ND, j = e - i * ND;
+    const int ra = mA * ND + i, cb = mB * ND + j;
+    double v = Kst[((size_t)A * S + s) * E + e];
+    if (ra == cb && mass) v += alpha_1 * mass[ra];  // :1797-1807
+    if (d2m && (d2m[ra] == -1 || d2m[cb] == -1)) v = (ra == cb) ? 1.0 : 0.0;  // MatZeroRowsColumnsIS, :1822
+    rows[e0 + m] = ra;
+    cols[e0 + m] = cb;
+    vals[e0 + m] = v;
   }
 }

@@ -551,14 +551,22 @@ class Solver:
             0 if loads is None else loads.n, int(step), float(thickness), None if a0 is None else a0.ctypes.data, int(flags)))
         return R
 
-    def jacobian_evaluation(self, alpha_1=0.0, lumped_mass=None, apply_dirichlet=False):  # __jacobian_evaluation
-        """COO triplets (rows, cols, vals) of the tangent matrix in masked dof numbering (Neo-Hookean)."""
+    def jacobian_evaluation(self, alpha_1=0.0, lumped_mass=None, apply_dirichlet=False, on_device=False):  # __jacobian_evaluation
+        """COO triplets (rows, cols, vals) of the tangent matrix in masked dof numbering.  on_device: torch tensors on
+        the GPU, written by the emit kernel itself (what MatSetValuesCOO of a GPU matrix type takes; nothing crosses PCIe)."""
         nnz = C.c_longlong(0)
         self._chk(self.L.nlps_gpu_tangent_assemble(self.h, C.byref(nnz)))
         n = int(nnz.value)
-        rows, cols, vals = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n)
+        self.L.nlps_gpu_tangent_coo.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        if on_device:
+            import torch
+            rows = torch.empty(n, dtype=torch.int32, device="cuda")
+            cols = torch.empty(n, dtype=torch.int32, device="cuda")
+            vals = torch.empty(n, dtype=torch.float64, device="cuda")
+        else:
+            rows, cols, vals = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n)
         self._chk(self.L.nlps_gpu_tangent_coo(self.h, float(alpha_1), _vp(lumped_mass), 1 if apply_dirichlet else 0,
-                                              _i(rows), _i(cols), _d(vals)))
+                                              _vp(rows), _vp(cols), _vp(vals)))
         return rows, cols, vals
 
     def create_sparsity_pattern(self):                  # __create_sparsity_pattern (after jacobian_evaluation)

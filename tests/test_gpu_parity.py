@@ -411,6 +411,10 @@ def test_tangent_matrix_neo_hookean(ndim):
         assert np.unique(key).size == key.size
         assert np.array_equal(S.create_sparsity_pattern(), pat_o), "sparsity pattern"
         assert np.array_equal(np.bincount(rows, minlength=ntot), pat_o), "COO rows vs pattern"
+        # triplets written into device arrays by the emit kernel itself: the same triplets, in the same order
+        rd, cd, vd = S.jacobian_evaluation(alpha_1, mass, dirichlet, on_device=True)
+        assert np.array_equal(rd.cpu().numpy(), rows) and np.array_equal(cd.cpu().numpy(), cols)
+        assert_close(vd.cpu().numpy(), vals, 1e-12, "device-resident COO arrays", scale=np.abs(vals).max())
         # the one-wave-per-particle form gives the same matrix
         S.L.nlps_gpu_tangent_set_grouped(S.h, 0)
         rows2, cols2, vals2 = S.jacobian_evaluation(alpha_1, mass, dirichlet)
