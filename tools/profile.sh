@@ -9,6 +9,7 @@
 #             FETCH_SIZE / WRITE_SIZE, two SQ groups
 #   twod      bench.py --workload step2d (2-D, 1 M particles): stats, FETCH_SIZE / WRITE_SIZE, two SQ groups
 #   dp        tools/kbench.py --law dp | hencky: stats, and the SQ groups for Drucker-Prager
+#   tangent   bench.py --workload tangent: the plain run (-> profiles/<tag>_tangent_bench.jsonl) and kernel stats
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p build/exp
 [ -x build/exp/hbm_calib ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o build/exp/hbm_calib tools/hbm_calib.hip
@@ -47,6 +48,10 @@ for PART in $PARTS; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/twod_stats -- python3 bench.py --workload step2d --steps 20 --warmup 5 > $O.twod.log 2>&1
     pmc_passes twod SQ2 python3 bench.py --workload step2d --steps 3 --warmup 2
     tail -1 $O.twod.log | cut -c1-200 ;;
+  tangent)
+    python3 bench.py --workload tangent > $O.tangent_bench.jsonl 2> /dev/null
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/tangent_stats -- python3 bench.py --workload tangent --no-cpu-baseline > $O.tangent.log 2>&1
+    tail -1 $O.tangent_bench.jsonl | cut -c1-200 ;;
   dp)
     for LAW in hencky dp; do
       rocprofv3 --kernel-trace --stats --output-format csv -d $O/kbench_${LAW}_stats -- python3 tools/kbench.py --law $LAW > $O.kbench_$LAW.log 2>&1
