@@ -1570,6 +1570,8 @@ struct nlps_gpu {
   size_t kscan_bytes = 0;
   long long knnz_blocks = -1;
   bool tangent_grouped = true;  // one workgroup per closest node (false: one wave per particle, kept for comparison)
+  bool tangent_symmetric = true;  // Neo-Hookean clouds: only the upper half of every row is assembled (nlps_gpu_debug_option "tangent_symmetric")
+  bool ktan_sym = false;          // how the last nlps_gpu_tangent_assemble filled the stencil array (nlps_gpu_tangent_coo mirrors the rest)
   int* order_d;
   int* order2_d = nullptr;  // canonical tile lists (k_tile_order), allocated on first use
 
@@ -2367,6 +2369,7 @@ extern "C" __attribute__((visibility("default"))) int nlps_gpu_debug_option(nlps
   else if (k == "node_lists") h->node_lists_on = (int)value;
   else if (k == "tile_ordering") h->tile_ordering = (int)value;
   else if (k == "defer_ranks") h->defer_ranks = (int)value;  // the riding search only counts, k_fill_orders hands out the ranks
+  else if (k == "tangent_symmetric") h->tangent_symmetric = value != 0;  // Neo-Hookean clouds: half rows + mirror (1) or every pair (0)
   else {
     h->err = "nlps_gpu_debug_option: unknown option " + k;
     return 1;
@@ -4701,6 +4704,7 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
   HIPCHK(hipMemsetAsync(h->ktouched_d, 0, nblk_st, h->stream));
   HIPCHK(hipMemsetAsync(h->kcnt_d, 0, (nn + 1) * sizeof(int), h->stream));
   const int np = h->P.np;
+  h->ktan_sym = false;
   if (np > 0 && h->tangent_grouped) {
     // particles grouped by closest node (radix sort of (I0, p) in the re-sort buffers), one workgroup per node
     hipLaunchKernelGGL(k_tangent_keys, dim3(nblk(np)), dim3(BLK), 0, h->stream, h->P, h->skey_d, h->sval_d);
@@ -4710,13 +4714,16 @@ extern "C" int nlps_gpu_tangent_assemble(nlps_gpu* h, long long* nnz) {
     HIPCHK(hipMemsetAsync(h->kng_d, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_tangent_groups, dim3(nblk(np)), dim3(BLK), 0, h->stream, np, h->skey2_d, h->khead_d, h->kng_d);
     const int ngrid = std::min(np, h->g.nnodes);  // upper bound of the number of groups; surplus workgroups exit
+    // a cloud of Neo-Hookean particles only: the upper half of every row, the rest by symmetry in nlps_gpu_tangent_coo
+    h->ktan_sym = h->tangent_symmetric && h->uniform_law == NLPS_MAT_NEO_HOOKEAN;
     if (ND == 2)
       hipLaunchKernelGGL(k_tangent_nh_grouped<2>, dim3(ngrid), dim3(TAN_NT), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
-                         h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d);
+                         h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d, h->ktan_sym ? 1 : 0);
     else
       hipLaunchKernelGGL(k_tangent_nh_grouped<3>, dim3(ngrid), dim3(TAN_NT), 0, h->stream, h->P, h->g, h->mats_d, np, h->skey2_d,
-                         h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d);
+                         h->sval2_d, h->khead_d, h->kng_d, h->kst_d, h->ktouched_d, h->gstatus_d, h->ktan_sym ? 1 : 0);
   } else if (np > 0) {
+    h->ktan_sym = false;
     if (ND == 2) hipLaunchKernelGGL(k_tangent_nh<2>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
     else hipLaunchKernelGGL(k_tangent_nh<3>, dim3(np), dim3(64), 0, h->stream, h->P, h->g, h->mats_d, h->kst_d, h->ktouched_d, h->gstatus_d);
   }
@@ -4755,7 +4762,7 @@ extern "C" int nlps_gpu_tangent_coo(nlps_gpu* h, double alpha_1, const double* l
   }
   if (is_device_ptr(rows) && is_device_ptr(cols) && is_device_ptr(vals)) {  // (MatSetValuesCOO of a GPU matrix type: no staging)
     LAUNCH_ND((k_tangent_emit<2>), (k_tangent_emit<3>), (nn + 3) / 4, nn, h->g, h->ktouched_d, h->kst_d, h->koffs_d, h->n2m_d,
-              apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows, cols, vals);
+              apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows, cols, vals, h->ktan_sym ? 1 : 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -4766,7 +4773,7 @@ extern "C" int nlps_gpu_tangent_coo(nlps_gpu* h, double alpha_1, const double* l
   HIPCHK(hipMalloc((void**)&cols_d, ne * sizeof(int)));
   HIPCHK(hipMalloc((void**)&vals_d, ne * sizeof(double)));
   LAUNCH_ND((k_tangent_emit<2>), (k_tangent_emit<3>), (nn + 3) / 4, nn, h->g, h->ktouched_d, h->kst_d, h->koffs_d, h->n2m_d,
-            apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows_d, cols_d, vals_d);
+            apply_dirichlet ? h->d2m_d : (const int*)nullptr, alpha_1, mass_d, rows_d, cols_d, vals_d, h->ktan_sym ? 1 : 0);
   int st = 0;
   if (hipGetLastError() != hipSuccess) st = 1;
   if (!st && hipMemcpyAsync(rows, rows_d, ne * sizeof(int), hipMemcpyDefault, h->stream) != hipSuccess) st = 1;

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
                                                             const int* __restrict__ sorted, const int* __restrict__ head,
                                                             const int* __restrict__ ngroups, double* __restrict__ Kst,
                                                             unsigned char* __restrict__ touched,
-                                                            int* __restrict__ gstatus) {
+                                                            int* __restrict__ gstatus, int sym) {
   constexpr int S = TanCfg<ND>::S, MAXM = TanCfg<ND>::MAXM, KN = Lme<ND>::KN;
   __shared__ double gn[TAN_GROUP][MAXM][ND], g1[TAN_GROUP][MAXM][ND], ub[TAN_GROUP][MAXM][ND];
   __shared__ double coef[TAN_GROUP][3];  // V0*c0, V0*c1, V0*G of each particle (Neo-Hookean)
@@ -316,10 +316,36 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
     __syncthreads();
     // phase B: the threads share the (sA, sB) pairs of the stencil; blocks are summed over the chunk
     // (every lane of a wave makes the same trips: the staging below is wave-cooperative)
-    for (int q0 = wave * 64; q0 < MAXM * MAXM; q0 += TAN_NT) {
+    // sym (a cloud of Neo-Hookean particles only: block (B, A) is the transpose of block (A, B), Neo-Hookean.c:89-141):
+    // only the pairs with sB >= sA are assembled -- in the stencil code s = i + 5 j + 25 k that is exactly "offset B - A
+    // lexicographically >= 0", the upper half of every row of the stencil array -- and k_tangent_emit reads the lower
+    // half from the mirrored block.  Half the added bytes, which are what this kernel's time is.  The triangle is
+    // walked as H = MAXM / 2 double rows (row r with its MAXM - r pairs + row MAXM - 1 - r with its r + 1) of MAXM + 1
+    // pairs and the middle row, so that consecutive lanes still follow consecutive sB.
+    constexpr int H = MAXM / 2, NPAIR_SYM = H * (MAXM + 1) + H + 1;
+    const int npair = sym ? NPAIR_SYM : MAXM * MAXM;
+    for (int q0 = wave * 64; q0 < npair; q0 += TAN_NT) {
       const int q = q0 + lane;
-      const bool valid = q < MAXM * MAXM;
-      const int sA = valid ? q / MAXM : 0, sB = valid ? q - sA * MAXM : 0;
+      const bool valid = q < npair;
+      int sA = 0, sB = 0;
+      if (valid && !sym) {
+        sA = q / MAXM;
+        sB = q - sA * MAXM;
+      } else if (valid) {
+        if (q < H * (MAXM + 1)) {
+          const int r = q / (MAXM + 1), c = q - r * (MAXM + 1);
+          if (c < MAXM - r) {
+            sA = r;
+            sB = r + c;
+          } else {
+            sA = MAXM - 1 - r;
+            sB = sA + (c - (MAXM - r));
+          }
+        } else {
+          sA = H;
+          sB = H + (q - H * (MAXM + 1));
+        }
+      }
       double acc[ND * ND];
 #pragma unroll
       for (int e = 0; e < ND * ND; e++) acc[e] = 0.0;
@@ -387,8 +413,16 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
       }
       const int ia = sA % 5, ja = (sA / 5) % 5, ka = sA / 25;
       const int nodeA = (i0 + ia - 2) + g.n[0] * ((j0 + ja - 2) + (ND == 3 ? g.n[1] * (k0 + ka - 2) : 0));
-      const long long blk = any ? (long long)nodeA * S + tangent_offset_index<ND>(sA, sB) : -1ll;
-      if (any) touched[blk] = 1;
+      const int oAB = tangent_offset_index<ND>(sA, sB);
+      const long long blk = any ? (long long)nodeA * S + oAB : -1ll;
+      if (any) {
+        touched[blk] = 1;
+        if (sym && sB != sA) {  // the structural visit of the mirrored pair (B, A), whose values the emit kernel derives
+          const int ib = sB % 5, jb = (sB / 5) % 5, kb = sB / 25;
+          const int nodeB = (i0 + ib - 2) + g.n[0] * ((j0 + jb - 2) + (ND == 3 ? g.n[1] * (k0 + kb - 2) : 0));
+          touched[(size_t)nodeB * S + (S - 1 - oAB)] = 1;
+        }
+      }
       constexpr int E = ND * ND;
 #pragma unroll
       for (int e = 0; e < E; e++) stage_v[wave][lane * E + e] = acc[e];
@@ -441,7 +475,7 @@ __global__ __launch_bounds__(256) void k_tangent_emit(int nnodes, GridD g, const
                                                       const double* __restrict__ Kst, const int* __restrict__ offs,
                                                       const int* __restrict__ n2m, const int* __restrict__ d2m, double alpha_1,
                                                       const double* __restrict__ mass, int* __restrict__ rows,
-                                                      int* __restrict__ cols, double* __restrict__ vals) {
+                                                      int* __restrict__ cols, double* __restrict__ vals, int sym) {
   constexpr int S = TanCfg<ND>::S, E = ND * ND;
   __shared__ unsigned short list[4][S];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -468,7 +502,8 @@ __global__ __launch_bounds__(256) void k_tangent_emit(int nnodes, GridD g, const
     const int mB = n2m[B];
     const int i = e / ND, j = e - i * ND;
     const int ra = mA * ND + i, cb = mB * ND + j;
-    double v = Kst[((size_t)A * S + s) * E + e];
+    // sym: the lower half of a row (offset before the centre) was not assembled: block (A, B) = block (B, A)^T
+    double v = (sym && s < S / 2) ? Kst[((size_t)B * S + (S - 1 - s)) * E + (j * ND + i)] : Kst[((size_t)A * S + s) * E + e];
     if (ra == cb && mass) v += alpha_1 * mass[ra];  // :1797-1807
     if (d2m && (d2m[ra] == -1 || d2m[cb] == -1)) v = (ra == cb) ? 1.0 : 0.0;  // MatZeroRowsColumnsIS, :1822
     rows[e0 + m] = ra;

@@ -415,6 +415,13 @@ def test_tangent_matrix_neo_hookean(ndim):
         rd, cd, vd = S.jacobian_evaluation(alpha_1, mass, dirichlet, on_device=True)
         assert np.array_equal(rd.cpu().numpy(), rows) and np.array_equal(cd.cpu().numpy(), cols)
         assert_close(vd.cpu().numpy(), vals, 1e-12, "device-resident COO arrays", scale=np.abs(vals).max())
+        # a Neo-Hookean cloud assembles the upper half of every row only and mirrors the rest: every pair assembled
+        # gives the same triplets (sums in another order)
+        S.debug_option("tangent_symmetric", 0)
+        rows3, cols3, vals3 = S.jacobian_evaluation(alpha_1, mass, dirichlet)
+        S.debug_option("tangent_symmetric", 1)
+        assert np.array_equal(rows3, rows) and np.array_equal(cols3, cols)
+        assert_close(vals3, vals, 1e-12, "every pair vs upper half + mirror", scale=np.abs(vals).max())
         # the one-wave-per-particle form gives the same matrix
         S.L.nlps_gpu_tangent_set_grouped(S.h, 0)
         rows2, cols2, vals2 = S.jacobian_evaluation(alpha_1, mass, dirichlet)
