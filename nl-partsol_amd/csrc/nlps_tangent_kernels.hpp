@@ -178,6 +178,11 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
   // of b, eigenvalues of the Kirchhoff block, moduli (AA or C_ep), the Kirchhoff block itself, V0
   __shared__ double sp_n[TAN_GROUP][ND * ND], sp_lam[TAN_GROUP][ND], sp_tauv[TAN_GROUP][ND], sp_C[TAN_GROUP][ND * ND],
       sp_tau[TAN_GROUP][ND * ND], sp_V0[TAN_GROUP];
+  // spectral laws: the block of a node pair is bilinear in the pushed-forward gradients of its two nodes,
+  // K_ij = sum_kl g1_A[k] g1_B[l] D[k][l][i][j] with ONE fourth-order tensor per particle (V0 folded in, built in phase A
+  // from the arrays above): phase B then costs d^2 products + d^4 FMAs per pair and particle instead of re-deriving the
+  // principal-axes moduli (three divisions among them) for each of the particle's 15 625 pairs
+  __shared__ __attribute__((aligned(16))) double spD[TAN_GROUP][(ND * ND * ND * ND + 1) & ~1];  // (rows of an even number of doubles: read as double2)
   __shared__ int law_of[TAN_GROUP];
   __shared__ u64 mem[TAN_GROUP][2];
   __shared__ double tab[TAN_NW][6][5];  // per wave: ex, ey, ez, lx, ly, lz of the particle it is building
@@ -274,6 +279,35 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
       }
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
+      if (spectral) {
+        // D[k][l][i][j] = V0 ( -delta_kj tau_il + sum_AB C_AB N_kA N_lB N_iA N_jB
+        //                      + sum_{A != B, |lam_B - lam_A| > 1e-14} hq_AB (lam_A N_lA N_kB N_iA N_jB + lam_B N_kB N_lB N_iA N_jA) ),
+        // hq_AB = (tau_B - tau_A) / (2 (lam_B - lam_A)), N_iA = component i of eigenvector A of b: the expansion of
+        // W_AB + delta_AB D_A of the comment in phase B with a = N^T g1_A, b = N^T g1_B, minus (tau g1_B) (x) g1_A
+        constexpr int E4 = ND * ND * ND * ND;
+        for (int e4 = lane; e4 < E4; e4 += 64) {
+          const int j = e4 % ND, i = (e4 / ND) % ND, l = (e4 / (ND * ND)) % ND, k = e4 / (ND * ND * ND);
+          double v = (k == j) ? -sp_tau[jj][i * ND + l] : 0.0;
+#pragma unroll
+          for (int A = 0; A < ND; A++) {
+            const double NiA = sp_n[jj][A + i * ND], NkA = sp_n[jj][A + k * ND], NlA = sp_n[jj][A + l * ND], NjA = sp_n[jj][A + j * ND];
+#pragma unroll
+            for (int B = 0; B < ND; B++) {
+              const double NjB = sp_n[jj][B + j * ND], NlB = sp_n[jj][B + l * ND], NkB = sp_n[jj][B + k * ND];
+              v = fma(sp_C[jj][A * ND + B] * NkA * NlB, NiA * NjB, v);
+              if (A != B) {
+                const double dl = sp_lam[jj][B] - sp_lam[jj][A];
+                if (fabs(dl) > 1E-14) {
+                  const double hq = 0.5 * ((sp_tauv[jj][B] - sp_tauv[jj][A]) / dl);
+                  v = fma(hq * sp_lam[jj][A] * NlA * NkB, NiA * NjB, v);
+                  v = fma(hq * sp_lam[jj][B] * NkB * NlB, NiA * NjA, v);
+                }
+              }
+            }
+          }
+          spD[jj][e4] = ok ? sp_V0[jj] * v : 0.0;
+        }
+      }
       for (int s = lane; s < MAXM; s += 64) {
         const bool on = ok && c.on(s);
         const int i = s % 5, j = (s / 5) % 5, k = s / 25;
@@ -359,46 +393,28 @@ __global__ __launch_bounds__(TAN_NT) void k_tangent_nh_grouped(PView P, GridD g,
           // K = V0 [ sum_AB (W_AB + delta_AB D_A) n_A (x) n_B - (tau g1_B) (x) g1_A ],  a = proj(sA), b = proj(sB):
           // W_AB = C_AB a_A b_B + [A != B] 1/2 q_AB lam_A b_A a_B ,  D_A = sum_{B != A} 1/2 q_AB lam_B a_B b_B ,
           // q_AB = (tau_B - tau_A) / (lam_B - lam_A) where |lam_B - lam_A| > 1e-14
-          double a[ND], b[ND], Wm[ND * ND];
+          // -- as the contraction of the particle's tensor spD (phase A) with g1_A (x) g1_B
+          // (the tensor is the same for every lane: read as double2, ds_read_b128 broadcasts -- pairs of ds_read2_b64, which
+          // the back end forms from scalar reads, take twice the LDS cycles)
+          constexpr int E = ND * ND, E4 = E * E;
+          double o[E];
 #pragma unroll
-          for (int A = 0; A < ND; A++) {
-            a[A] = gn[jj][sA][A];
-            b[A] = gn[jj][sB][A];
+          for (int k = 0; k < ND; k++)
+#pragma unroll
+            for (int l = 0; l < ND; l++) o[k * ND + l] = g1[jj][sA][k] * g1[jj][sB][l];
+          const double2* D2 = reinterpret_cast<const double2*>(&spD[jj][0]);
+          // all reads first, then the arithmetic (the scheduler otherwise alternates them with a wait each: at two waves
+          // per SIMD the LDS latency of ~40 such waits per pair and particle was most of this path's time)
+          double2 d[(E4 + 1) / 2];
+#pragma unroll
+          for (int t = 0; t < (E4 + 1) / 2; t++) d[t] = D2[t];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < E4 / 2; t++) {
+            acc[(2 * t) % E] = fma(o[(2 * t) / E], d[t].x, acc[(2 * t) % E]);
+            acc[(2 * t + 1) % E] = fma(o[(2 * t + 1) / E], d[t].y, acc[(2 * t + 1) % E]);
           }
-#pragma unroll
-          for (int A = 0; A < ND; A++) {
-            double DA = 0.0;
-#pragma unroll
-            for (int B = 0; B < ND; B++) {
-              double w = sp_C[jj][A * ND + B] * a[A] * b[B];
-              if (A != B) {
-                const double dl = sp_lam[jj][B] - sp_lam[jj][A];
-                if (fabs(dl) > 1E-14) {
-                  const double hq = 0.5 * ((sp_tauv[jj][B] - sp_tauv[jj][A]) / dl);
-                  w += hq * sp_lam[jj][A] * b[A] * a[B];
-                  DA += hq * sp_lam[jj][B] * a[B] * b[B];
-                }
-              }
-              Wm[A * ND + B] = w;
-            }
-            Wm[A * ND + A] += DA;
-          }
-          const double V0 = sp_V0[jj];
-#pragma unroll
-          for (int i = 0; i < ND; i++) {
-            double tb = 0.0;  // (tau g1_B)[i]
-#pragma unroll
-            for (int k2 = 0; k2 < ND; k2++) tb = fma(sp_tau[jj][i * ND + k2], g1[jj][sB][k2], tb);
-#pragma unroll
-            for (int j = 0; j < ND; j++) {
-              double v = -tb * g1[jj][sA][j];
-#pragma unroll
-              for (int A = 0; A < ND; A++)
-#pragma unroll
-                for (int B = 0; B < ND; B++) v = fma(Wm[A * ND + B], sp_n[jj][A + i * ND] * sp_n[jj][B + j * ND], v);
-              acc[i * ND + j] = fma(V0, v, acc[i * ND + j]);
-            }
-          }
+          if (E4 & 1) acc[(E4 - 1) % E] = fma(o[(E4 - 1) / E], d[E4 / 2].x, acc[(E4 - 1) % E]);
           continue;
         }
         double len0 = 0.0;
