@@ -1382,6 +1382,49 @@ __global__ void k_gather_fields(double* __restrict__ out, const double* __restri
   for (int f = f0; f < f1; f++) out[(size_t)f * npad + i] = in[(size_t)f * npad + j];
 }
 
+// the live components of the re-sort as ONE launch: blockIdx.y = group of GATHER_FIELDS entries of a list of components
+struct FieldList {
+  int n;
+  unsigned char f[128];
+};
+__global__ void k_gather_field_list(double* __restrict__ out, const double* __restrict__ in, const int* __restrict__ idx,
+                                    int n, size_t npad, FieldList fl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t j = (size_t)idx[i];
+  const int q0 = blockIdx.y * GATHER_FIELDS, q1 = min(fl.n, q0 + GATHER_FIELDS);
+  for (int q = q0; q < q1; q++) {
+    const size_t f = fl.f[q];
+    out[f * npad + i] = in[f * npad + j];
+  }
+}
+
+// the integer arrays of the particles (closest nodes, material, list length, status, permutation, ids; the two mask
+// words) through one scratch block: one gather launch and one copy-back launch instead of two per array
+struct SmallArrays {
+  int* ia[7];
+  unsigned long long* ua[2];
+};
+__global__ void k_gather_small(SmallArrays A, const int* __restrict__ idx, int n, size_t npad, int* __restrict__ si,
+                               unsigned long long* __restrict__ su) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = idx[i];
+#pragma unroll
+  for (int a = 0; a < 7; a++) si[(size_t)a * npad + i] = A.ia[a][j];
+#pragma unroll
+  for (int a = 0; a < 2; a++) su[(size_t)a * npad + i] = A.ua[a][j];
+}
+__global__ void k_copy_small(SmallArrays A, int n, size_t npad, const int* __restrict__ si,
+                             const unsigned long long* __restrict__ su) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int a = 0; a < 7; a++) A.ia[a][i] = si[(size_t)a * npad + i];
+#pragma unroll
+  for (int a = 0; a < 2; a++) A.ua[a][i] = su[(size_t)a * npad + i];
+}
+
 template <class T>
 __global__ void k_gather(T* __restrict__ out, const T* __restrict__ in, const int* __restrict__ idx, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2203,29 +2246,36 @@ static int resort(nlps_gpu* h, const unsigned char* leaving = nullptr, bool live
     // contiguous runs of live components (enum at the top of this file; F and b_e by their current n slots)
     const int fn = fFN(h->P), ben = fBEN(h->P);
     const int runs[][2] = {{F_X, 12}, {fn, 9}, {ben, 9}, {F_JN, 1}, {F_RHO, 3}, {F_KN, 1}, {F_EN, 1}, {F_LAM, 11}};
+    FieldList fl;
+    fl.n = 0;
     for (auto& r : runs)
-      hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (r[1] + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
-                         h->Pd_alt + (size_t)r[0] * npad, (const double*)h->P.d + (size_t)r[0] * npad, idx, np, npad, r[1]);
+      for (int q = 0; q < r[1]; q++) fl.f[fl.n++] = (unsigned char)(r[0] + q);
     if (h->nd == 2) {  // the zz slots of F_n+1 and DF are never written by the 2-D kernels (they stay 1 from the upload)
-      const int zz[2] = {fFN1(h->P) + 4, F_DF + 4};
-      for (int f : zz)
-        hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), 1), dim3(BLK), 0, h->stream, h->Pd_alt + (size_t)f * npad,
-                           (const double*)h->P.d + (size_t)f * npad, idx, np, npad, 1);
+      fl.f[fl.n++] = (unsigned char)(fFN1(h->P) + 4);
+      fl.f[fl.n++] = (unsigned char)(F_DF + 4);
     }
+    static_assert((int)NFD <= 255, "component indices travel as bytes");
+    hipLaunchKernelGGL(k_gather_field_list, dim3(nblk(np), (fl.n + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
+                       h->Pd_alt, (const double*)h->P.d, idx, np, npad, fl);
   } else {
     hipLaunchKernelGGL(k_gather_fields, dim3(nblk(np), (nf + GATHER_FIELDS - 1) / GATHER_FIELDS), dim3(BLK), 0, h->stream,
                        h->Pd_alt, (const double*)h->P.d, idx, np, npad, nf);
   }
   std::swap(h->P.d, h->Pd_alt);
-  int* iarr[] = {h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
-  for (int* a : iarr) {
-    hipLaunchKernelGGL(k_gather<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (int*)h->gather_tmp, a, idx, np);
-    hipLaunchKernelGGL(k_copy<int>, dim3(nblk(np)), dim3(BLK), 0, h->stream, a, (const int*)h->gather_tmp, np);
-  }
-  u64* uarr[] = {h->P.mlo, h->P.mhi};
-  for (u64* a : uarr) {
-    hipLaunchKernelGGL(k_gather<u64>, dim3(nblk(np)), dim3(BLK), 0, h->stream, (u64*)h->gather_tmp, a, idx, np);
-    hipLaunchKernelGGL(k_copy<u64>, dim3(nblk(np)), dim3(BLK), 0, h->stream, a, (const u64*)h->gather_tmp, np);
+  {
+    // (the twin block now holds the OLD field values, which nothing reads any more: its head is the scratch of the
+    // integer arrays -- 2 x npad doubles for the mask words, then 7 x npad ints)
+    SmallArrays A;
+    int* iarr[7] = {h->P.I0, h->P.I0n, h->P.mat, h->P.nn, h->P.status, h->perm_d, h->gid_d};
+    for (int a = 0; a < 7; a++) A.ia[a] = iarr[a];
+    A.ua[0] = h->P.mlo;
+    A.ua[1] = h->P.mhi;
+    static_assert((int)NFD >= 6, "the scratch of the integer arrays needs 2 + 3.5 components of the twin block");
+    unsigned long long* su = reinterpret_cast<unsigned long long*>(h->Pd_alt);
+    int* si = reinterpret_cast<int*>(h->Pd_alt + 2 * npad);
+    hipLaunchKernelGGL(k_gather_small, dim3(nblk(np)), dim3(BLK), 0, h->stream, A, idx, np, npad, si, su);
+    hipLaunchKernelGGL(k_copy_small, dim3(nblk(np)), dim3(BLK), 0, h->stream, A, np, npad, (const int*)si,
+                       (const unsigned long long*)su);
   }
   HIPCHK(hipGetLastError());
   h->perm_dirty = true;
