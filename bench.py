@@ -373,6 +373,17 @@ def bench_residual(a, stream=None, laws=("nh", "dp"), cpu=True, emit=True):
         agree = float(np.max(np.abs(r1 - R_d.cpu().numpy())) / max(np.max(np.abs(r1)), 1e-300))
         st = S.download_state(fields=["EPS_n1", "EPS_n"])
         yielding = float(np.mean(st["EPS_n1"] > st["EPS_n"]))
+        # the other half of a Newton iterate: __jacobian_evaluation from the state this evaluation left, triplets written
+        # into device arrays (MatSetValuesCOO of a GPU matrix type); a few repetitions, the first one allocates
+        tan = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rr, cc, vv = S.jacobian_evaluation(alpha[0], dev[3], True, on_device=True)
+            torch.cuda.synchronize()
+            tan.append(1e3 * (time.perf_counter() - t0))
+            nnz_t = int(vv.numel())
+            del rr, cc, vv
         flags = S.status_flags()
         npart = S.np
         S.close()
@@ -391,6 +402,10 @@ def bench_residual(a, stream=None, laws=("nh", "dp"), cpu=True, emit=True):
                             "host_vectors_same_step": fused_host_same},
                "separate_stages_ms": {"device_vectors": sep_dev, "host_vectors_VecGetArray": sep_host},
                "per_call_wall_ms": spikes, "fused_over_separate": sep_dev / fused_dev, "fused_vs_separate_max_rel_diff": agree, "status_flags": flags,
+               "tangent": {"ms_per_assembly_with_triplets_on_device": float(np.median(tan[1:])), "nnz": nnz_t,
+                           "note": "nlps_gpu_tangent_assemble + nlps_gpu_tangent_coo into device arrays at this state "
+                                   "(__jacobian_evaluation, U-Newmark-beta.c:1646-1830); python bench.py --workload tangent "
+                                   "has the per-case lines"},
                "roofline": {"bound": "hbm", "kernel": "k3_tile<3,%d,3> (MODE 3)" % (0 if law == "nh" else 2), "achieved": achieved,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                             "kernel_ms": k_ms, "algorithmic_bytes_per_particle": alg,
@@ -874,7 +889,8 @@ def main():
     if world == 1 and not a.no_implicit:  # the maintained driver's hot call at the same size (Neo-Hookean), short form
         r = bench_residual(a, stream=ctx.stream, laws=("nh",), cpu=False, emit=False)[0]
         implicit = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "fused_ms", "separate_stages_ms",
-                                      "fused_over_separate", "fused_vs_separate_max_rel_diff", "roofline", "status_flags")}
+                                      "fused_over_separate", "fused_vs_separate_max_rel_diff", "roofline", "status_flags",
+                                      "tangent")}
         implicit["workload"] = r["config"]["workload"]
     if rank == 0:
         npart = rec["particles_rank0"]
